@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of TSDF integrate + raycast (BASELINE.json metric) on N MI355X.
+
+A "step" is one pass of the hot path over one frame of the synthetic KITTI-like sequence
+(dynslam_amd/synth.py): UpdateView (inputs already resident in HBM) -> SetPose ->
+ProcessFrame (allocate + integrate) -> Prepare (expected depths + raycast + ICP maps).
+Workload = BASELINE.json configs[1]: static map only, 1242x375, 5 mm voxels, one GPU.
+With --gpus N every rank runs the same workload on its own volume (the path shards by
+volume): weak scaling, no data-path collective; value = N*K / max-rank time.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
+extra objects "roofline" (dominant kernel: integrate) and "cpu_baseline" (the CPU oracle on
+a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+PRESETS = {
+    # BASELINE.json "5mm voxels": upstream InfiniTAM indoor ratio mu = 4 * voxel
+    "5mm": dict(voxel_size=0.005, mu=0.02, sdf_local_block_num=1 << 23, hash_bucket_num=1 << 23,
+                excess_list_size=1 << 21),
+    "4mm": dict(voxel_size=0.004, mu=0.016, sdf_local_block_num=1 << 24, hash_bucket_num=1 << 24,
+                excess_list_size=1 << 22),
+    # the reference's own experiments: 5 cm voxels
+    "5cm": dict(voxel_size=0.05, mu=0.2, sdf_local_block_num=1 << 18, hash_bucket_num=1 << 20,
+                excess_list_size=1 << 17),
+    "3.5cm": dict(voxel_size=0.035, mu=0.14, sdf_local_block_num=1 << 19, hash_bucket_num=1 << 20,
+                  excess_list_size=1 << 17),
+}
+
+
+def _gen_frame(args):
+    from dynslam_amd.synth import StreetScene
+    w, h, i = args
+    rgba, d, T, _ = StreetScene(w, h).frame(i)
+    return rgba, d, T
+
+
+def make_frames(w, h, n):
+    procs = min(n, max(1, (os.cpu_count() or 2) - 1), 16)
+    if procs <= 1:
+        return [_gen_frame((w, h, i)) for i in range(n)]
+    with Pool(procs) as pool:
+        return pool.map(_gen_frame, [(w, h, i) for i in range(n)])
+
+
+def settings_kwargs(preset):
+    kw = dict(PRESETS[preset])
+    kw.update(max_w=100, view_frustum_min=0.2, view_frustum_max=30.0)
+    return kw
+
+
+def cpu_baseline(frames, w, h, preset, budget_s):
+    """The CPU oracle (kind "port": our restatement of ITMSceneReconstructionEngine_CPU +
+    ITMVisualisationEngine_CPU; the reference's own engines are not in /root/reference) on
+    the first frames of the same sequence, single thread, bounded by budget_s."""
+    from dynslam_amd.engine import make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, oracle_settings
+    kw = settings_kwargs(preset)
+    # the oracle keeps the voxel array in host RAM: size it for the sample only
+    kw["sdf_local_block_num"] = min(kw["sdf_local_block_num"], 1 << 20)
+    kw["hash_bucket_num"] = min(kw["hash_bucket_num"], 1 << 22)
+    kw["excess_list_size"] = min(kw["excess_list_size"], 1 << 20)
+    sc = StreetScene(w, h)
+    e = OracleEngine(oracle_settings(**kw), make_calib(*sc.intrinsics(), w, h), threads=1)
+    done, t_total = 0, 0.0
+    for rgba, d, T in frames:
+        e.update_view(rgba, d)
+        e.set_pose_inv_m(T)
+        t0 = time.perf_counter()
+        try:
+            e.process_frame()
+        except Exception:
+            break
+        e.prepare()
+        t_total += time.perf_counter() - t0
+        done += 1
+        if t_total > budget_s:
+            break
+    e.close()
+    if done == 0:
+        return None
+    return {"value": done / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} frames of the same sequence ({w}x{h}, preset {preset}), "
+                      f"allocate+integrate+raycast, oracle/dsr_oracle.cpp single thread, {t_total:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=45)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preset", default="5mm", choices=sorted(PRESETS))
+    ap.add_argument("--width", type=int, default=1242)
+    ap.add_argument("--height", type=int, default=375)
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--decay", action="store_true", help="also run voxel GC each frame (min_age 200, max_weight 1)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+    from dynslam_amd.synth import StreetScene
+
+    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
+    n_frames = Wm + K
+    frames = make_frames(W, H, n_frames)
+    # inputs resident in HBM before the timed region
+    rgb_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    dep_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    poses = [f[2] for f in frames]
+    torch.cuda.synchronize()
+
+    sc = StreetScene(W, H)
+    kw = settings_kwargs(args.preset)
+    eng = EngineCore(default_settings(**kw, device=local_rank, sync_status=0), make_calib(*sc.intrinsics(), W, H))
+
+    def step(i):
+        eng.update_view_dev(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr())
+        eng.set_pose_inv_m(poses[i])
+        eng.process_frame()
+        eng.prepare()
+        if args.decay:
+            eng.decay(1, 200, False)
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    for i in range(Wm):
+        step(i)
+    eng.sync()
+    if not args.no_profile:
+        eng.profile_enable(True)
+        eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_get() if not args.no_profile else []
+    eng.profile_enable(False)
+    stats = eng.get_stats()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_frames = K * world
+        roofline = None
+        kernels = {}
+        for r in prof:
+            kernels[r["name"]] = {"ms_total": round(r["total_ms"], 4), "launches": r["launches"],
+                                  "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
+                                  "GBps": round(r["bytes"] / (r["total_ms"] * 1e6), 1) if r["total_ms"] > 0 and r["bytes"] > 0 else None}
+            if r["name"] == "integrate" and r["total_ms"] > 0:
+                achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": None,
+                            "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
+                            "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}
+        cpu = None
+        if not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(frames, W, H, args.preset, args.cpu_budget_s)
+            except Exception as ex:  # the baseline must never take the bench line down
+                cpu = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {ex}"}
+        out = {
+            "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
+            "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: static map only, synthetic KITTI-like street {W}x{H}, "
+                                   f"preset {args.preset} (voxel {kw['voxel_size']} m, mu {kw['mu']} m), "
+                                   f"frames {Wm}..{Wm + K - 1} of a {n_frames}-frame sequence, one volume per GPU",
+                       "visible_blocks_last_frame": stats.no_visible_blocks,
+                       "allocated_blocks": kw["sdf_local_block_num"] - 1 - stats.last_free_block_id,
+                       "status": stats.sticky_status, "decay": bool(args.decay)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

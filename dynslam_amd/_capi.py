@@ -1,0 +1,133 @@
+"""ctypes declarations of the C ABI in include/dsr.h.
+
+`bind(lib, prefix)` attaches argtypes/restypes for every entry point the header
+declares; the product binds `dsr_` from libdsr_hip.so (engine.py), the test
+infrastructure binds `orc_` from oracle/liboracle.so (oracle/oracle.py).
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+ABI_VERSION = 1
+BLOCK_SIZE = 8
+BLOCK_SIZE3 = 512
+
+DSR_OK = 0
+DSR_E_ARG = 1
+DSR_E_DEVICE = 2
+DSR_E_OUT_OF_BLOCKS = 3
+DSR_E_NO_VIEW = 4
+DSR_E_NOMEM = 5
+
+IMAGE_ORIGINAL_RGB = 0
+IMAGE_ORIGINAL_DEPTH = 1
+IMAGE_SCENERAYCAST = 2
+IMAGE_FREECAMERA_SHADED = 3
+IMAGE_FREECAMERA_COLOUR_FROM_VOLUME = 4
+IMAGE_FREECAMERA_COLOUR_FROM_NORMAL = 5
+IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT = 6
+IMAGE_FREECAMERA_DEPTH = 7
+
+
+class HashEntry(C.Structure):
+    _fields_ = [("pos", C.c_int16 * 3), ("_pad", C.c_int16), ("offset", C.c_int32), ("ptr", C.c_int32)]
+
+
+class Voxel(C.Structure):
+    _fields_ = [("sdf", C.c_int16), ("w_depth", C.c_uint8), ("clr", C.c_uint8 * 3),
+                ("w_color", C.c_uint8), ("_pad", C.c_uint8)]
+
+
+class Settings(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("mu", C.c_float), ("max_w", C.c_int32),
+        ("view_frustum_min", C.c_float), ("view_frustum_max", C.c_float),
+        ("stop_integrating_at_max_w", C.c_int32), ("sdf_local_block_num", C.c_int32),
+        ("hash_bucket_num", C.c_int32), ("excess_list_size", C.c_int32),
+        ("use_swapping", C.c_int32), ("use_bilateral_filter", C.c_int32),
+        ("device", C.c_int32), ("sync_status", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class Intrinsics(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Calib(C.Structure):
+    _fields_ = [("rgb", Intrinsics), ("depth", Intrinsics),
+                ("trafo_rgb_to_depth", C.c_float * 16), ("disparity_calib", C.c_float * 2)]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("num_allocated_voxel_blocks", C.c_int32), ("last_free_block_id", C.c_int32),
+        ("last_free_excess_list_id", C.c_int32), ("no_visible_blocks", C.c_int32),
+        ("no_total_entries", C.c_int32), ("voxel_bytes", C.c_int32), ("block_voxels", C.c_int32),
+        ("sticky_status", C.c_int32), ("decayed_block_count", C.c_int64),
+        ("frames_processed", C.c_int64), ("no_visible_blocks_freeview", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64),
+                ("bytes", C.c_double)]
+
+
+assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8
+
+_P = C.c_void_p
+_H = C.c_void_p  # dsr_engine*
+
+# name -> (restype, argtypes); exactly the entry points declared in include/dsr.h
+SIGNATURES = {
+    "abi_version": (C.c_int, []),
+    "default_settings": (None, [C.POINTER(Settings)]),
+    "last_error": (C.c_char_p, []),
+    "engine_create": (C.c_int, [C.POINTER(Settings), C.POINTER(Calib), C.POINTER(_H)]),
+    "engine_destroy": (None, [_H]),
+    "reset_scene": (C.c_int, [_H]),
+    "sync": (C.c_int, [_H]),
+    "update_view": (C.c_int, [_H, _P, _P]),
+    "update_view_dev": (C.c_int, [_H, _P, _P]),
+    "set_view_float": (C.c_int, [_H, _P, _P]),
+    "set_view_float_dev": (C.c_int, [_H, _P, _P]),
+    "get_view": (C.c_int, [_H, _P, _P]),
+    "set_pose_inv_m": (C.c_int, [_H, _P]),
+    "set_pose_m": (C.c_int, [_H, _P]),
+    "get_pose": (C.c_int, [_H, _P, _P]),
+    "set_fusion_weight_params": (C.c_int, [_H, C.c_int]),
+    "process_frame": (C.c_int, [_H]),
+    "allocate_scene_from_depth": (C.c_int, [_H]),
+    "integrate_into_scene": (C.c_int, [_H]),
+    "prepare": (C.c_int, [_H]),
+    "decay": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
+    "get_image": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
+    "get_image_dev": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
+    "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),
+    "dump_hash_table": (C.c_int, [_H, _P]),
+    "dump_visible_list": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int32)]),
+    "dump_visible_types": (C.c_int, [_H, _P]),
+    "dump_voxel_blocks": (C.c_int, [_H, C.c_int, C.c_int, _P]),
+    "dump_allocation_lists": (C.c_int, [_H, _P, _P]),
+    "dump_render_state": (C.c_int, [_H, C.c_int, _P, _P, _P, _P, _P]),
+    "profile_enable": (C.c_int, [_H, C.c_int]),
+    "profile_reset": (C.c_int, [_H]),
+    "profile_get": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),
+}
+
+
+def bind(lib, prefix):
+    """Return a namespace of typed functions `prefix + name` looked up in `lib`.
+
+    Raises AttributeError when the library does not export a declared symbol.
+    """
+    ns = SimpleNamespace()
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, prefix + name)
+        fn.restype = res
+        fn.argtypes = args
+        setattr(ns, name, fn)
+    ns.lib = lib
+    ns.prefix = prefix
+    return ns

@@ -1,0 +1,166 @@
+// dsr_device.h — shared device-side types and helpers of the HIP engine (gfx950).
+//
+// Numerics contract (DESIGN.md "bit-exactness"): every floating point expression
+// is evaluated in the order of the upstream InfiniTAM-v2 shared engine headers,
+// the TU is compiled with -ffp-contract=off (no FMA contraction) and HIP's default
+// correctly rounded fp32 divide/sqrt, so results equal the x86-64 _CPU engines bit
+// for bit.  Out-of-range float->int conversions use the saturating hardware
+// conversion (v_cvt_i32_f32), which is the adopted definition on both sides.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dsr.h"
+
+namespace dsr {
+
+constexpr int kBlockSize = DSR_BLOCK_SIZE;    // 8
+constexpr int kBlockSize3 = DSR_BLOCK_SIZE3;  // 512
+constexpr int kBlockBytes = 4096;             // one voxel block in HBM
+
+// Plane-wise voxel block layout in HBM (4096 B per block, DESIGN.md "HBM layout"):
+//   [   0,1024) int16  sdf[512]
+//   [1024,1536) uint8  w_depth[512]
+//   [1536,2048) uint8  w_color[512]
+//   [2048,4096) uchar4 clr[512]   (r,g,b,0)
+constexpr int kOffSdf = 0;
+constexpr int kOffWDepth = 1024;
+constexpr int kOffWColor = 1536;
+constexpr int kOffClr = 2048;
+
+constexpr float kFarAway = 999999.9f;  // FAR_AWAY
+constexpr float kVeryClose = 0.05f;    // VERY_CLOSE
+constexpr int kMinmaxSubsample = 8;    // minmaximg_subsample
+
+// device-resident counters (int32 each), never read by the host on the hot path
+enum Ctr {
+  CTR_LAST_FREE_BLOCK = 0,    // scene->localVBA.lastFreeBlockId
+  CTR_LAST_FREE_EXCESS = 1,   // lastFreeExcessListId
+  CTR_NO_VISIBLE_LIVE = 2,    // renderState_live->noVisibleBlocks
+  CTR_NO_VISIBLE_FREE = 3,    // renderState_freeview->noVisibleBlocks
+  CTR_STATUS = 4,             // sticky dsr_status
+  CTR_ALLOC_OLD_HEAD_VBA = 5, // allocation context of the running frame
+  CTR_ALLOC_OLD_HEAD_EXC = 6,
+  CTR_ALLOC_TOTAL12 = 7,
+  CTR_ALLOC_TOTAL2 = 8,
+  CTR_DECAY_FREED = 9,        // blocks freed by the running decay call
+  CTR_DECAY_NCAND = 10,       // candidates of the running decay call
+  CTR_TMP_OLD_NVIS = 11,      // live visible count before the post-decay compaction
+  CTR_COUNT = 16
+};
+// device-resident 64-bit work counters (roofline bookkeeping + decayed count)
+enum Work {
+  WORK_V_INTEGRATED = 0,  // sum of noVisibleBlocks over integrate launches
+  WORK_V_EXPECTED = 1,    // ... over expected-depth launches
+  WORK_DECAYED_BLOCKS = 2,
+  WORK_V_DECAY = 3,
+  WORK_COUNT = 8
+};
+
+struct Mat4 { float m[16]; };  // ORUtils::Matrix4f, column-major
+
+struct FrameP {
+  Mat4 M;        // world->camera of the view being processed (M_d or free camera)
+  Mat4 invM;     // its inverse (ORUtils cofactor inverse, computed on the host)
+  Mat4 M_rgb;    // calib_inv * M_d
+  float4 proj;   // fx, fy, cx, cy (depth / free camera)
+  float4 proj_rgb;
+  float mu, voxelSize;
+  float vfMin, vfMax;
+  int W, H, Wr, Hr;
+  int maxW, stopAtMaxW, depthWeighting, rgbSame;
+  int noBuckets, noExcess, noTotalEntries, noBlocks;
+  uint32_t hashMask;
+  uint32_t maxSteps;  // bound on noSteps of the allocation ray walk
+  int useSwapping;
+};
+
+struct SceneP {
+  dsr_hash_entry *table;
+  uint8_t *vba;           // noBlocks * 4096 bytes
+  int32_t *voxelAllocList;
+  int32_t *excessAllocList;
+  int32_t *ctr;           // Ctr
+  unsigned long long *work;  // Work
+  uint32_t *allocKey;     // per entry: 0 or (pixel*maxSteps + step + 1) of the winning writer
+};
+
+// ------------------------------------------------------------------ conversions
+
+__device__ __forceinline__ int f2i(float f) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));  // saturating, NaN -> 0
+  return r;
+}
+__device__ __forceinline__ short f2s(float f) { return (short)f2i(f); }
+
+__device__ __forceinline__ float sdf_to_float(float v) { return v / 32767.0f; }
+__device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f * 32767.0f); }
+
+// ORUtils Matrix4 * Vector4 (w explicit)
+__device__ __forceinline__ float4 mat_mul(const Mat4 &a, float x, float y, float z, float w) {
+  float4 r;
+  r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;
+  r.y = a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w;
+  r.z = a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w;
+  r.w = a.m[3] * x + a.m[7] * y + a.m[11] * z + a.m[15] * w;
+  return r;
+}
+// same without the (unused) w row
+__device__ __forceinline__ float3 mat_mul3(const Mat4 &a, float x, float y, float z, float w) {
+  float3 r;
+  r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;
+  r.y = a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w;
+  r.z = a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w;
+  return r;
+}
+
+__device__ __forceinline__ uint32_t hash_index(int bx, int by, int bz, uint32_t mask) {
+  return (((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349669u) ^ ((uint32_t)bz * 83492791u)) & mask;
+}
+
+// 16-byte load of one hash entry
+__device__ __forceinline__ dsr_hash_entry load_entry(const dsr_hash_entry *table, uint32_t idx) {
+  int4 raw = *reinterpret_cast<const int4 *>(table + idx);
+  dsr_hash_entry e;
+  e.pos[0] = (short)(raw.x & 0xffff);
+  e.pos[1] = (short)((uint32_t)raw.x >> 16);
+  e.pos[2] = (short)(raw.y & 0xffff);
+  e._pad = 0;
+  e.offset = raw.z;
+  e.ptr = raw.w;
+  return e;
+}
+
+// ------------------------------------------------------- workgroup-ordered scans
+
+// Exclusive scan of an int2 over a workgroup of NT threads (NT multiple of 64).
+// wave64 shuffles inside a wave, LDS across waves.  lds must hold NT/64 int2.
+template <int NT>
+__device__ __forceinline__ int2 wg_exclusive_scan2(int2 v, int2 &total, int2 *lds) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int2 inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int ox = __shfl_up(inc.x, d), oy = __shfl_up(inc.y, d);
+    if (lane >= d) { inc.x += ox; inc.y += oy; }
+  }
+  if (lane == 63) lds[wid] = inc;
+  __syncthreads();
+  int2 woff = make_int2(0, 0), tot = make_int2(0, 0);
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    int2 s = lds[w];
+    if (w < wid) { woff.x += s.x; woff.y += s.y; }
+    tot.x += s.x; tot.y += s.y;
+  }
+  __syncthreads();
+  total = tot;
+  return make_int2(woff.x + inc.x - v.x, woff.y + inc.y - v.y);
+}
+
+constexpr int kTileThreads = 256;
+constexpr int kTileItems = 8;
+constexpr int kTile = kTileThreads * kTileItems;  // entries per workgroup in table sweeps
+
+}  // namespace dsr

@@ -1,0 +1,893 @@
+// dsr_engine.hip — host side of the HIP engine: implements the C ABI of include/dsr.h.
+//
+// One dsr_engine = one ITMMainEngine (InfiniTamDriver.h:79): scene (hash table, excess list,
+// voxel block array), two render states, a view and the tracking pose — all resident in HBM.
+// Every call enqueues kernels on the engine's own HIP stream; the hot path
+// (update_view_dev / process_frame / prepare / decay) never synchronises: list lengths and
+// free-list heads stay in device memory and kernels use fixed grids that read them there.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dsr_device.h"
+#include "k_alloc.h"
+#include "k_decay.h"
+#include "k_integrate.h"
+#include "k_raycast.h"
+
+using namespace dsr;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) {                                                                        \
+      char _b[512];                                                                                \
+      snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return fail(DSR_E_DEVICE, _b);                                                               \
+    }                                                                                              \
+  } while (0)
+
+// ----------------------------------------------------------------- host matrices
+// ORUtils::Matrix4f helpers, float, same operation order as the oracle (host code is
+// compiled with -ffp-contract=off as well).
+
+Mat4 m4_identity() { Mat4 r; memset(&r, 0, sizeof r); r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f; return r; }
+
+Mat4 m4_mul(const Mat4 &l, const Mat4 &r) {
+  Mat4 o;
+  for (int x = 0; x < 4; x++)
+    for (int y = 0; y < 4; y++) {
+      float s = 0.0f;
+      for (int k = 0; k < 4; k++) s += l.m[k * 4 + y] * r.m[x * 4 + k];
+      o.m[x * 4 + y] = s;
+    }
+  return o;
+}
+
+// ORUtils Matrix4::inv (cofactor expansion on the transposed source)
+bool m4_inv(const Mat4 &in, Mat4 &out) {
+  float t[12], s[16], det;
+  float *d = out.m;
+  for (int i = 0; i < 4; i++) { s[i] = in.m[i * 4]; s[i + 4] = in.m[i * 4 + 1]; s[i + 8] = in.m[i * 4 + 2]; s[i + 12] = in.m[i * 4 + 3]; }
+  t[0] = s[10] * s[15]; t[1] = s[11] * s[14]; t[2] = s[9] * s[15]; t[3] = s[11] * s[13];
+  t[4] = s[9] * s[14]; t[5] = s[10] * s[13]; t[6] = s[8] * s[15]; t[7] = s[11] * s[12];
+  t[8] = s[8] * s[14]; t[9] = s[10] * s[12]; t[10] = s[8] * s[13]; t[11] = s[9] * s[12];
+  d[0] = (t[0] * s[5] + t[3] * s[6] + t[4] * s[7]) - (t[1] * s[5] + t[2] * s[6] + t[5] * s[7]);
+  d[1] = (t[1] * s[4] + t[6] * s[6] + t[9] * s[7]) - (t[0] * s[4] + t[7] * s[6] + t[8] * s[7]);
+  d[2] = (t[2] * s[4] + t[7] * s[5] + t[10] * s[7]) - (t[3] * s[4] + t[6] * s[5] + t[11] * s[7]);
+  d[3] = (t[5] * s[4] + t[8] * s[5] + t[11] * s[6]) - (t[4] * s[4] + t[9] * s[5] + t[10] * s[6]);
+  d[4] = (t[1] * s[1] + t[2] * s[2] + t[5] * s[3]) - (t[0] * s[1] + t[3] * s[2] + t[4] * s[3]);
+  d[5] = (t[0] * s[0] + t[7] * s[2] + t[8] * s[3]) - (t[1] * s[0] + t[6] * s[2] + t[9] * s[3]);
+  d[6] = (t[3] * s[0] + t[6] * s[1] + t[11] * s[3]) - (t[2] * s[0] + t[7] * s[1] + t[10] * s[3]);
+  d[7] = (t[4] * s[0] + t[9] * s[1] + t[10] * s[2]) - (t[5] * s[0] + t[8] * s[1] + t[11] * s[2]);
+  t[0] = s[2] * s[7]; t[1] = s[3] * s[6]; t[2] = s[1] * s[7]; t[3] = s[3] * s[5];
+  t[4] = s[1] * s[6]; t[5] = s[2] * s[5]; t[6] = s[0] * s[7]; t[7] = s[3] * s[4];
+  t[8] = s[0] * s[6]; t[9] = s[2] * s[4]; t[10] = s[0] * s[5]; t[11] = s[1] * s[4];
+  d[8] = (t[0] * s[13] + t[3] * s[14] + t[4] * s[15]) - (t[1] * s[13] + t[2] * s[14] + t[5] * s[15]);
+  d[9] = (t[1] * s[12] + t[6] * s[14] + t[9] * s[15]) - (t[0] * s[12] + t[7] * s[14] + t[8] * s[15]);
+  d[10] = (t[2] * s[12] + t[7] * s[13] + t[10] * s[15]) - (t[3] * s[12] + t[6] * s[13] + t[11] * s[15]);
+  d[11] = (t[5] * s[12] + t[8] * s[13] + t[11] * s[14]) - (t[4] * s[12] + t[9] * s[13] + t[10] * s[14]);
+  d[12] = (t[2] * s[10] + t[5] * s[11] + t[1] * s[9]) - (t[4] * s[11] + t[0] * s[9] + t[3] * s[10]);
+  d[13] = (t[8] * s[11] + t[0] * s[8] + t[7] * s[10]) - (t[6] * s[10] + t[9] * s[11] + t[1] * s[8]);
+  d[14] = (t[6] * s[9] + t[11] * s[11] + t[3] * s[8]) - (t[10] * s[11] + t[2] * s[8] + t[7] * s[9]);
+  d[15] = (t[10] * s[10] + t[4] * s[8] + t[9] * s[9]) - (t[8] * s[9] + t[11] * s[10] + t[5] * s[8]);
+  det = s[0] * d[0] + s[1] * d[1] + s[2] * d[2] + s[3] * d[3];
+  if (det == 0.0f) return false;
+  float inv = 1.0f / det;
+  for (int i = 0; i < 16; i++) d[i] *= inv;
+  return true;
+}
+
+struct RenderStateDev {  // ITMRenderState_VH
+  int32_t *visibleIDs = nullptr;
+  int32_t *visibleIDsAlt = nullptr;  // ping-pong target of the post-decay compaction (live only)
+  uint8_t *visType = nullptr;
+  float2 *minmax = nullptr;
+  float4 *raycastResult = nullptr;
+  uchar4 *raycastImage = nullptr;
+  int ctrIdx = CTR_NO_VISIBLE_LIVE;
+};
+
+struct ProfRec { std::string name; double ms = 0; long long launches = 0; };
+
+}  // namespace
+
+struct dsr_engine {
+  dsr_settings s;
+  dsr_calib calib;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int W = 0, H = 0, Wr = 0, Hr = 0, P = 0;
+  int noBuckets = 0, noExcess = 0, E = 0, noBlocks = 0;
+  int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
+  uint32_t maxSteps = 0;
+  int gridPersistent = 2048;
+  Mat4 calibInv, M_d, invM_d;
+
+  SceneP scene{};
+  RenderStateDev live, freeview;
+  int2 *tileSums = nullptr;
+
+  // view
+  bool hasView = false;
+  uchar4 *rgb = nullptr;
+  float *depth = nullptr, *depthTmp = nullptr;
+  short *rawDepth = nullptr;
+  // tracking state point cloud
+  float4 *pointsMap = nullptr, *normalsMap = nullptr;
+  // scratch
+  float *freeDepth = nullptr;
+  dsr_voxel *aosScratch = nullptr;
+  int aosScratchBlocks = 0;
+
+  int depthWeighting = 0;
+  long long framesProcessed = 0;
+
+  // voxel GC FIFO of visible lists
+  std::vector<int32_t *> fifoSlots;  // ring storage (device), each noBlocks ints
+  int32_t *fifoCounts = nullptr;     // device, one int per slot
+  int fifoCap = 0, fifoHead = 0, fifoLen = 0;
+  int32_t *decayCand = nullptr;      // forceAll candidate list
+  uint8_t *decayFlags = nullptr;
+
+  // profiling
+  bool profiling = false;
+  std::vector<ProfRec> profRecs;
+  std::map<std::string, int> profIndex;
+  struct Pending { int rec; hipEvent_t a, b; };
+  std::vector<Pending> profPending;
+  std::vector<hipEvent_t> eventPool;
+};
+
+namespace {
+
+int set_device(dsr_engine *e) {
+  HIP_TRY(hipSetDevice(e->device));
+  return DSR_OK;
+}
+
+hipEvent_t get_event(dsr_engine *e) {
+  if (!e->eventPool.empty()) { hipEvent_t ev = e->eventPool.back(); e->eventPool.pop_back(); return ev; }
+  hipEvent_t ev = nullptr;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+
+void prof_resolve(dsr_engine *e) {
+  if (e->profPending.empty()) return;
+  (void)hipStreamSynchronize(e->stream);
+  for (auto &p : e->profPending) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { e->profRecs[p.rec].ms += ms; e->profRecs[p.rec].launches++; }
+    e->eventPool.push_back(p.a); e->eventPool.push_back(p.b);
+  }
+  e->profPending.clear();
+}
+
+struct ProfScope {
+  dsr_engine *e; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(dsr_engine *e_, const char *name) : e(e_) {
+    if (!e->profiling) return;
+    auto it = e->profIndex.find(name);
+    if (it == e->profIndex.end()) {
+      rec = (int)e->profRecs.size();
+      e->profIndex[name] = rec;
+      ProfRec r; r.name = name; e->profRecs.push_back(r);
+    } else rec = it->second;
+    if (e->profPending.size() > 8192) prof_resolve(e);
+    a = get_event(e); b = get_event(e);
+    (void)hipEventRecord(a, e->stream);
+  }
+  ~ProfScope() {
+    if (rec < 0) return;
+    (void)hipEventRecord(b, e->stream);
+    e->profPending.push_back({rec, a, b});
+  }
+};
+
+#define LAUNCH(e, name, kernel, grid, block, ...)                                \
+  do {                                                                           \
+    ProfScope _ps((e), (name));                                                  \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (e)->stream, __VA_ARGS__);        \
+  } while (0)
+
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+FrameP make_frame_params(const dsr_engine *e, const Mat4 &M, const Mat4 &invM, const float proj[4]) {
+  FrameP p;
+  memset(&p, 0, sizeof p);
+  p.M = M; p.invM = invM;
+  p.M_rgb = m4_mul(e->calibInv, M);
+  p.proj = make_float4(proj[0], proj[1], proj[2], proj[3]);
+  p.proj_rgb = make_float4(e->calib.rgb.fx, e->calib.rgb.fy, e->calib.rgb.cx, e->calib.rgb.cy);
+  p.mu = e->s.mu; p.voxelSize = e->s.voxel_size;
+  p.vfMin = e->s.view_frustum_min; p.vfMax = e->s.view_frustum_max;
+  p.W = e->W; p.H = e->H; p.Wr = e->Wr; p.Hr = e->Hr;
+  p.maxW = e->s.max_w; p.stopAtMaxW = e->s.stop_integrating_at_max_w; p.depthWeighting = e->depthWeighting;
+  p.rgbSame = (memcmp(&p.M_rgb, &p.M, sizeof(Mat4)) == 0 && memcmp(&p.proj, &p.proj_rgb, sizeof(float4)) == 0 &&
+               e->W == e->Wr && e->H == e->Hr) ? 1 : 0;
+  p.noBuckets = e->noBuckets; p.noExcess = e->noExcess; p.noTotalEntries = e->E; p.noBlocks = e->noBlocks;
+  p.hashMask = (uint32_t)(e->noBuckets - 1);
+  p.maxSteps = e->maxSteps;
+  p.useSwapping = e->s.use_swapping;
+  return p;
+}
+
+void depth_proj(const dsr_engine *e, float proj[4]) {
+  proj[0] = e->calib.depth.fx; proj[1] = e->calib.depth.fy; proj[2] = e->calib.depth.cx; proj[3] = e->calib.depth.cy;
+}
+
+int reset_scene(dsr_engine *e) {
+  LAUNCH(e, "reset", k_reset_table, dim3(div_up(e->E, 256)), dim3(256), e->scene.table, e->E, e->scene.allocKey);
+  LAUNCH(e, "reset", k_iota, dim3(div_up(e->noExcess, 256)), dim3(256), e->scene.excessAllocList, e->noExcess);
+  LAUNCH(e, "reset", k_iota, dim3(div_up(e->noBlocks, 256)), dim3(256), e->scene.voxelAllocList, e->noBlocks);
+  LAUNCH(e, "reset", k_reset_vba, dim3(4096), dim3(256), reinterpret_cast<uint4 *>(e->scene.vba),
+         (size_t)e->noBlocks * (kBlockBytes / 16));
+  LAUNCH(e, "reset", k_reset_counters, dim3(1), dim3(64), e->scene.ctr, e->scene.work, e->noBlocks, e->noExcess);
+  HIP_TRY(hipMemsetAsync(e->live.visType, 0, (size_t)e->E, e->stream));
+  HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
+  e->fifoHead = 0; e->fifoLen = 0;
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+void free_all(dsr_engine *e) {
+  auto F = [](void *p) { if (p) (void)hipFree(p); };
+  F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
+  F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey);
+  for (RenderStateDev *rs : {&e->live, &e->freeview}) {
+    F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
+  }
+  F(e->tileSums); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
+  F(e->freeDepth); F(e->aosScratch);
+  for (auto p : e->fifoSlots) F(p);
+  F(e->fifoCounts); F(e->decayCand); F(e->decayFlags);
+  for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+}
+
+template <class T>
+int dmalloc(T **p, size_t n) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+  return DSR_OK;
+}
+
+int convert_view(dsr_engine *e) {
+  const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
+  LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, e->depth,
+         e->P, a, b);
+  if (e->s.use_bilateral_filter) {
+    // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
+    HIP_TRY(hipMemcpyAsync(e->depthTmp, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+    dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+    for (int k = 0; k < 5; ++k) {
+      if (k & 1) LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depthTmp, e->depth, e->W, e->H);
+      else LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depth, e->depthTmp, e->W, e->H);
+    }
+    HIP_TRY(hipMemcpyAsync(e->depth, e->depthTmp, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  }
+  e->hasView = true;
+  return DSR_OK;
+}
+
+// AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
+int allocate_scene(dsr_engine *e) {
+  float proj[4]; depth_proj(e, proj);
+  FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
+  RenderStateDev &rs = e->live;
+  LAUNCH(e, "mark_prev_visible", k_mark_previous_visible, dim3(512), dim3(256), (const int32_t *)rs.visibleIDs,
+         (const int32_t *)e->scene.ctr, (int)CTR_NO_VISIBLE_LIVE, rs.visType);
+  LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
+         (const float *)e->depth, rs.visType);
+  LAUNCH(e, "alloc_count", k_alloc_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
+  LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, (const float *)e->depth,
+         (const int2 *)e->tileSums, rs.visType);
+  LAUNCH(e, "visible_count", (k_visible_count<false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
+         e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+         (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+  LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
+         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int integrate_scene(dsr_engine *e) {
+  float proj[4]; depth_proj(e, proj);
+  FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
+  if (p.rgbSame)
+    LAUNCH(e, "integrate", (k_integrate<true>), dim3(e->gridPersistent), dim3(256), p, e->scene, (const float *)e->depth,
+           (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
+  else
+    LAUNCH(e, "integrate", (k_integrate<false>), dim3(e->gridPersistent), dim3(256), p, e->scene,
+           (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
+  const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
+  LAUNCH(e, "minmax_init", k_minmax_init, dim3(div_up(mw * mh, 256)), dim3(256), rs.minmax, mw * mh,
+         (const int32_t *)e->scene.ctr, rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? (int)CTR_NO_VISIBLE_LIVE : -1);
+  LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int32_t *)rs.visibleIDs,
+         rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+  return DSR_OK;
+}
+
+int sticky_status(dsr_engine *e, int *status) {
+  HIP_TRY(hipMemcpyAsync(status, e->scene.ctr + CTR_STATUS, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int ensure_fifo(dsr_engine *e, int slotsNeeded) {
+  if (slotsNeeded <= e->fifoCap) return DSR_OK;
+  // grow the ring, keeping queue order
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::vector<int32_t *> ns((size_t)slotsNeeded, nullptr);
+  int32_t *ncounts = nullptr;
+  int st = dmalloc(&ncounts, (size_t)slotsNeeded);
+  if (st) return st;
+  for (int i = 0; i < slotsNeeded; ++i) {
+    if (i < e->fifoLen) {
+      int old = (e->fifoHead + i) % e->fifoCap;
+      ns[i] = e->fifoSlots[old];
+      e->fifoSlots[old] = nullptr;
+      HIP_TRY(hipMemcpy(ncounts + i, e->fifoCounts + old, 4, hipMemcpyDeviceToDevice));
+    }
+  }
+  for (auto p : e->fifoSlots) if (p) { // unused old slots are recycled
+    for (int i = 0; i < slotsNeeded; ++i) if (!ns[i]) { ns[i] = p; p = nullptr; break; }
+    if (p) (void)hipFree(p);
+  }
+  for (int i = 0; i < slotsNeeded; ++i)
+    if (!ns[i]) { st = dmalloc(&ns[i], (size_t)e->noBlocks); if (st) return st; }
+  if (e->fifoCounts) (void)hipFree(e->fifoCounts);
+  e->fifoCounts = ncounts;
+  e->fifoSlots.swap(ns);
+  e->fifoCap = slotsNeeded;
+  e->fifoHead = 0;
+  return DSR_OK;
+}
+
+}  // namespace
+
+#define CHECK_E(e)                                          \
+  if (!(e)) return fail(DSR_E_ARG, "null engine");          \
+  { int _st = set_device(e); if (_st) return _st; }
+
+extern "C" {
+
+int dsr_abi_version(void) { return DSR_ABI_VERSION; }
+
+void dsr_default_settings(dsr_settings *s) {
+  memset(s, 0, sizeof *s);
+  s->voxel_size = 0.005f; s->mu = 0.02f; s->max_w = 100;
+  s->view_frustum_min = 0.2f; s->view_frustum_max = 3.0f;
+  s->stop_integrating_at_max_w = 0;
+  s->sdf_local_block_num = DSR_DEFAULT_LOCAL_BLOCK_NUM;
+  s->hash_bucket_num = DSR_DEFAULT_BUCKET_NUM;
+  s->excess_list_size = DSR_DEFAULT_EXCESS_LIST_SIZE;
+  s->use_swapping = 0; s->use_bilateral_filter = 0; s->device = -1; s->sync_status = 1;
+}
+
+const char *dsr_last_error(void) { return g_err.c_str(); }
+
+int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_engine **out) {
+  if (!settings || !calib || !out) return fail(DSR_E_ARG, "null argument");
+  const dsr_settings &s = *settings;
+  if (s.hash_bucket_num <= 0 || (s.hash_bucket_num & (s.hash_bucket_num - 1))) return fail(DSR_E_ARG, "hash_bucket_num must be a power of two");
+  if (s.excess_list_size <= 0 || s.sdf_local_block_num <= 0) return fail(DSR_E_ARG, "bad table sizes");
+  if (!(s.voxel_size > 0) || !(s.mu > 0) || s.max_w < 1 || s.max_w > 255) return fail(DSR_E_ARG, "bad scene params");
+  if (calib->depth.width <= 0 || calib->depth.height <= 0) return fail(DSR_E_ARG, "bad image size");
+  if (s.use_swapping) return fail(DSR_E_ARG, "swapping not implemented in this build");
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
+    return fail(DSR_E_DEVICE, "no HIP device: the HIP engine has no CPU fallback");
+  dsr_engine *e = new (std::nothrow) dsr_engine();
+  if (!e) return fail(DSR_E_NOMEM, "oom");
+  e->s = s; e->calib = *calib;
+  if (s.device >= 0) e->device = s.device;
+  else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+  if (e->device >= nDev) { delete e; return fail(DSR_E_ARG, "device ordinal out of range"); }
+  e->W = calib->depth.width; e->H = calib->depth.height; e->Wr = calib->rgb.width; e->Hr = calib->rgb.height;
+  e->P = e->W * e->H;
+  e->noBuckets = s.hash_bucket_num; e->noExcess = s.excess_list_size; e->E = e->noBuckets + e->noExcess;
+  e->noBlocks = s.sdf_local_block_num;
+  e->numTilesE = div_up(e->E, kTile); e->numTilesB = div_up(e->noBlocks, kTile);
+  e->numTilesMax = std::max(e->numTilesE, e->numTilesB);
+  {
+    // bound on noSteps = ceil(2*|dir|), |dir| ~ 2*mu / (8*voxelSize) block units
+    double len = 2.0 * (double)s.mu / (8.0 * (double)s.voxel_size);
+    double S = std::ceil(2.0 * len * 1.05) + 3.0;
+    if (S * (double)e->P >= 4294967295.0) { delete e; return fail(DSR_E_ARG, "mu/voxel_size ratio too large for the 32-bit allocation key"); }
+    e->maxSteps = (uint32_t)S;
+  }
+  Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
+  if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
+  e->M_d = m4_identity(); e->invM_d = m4_identity();
+
+  int st = set_device(e);
+  if (st) { delete e; return st; }
+#define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
+  ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
+  ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
+  ALLOC(dmalloc(&e->scene.voxelAllocList, (size_t)e->noBlocks));
+  ALLOC(dmalloc(&e->scene.excessAllocList, (size_t)e->noExcess));
+  ALLOC(dmalloc(&e->scene.ctr, (size_t)CTR_COUNT));
+  ALLOC(dmalloc(&e->scene.work, (size_t)WORK_COUNT));
+  ALLOC(dmalloc(&e->scene.allocKey, (size_t)e->E));
+  const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
+  for (RenderStateDev *rs : {&e->live, &e->freeview}) {
+    ALLOC(dmalloc(&rs->visibleIDs, (size_t)e->noBlocks));
+    ALLOC(dmalloc(&rs->visType, (size_t)e->E));
+    ALLOC(dmalloc(&rs->minmax, (size_t)mw * mh));
+    ALLOC(dmalloc(&rs->raycastResult, (size_t)e->P));
+    ALLOC(dmalloc(&rs->raycastImage, (size_t)e->P));
+  }
+  ALLOC(dmalloc(&e->live.visibleIDsAlt, (size_t)e->noBlocks));
+  e->live.ctrIdx = CTR_NO_VISIBLE_LIVE; e->freeview.ctrIdx = CTR_NO_VISIBLE_FREE;
+  ALLOC(dmalloc(&e->tileSums, (size_t)e->numTilesMax + 1));
+  ALLOC(dmalloc(&e->rgb, (size_t)e->Wr * e->Hr));
+  ALLOC(dmalloc(&e->depth, (size_t)e->P));
+  ALLOC(dmalloc(&e->depthTmp, (size_t)e->P));
+  ALLOC(dmalloc(&e->rawDepth, (size_t)e->P + 4));
+  ALLOC(dmalloc(&e->pointsMap, (size_t)e->P));
+  ALLOC(dmalloc(&e->normalsMap, (size_t)e->P));
+  ALLOC(dmalloc(&e->freeDepth, (size_t)e->P));
+  ALLOC(dmalloc(&e->decayFlags, (size_t)e->noBlocks));
+  ALLOC(dmalloc(&e->decayCand, (size_t)e->noBlocks));
+  // clear image-sized buffers once so that dumps before the first frame are defined
+  for (RenderStateDev *rs : {&e->live, &e->freeview}) {
+    (void)hipMemsetAsync(rs->raycastResult, 0, (size_t)e->P * 16, e->stream);
+    (void)hipMemsetAsync(rs->raycastImage, 0, (size_t)e->P * 4, e->stream);
+    (void)hipMemsetAsync(rs->minmax, 0, (size_t)mw * mh * 8, e->stream);
+    (void)hipMemsetAsync(rs->visibleIDs, 0, (size_t)e->noBlocks * 4, e->stream);
+  }
+  (void)hipMemsetAsync(e->pointsMap, 0, (size_t)e->P * 16, e->stream);
+  (void)hipMemsetAsync(e->normalsMap, 0, (size_t)e->P * 16, e->stream);
+  ALLOC(reset_scene(e));
+  if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "engine initialisation failed"); }
+#undef ALLOC
+  *out = e;
+  return DSR_OK;
+}
+
+void dsr_engine_destroy(dsr_engine *e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  free_all(e);
+  delete e;
+}
+
+int dsr_reset_scene(dsr_engine *e) {
+  CHECK_E(e);
+  return reset_scene(e);
+}
+
+int dsr_sync(dsr_engine *e) {
+  CHECK_E(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+// ---- view
+
+int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm) {
+  CHECK_E(e);
+  if (!rgba || !depth_mm) return fail(DSR_E_ARG, "null image");
+  HIP_TRY(hipMemcpyAsync(e->rgb, rgba, (size_t)e->Wr * e->Hr * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->rawDepth, depth_mm, (size_t)e->P * 2, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // pageable host memory may be reused by the caller
+  return convert_view(e);
+}
+
+int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev) {
+  CHECK_E(e);
+  if (!rgba_dev || !depth_mm_dev) return fail(DSR_E_ARG, "null image");
+  HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->rawDepth, depth_mm_dev, (size_t)e->P * 2, hipMemcpyDeviceToDevice, e->stream));
+  return convert_view(e);
+}
+
+int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m) {
+  CHECK_E(e);
+  if (!rgba || !depth_m) return fail(DSR_E_ARG, "null image");
+  HIP_TRY(hipMemcpyAsync(e->rgb, rgba, (size_t)e->Wr * e->Hr * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->depth, depth_m, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->hasView = true;
+  return DSR_OK;
+}
+
+int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m_dev) {
+  CHECK_E(e);
+  if (!rgba_dev || !depth_m_dev) return fail(DSR_E_ARG, "null image");
+  HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->depth, depth_m_dev, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  e->hasView = true;
+  return DSR_OK;
+}
+
+int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToHost, e->stream));
+  if (depth_m_out) HIP_TRY(hipMemcpyAsync(depth_m_out, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+// ---- pose
+
+int dsr_set_pose_inv_m(dsr_engine *e, const float inv_m[16]) {
+  if (!e || !inv_m) return fail(DSR_E_ARG, "null");
+  Mat4 im; memcpy(im.m, inv_m, sizeof im.m);
+  Mat4 M;
+  if (!m4_inv(im, M)) return fail(DSR_E_ARG, "singular pose");
+  e->M_d = M;
+  m4_inv(e->M_d, e->invM_d);
+  return DSR_OK;
+}
+int dsr_set_pose_m(dsr_engine *e, const float m[16]) {
+  if (!e || !m) return fail(DSR_E_ARG, "null");
+  Mat4 M; memcpy(M.m, m, sizeof M.m);
+  Mat4 inv;
+  if (!m4_inv(M, inv)) return fail(DSR_E_ARG, "singular pose");
+  e->M_d = M; e->invM_d = inv;
+  return DSR_OK;
+}
+int dsr_get_pose(dsr_engine *e, float m_out[16], float inv_m_out[16]) {
+  if (!e) return fail(DSR_E_ARG, "null");
+  if (m_out) memcpy(m_out, e->M_d.m, sizeof e->M_d.m);
+  if (inv_m_out) memcpy(inv_m_out, e->invM_d.m, sizeof e->invM_d.m);
+  return DSR_OK;
+}
+
+// ---- fusion
+
+int dsr_set_fusion_weight_params(dsr_engine *e, int depth_weighting) {
+  if (!e) return fail(DSR_E_ARG, "null");
+  e->depthWeighting = depth_weighting ? 1 : 0;
+  return DSR_OK;
+}
+
+int dsr_allocate_scene_from_depth(dsr_engine *e) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  int st = allocate_scene(e);
+  if (st) return st;
+  if (e->s.sync_status) {
+    int status = DSR_OK;
+    st = sticky_status(e, &status);
+    if (st) return st;
+    if (status != DSR_OK) return fail(status, "out of voxel blocks / excess list entries");
+  }
+  return DSR_OK;
+}
+
+int dsr_integrate_into_scene(dsr_engine *e) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  return integrate_scene(e);
+}
+
+int dsr_process_frame(dsr_engine *e) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  int st = allocate_scene(e);
+  if (st) return st;
+  st = integrate_scene(e);
+  if (st) return st;
+  e->framesProcessed++;
+  if (e->s.sync_status) {
+    int status = DSR_OK;
+    st = sticky_status(e, &status);
+    if (st) return st;
+    if (status != DSR_OK) {
+      // the fork throws per failing frame: clear the sticky word after reporting it
+      (void)hipMemsetAsync(e->scene.ctr + CTR_STATUS, 0, 4, e->stream);
+      return fail(status, "out of voxel blocks / excess list entries");
+    }
+  }
+  return DSR_OK;
+}
+
+int dsr_prepare(dsr_engine *e) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  float proj[4]; depth_proj(e, proj);
+  FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
+  RenderStateDev &rs = e->live;
+  int st = expected_depths(e, rs, p);
+  if (st) return st;
+  dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+  LAUNCH(e, "raycast", k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+         e->normalsMap, rs.raycastImage);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) {
+  CHECK_E(e);
+  if (min_age < 0) return fail(DSR_E_ARG, "negative min_age");
+  RenderStateDev &rs = e->live;
+  const int32_t *cand = nullptr;
+  const int32_t *nCandPtr = nullptr;
+  if (force_all_voxels) {
+    LAUNCH(e, "decay_candidates", k_allocated_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
+    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_NCAND,
+           e->noBlocks);
+    LAUNCH(e, "decay_candidates", k_allocated_write, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+           (const int2 *)e->tileSums, e->decayCand, e->noBlocks);
+    cand = e->decayCand;
+    nCandPtr = e->scene.ctr + CTR_DECAY_NCAND;
+  } else {
+    int st = ensure_fifo(e, std::max(min_age + 1, e->fifoLen + 1));
+    if (st) return st;
+    const int slot = (e->fifoHead + e->fifoLen) % e->fifoCap;
+    LAUNCH(e, "decay_fifo_push", k_fifo_push, dim3(512), dim3(256), (const int32_t *)rs.visibleIDs,
+           (const int32_t *)e->scene.ctr, e->fifoSlots[slot], e->fifoCounts + slot);
+    e->fifoLen++;
+    if (e->fifoLen <= min_age) { HIP_TRY(hipGetLastError()); return DSR_OK; }
+    cand = e->fifoSlots[e->fifoHead];
+    nCandPtr = e->fifoCounts + e->fifoHead;
+    e->fifoHead = (e->fifoHead + 1) % e->fifoCap;
+    e->fifoLen--;
+  }
+  LAUNCH(e, "decay_blocks", k_decay_blocks, dim3(e->gridPersistent), dim3(256), e->scene, cand, nCandPtr, max_weight,
+         e->decayFlags);
+  LAUNCH(e, "decay_count", k_flag_count, dim3(e->numTilesB), dim3(kTileThreads), (const uint8_t *)e->decayFlags, nCandPtr,
+         e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene, (int)SCAN_DECAY, 0);
+  LAUNCH(e, "decay_commit", k_decay_commit, dim3(e->numTilesB), dim3(kTileThreads), e->scene, cand, nCandPtr,
+         (const uint8_t *)e->decayFlags, (const int2 *)e->tileSums, rs.visType);
+  // drop freed entries from the live visible list (ordered compaction into the alternate buffer)
+  LAUNCH(e, "decay_compact", k_live_keep_count, dim3(e->numTilesB), dim3(kTileThreads), (const int32_t *)rs.visibleIDs,
+         (const int32_t *)e->scene.ctr, (const uint8_t *)rs.visType, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene,
+         (int)SCAN_COMPACT_LIVE, e->noBlocks);
+  LAUNCH(e, "decay_compact", k_live_keep_write, dim3(e->numTilesB), dim3(kTileThreads), (const int32_t *)rs.visibleIDs,
+         (const int32_t *)e->scene.ctr, (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDsAlt);
+  std::swap(rs.visibleIDs, rs.visibleIDsAlt);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+// ---- rendering
+
+static int render_common(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out,
+                         void *depth_out, bool outIsDevice) {
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  const hipMemcpyKind kind = outIsDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const size_t P = (size_t)e->P;
+  switch (type) {
+    case DSR_IMAGE_ORIGINAL_RGB:
+      if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, P * 4, kind, e->stream));
+      break;
+    case DSR_IMAGE_SCENERAYCAST:
+      if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->live.raycastImage, P * 4, kind, e->stream));
+      break;
+    case DSR_IMAGE_FREECAMERA_SHADED:
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME:
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL:
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT:
+    case DSR_IMAGE_FREECAMERA_DEPTH: {
+      Mat4 M = e->M_d, invM;
+      if (pose_m) memcpy(M.m, pose_m, sizeof M.m);
+      if (!m4_inv(M, invM)) return fail(DSR_E_ARG, "singular free-camera pose");
+      float proj[4]; depth_proj(e, proj);
+      if (intrinsics) memcpy(proj, intrinsics, sizeof proj);
+      FrameP p = make_frame_params(e, M, invM, proj);
+      RenderStateDev &rs = e->freeview;
+      // FindVisibleBlocks: ordered compaction of entries inside the free camera's frustum
+      LAUNCH(e, "freeview_visible", (k_visible_count<true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
+             rs.visType, e->tileSums);
+      LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+             (int)SCAN_VISIBLE_FREE, e->noBlocks);
+      LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E,
+             (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
+      int st = expected_depths(e, rs, p);
+      if (st) return st;
+      dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+      LAUNCH(e, "raycast_freeview", k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax,
+             rs.raycastResult);
+      LAUNCH(e, "render", k_render, g, dim3(256), p, e->scene, type, (const float4 *)rs.raycastResult, rs.raycastImage,
+             depth_out ? e->freeDepth : (float *)nullptr);
+      HIP_TRY(hipGetLastError());
+      if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
+      if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
+      break;
+    }
+    default: return fail(DSR_E_ARG, "unsupported image type");
+  }
+  if (!outIsDevice) HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], uint8_t *rgba_out,
+                  float *depth_out) {
+  CHECK_E(e);
+  return render_common(e, type, pose_m, intrinsics, rgba_out, depth_out, false);
+}
+
+int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out_dev,
+                      void *depth_out_dev) {
+  CHECK_E(e);
+  return render_common(e, type, pose_m, intrinsics, rgba_out_dev, depth_out_dev, true);
+}
+
+// ---- statistics / dumps
+
+int dsr_get_stats(dsr_engine *e, dsr_stats *out) {
+  CHECK_E(e);
+  if (!out) return fail(DSR_E_ARG, "null");
+  int32_t ctr[CTR_COUNT];
+  unsigned long long work[WORK_COUNT];
+  HIP_TRY(hipMemcpyAsync(ctr, e->scene.ctr, sizeof ctr, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(work, e->scene.work, sizeof work, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  memset(out, 0, sizeof *out);
+  out->num_allocated_voxel_blocks = e->noBlocks;
+  out->last_free_block_id = ctr[CTR_LAST_FREE_BLOCK];
+  out->last_free_excess_list_id = ctr[CTR_LAST_FREE_EXCESS];
+  out->no_visible_blocks = ctr[CTR_NO_VISIBLE_LIVE];
+  out->no_total_entries = e->E;
+  out->voxel_bytes = (int)sizeof(dsr_voxel);
+  out->block_voxels = kBlockSize3;
+  out->sticky_status = ctr[CTR_STATUS];
+  out->decayed_block_count = (int64_t)work[WORK_DECAYED_BLOCKS];
+  out->frames_processed = e->framesProcessed;
+  out->no_visible_blocks_freeview = ctr[CTR_NO_VISIBLE_FREE];
+  return DSR_OK;
+}
+
+int dsr_dump_hash_table(dsr_engine *e, dsr_hash_entry *out) {
+  CHECK_E(e);
+  if (!out) return fail(DSR_E_ARG, "null");
+  HIP_TRY(hipMemcpyAsync(out, e->scene.table, (size_t)e->E * sizeof(dsr_hash_entry), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_dump_visible_list(dsr_engine *e, int freeview, int32_t *ids_out, int32_t *n) {
+  CHECK_E(e);
+  if (!n) return fail(DSR_E_ARG, "null");
+  RenderStateDev &rs = freeview ? e->freeview : e->live;
+  int32_t cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, e->scene.ctr + rs.ctrIdx, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *n = cnt;
+  if (ids_out && cnt > 0) {
+    HIP_TRY(hipMemcpyAsync(ids_out, rs.visibleIDs, (size_t)cnt * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return DSR_OK;
+}
+
+int dsr_dump_visible_types(dsr_engine *e, uint8_t *out) {
+  CHECK_E(e);
+  if (!out) return fail(DSR_E_ARG, "null");
+  HIP_TRY(hipMemcpyAsync(out, e->live.visType, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_dump_voxel_blocks(dsr_engine *e, int first_block, int n_blocks, dsr_voxel *out) {
+  CHECK_E(e);
+  if (!out || first_block < 0 || n_blocks < 0 || (long long)first_block + n_blocks > e->noBlocks) return fail(DSR_E_ARG, "bad block range");
+  const int chunk = 16384;  // 64 MiB of AoS voxels per pass
+  if (e->aosScratchBlocks < std::min(chunk, n_blocks)) {
+    if (e->aosScratch) (void)hipFree(e->aosScratch);
+    e->aosScratch = nullptr;
+    e->aosScratchBlocks = std::min(chunk, std::max(n_blocks, 1));
+    int st = dmalloc(&e->aosScratch, (size_t)e->aosScratchBlocks * kBlockSize3);
+    if (st) { e->aosScratchBlocks = 0; return st; }
+  }
+  for (int done = 0; done < n_blocks; done += e->aosScratchBlocks) {
+    const int nb = std::min(e->aosScratchBlocks, n_blocks - done);
+    LAUNCH(e, "blocks_to_aos", k_blocks_to_aos, dim3(std::min(2048, div_up(nb, 4))), dim3(256),
+           (const uint8_t *)e->scene.vba, first_block + done, nb, e->aosScratch);
+    HIP_TRY(hipMemcpyAsync(out + (size_t)done * kBlockSize3, e->aosScratch, (size_t)nb * kBlockSize3 * sizeof(dsr_voxel),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return DSR_OK;
+}
+
+int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t *excess_alloc_list) {
+  CHECK_E(e);
+  if (voxel_alloc_list) HIP_TRY(hipMemcpyAsync(voxel_alloc_list, e->scene.voxelAllocList, (size_t)e->noBlocks * 4, hipMemcpyDeviceToHost, e->stream));
+  if (excess_alloc_list) HIP_TRY(hipMemcpyAsync(excess_alloc_list, e->scene.excessAllocList, (size_t)e->noExcess * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result, float *points, float *normals,
+                          uint8_t *raycast_image) {
+  CHECK_E(e);
+  RenderStateDev &rs = which ? e->freeview : e->live;
+  const size_t P = (size_t)e->P;
+  const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
+  if (minmax) HIP_TRY(hipMemcpyAsync(minmax, rs.minmax, (size_t)mw * mh * 8, hipMemcpyDeviceToHost, e->stream));
+  if (raycast_result) HIP_TRY(hipMemcpyAsync(raycast_result, rs.raycastResult, P * 16, hipMemcpyDeviceToHost, e->stream));
+  if (points) HIP_TRY(hipMemcpyAsync(points, e->pointsMap, P * 16, hipMemcpyDeviceToHost, e->stream));
+  if (normals) HIP_TRY(hipMemcpyAsync(normals, e->normalsMap, P * 16, hipMemcpyDeviceToHost, e->stream));
+  if (raycast_image) HIP_TRY(hipMemcpyAsync(raycast_image, rs.raycastImage, P * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+// ---- profiling
+
+int dsr_profile_enable(dsr_engine *e, int enable) {
+  CHECK_E(e);
+  if (!enable) prof_resolve(e);
+  e->profiling = enable != 0;
+  return DSR_OK;
+}
+
+int dsr_profile_reset(dsr_engine *e) {
+  CHECK_E(e);
+  prof_resolve(e);
+  for (auto &r : e->profRecs) { r.ms = 0; r.launches = 0; }
+  // work counters restart as well (decayed-block count is kept)
+  unsigned long long zero = 0;
+  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_INTEGRATED, &zero, 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_EXPECTED, &zero, 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_DECAY, &zero, 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
+  if (!e || !out || cap <= 0) return 0;
+  if (set_device(e)) return 0;
+  prof_resolve(e);
+  unsigned long long work[WORK_COUNT];
+  if (hipMemcpy(work, e->scene.work, sizeof work, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  const double P = (double)e->P, E = (double)e->E, B = (double)kBlockBytes;
+  int n = 0;
+  for (auto &r : e->profRecs) {
+    if (n >= cap) break;
+    if (r.launches == 0) continue;
+    dsr_kernel_time &k = out[n++];
+    memset(&k, 0, sizeof k);
+    strncpy(k.name, r.name.c_str(), sizeof k.name - 1);
+    k.total_ms = r.ms; k.launches = r.launches;
+    const double L = (double)r.launches;
+    // algorithmic bytes, SURVEY.md 8(d) / DESIGN.md "byte model"
+    if (r.name == "integrate") k.bytes = (double)work[WORK_V_INTEGRATED] * (16.0 + 2.0 * B) + L * 8.0 * P;
+    else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;
+    else if (r.name == "expected_depth") k.bytes = (double)work[WORK_V_EXPECTED] * 16.0 + L * 8.0 * std::ceil(e->W / 8.0) * std::ceil(e->H / 8.0);
+    else if (r.name == "icp_maps") k.bytes = L * P * (16.0 + 16.0 + 16.0 + 4.0);
+    else if (r.name == "alloc_count") k.bytes = L * E * 4.0;
+    else if (r.name == "alloc_commit") k.bytes = L * E * 4.0;
+    else if (r.name == "visible_count") k.bytes = L * E * 1.0;
+    else if (r.name == "visible_write") k.bytes = L * E * 1.0;
+    else if (r.name == "decay_blocks") k.bytes = (double)work[WORK_V_DECAY] * (16.0 + 2.0 * B);
+    else k.bytes = 0.0;
+  }
+  return n;
+}
+
+}  // extern "C"

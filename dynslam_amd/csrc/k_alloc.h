@@ -1,0 +1,404 @@
+// k_alloc.h — view conversion, voxel-block allocation and visible-list kernels.
+//
+// Replaces: convertDepthAffineToFloat_device, buildHashAllocAndVisibleType,
+// allocateVoxelBlocksList, buildVisibleList, setToType3 of upstream's *_CUDA engines — with a
+// DETERMINISTIC formulation whose result equals the serial _CPU engine:
+//   * K1 marks per pixel; for every target entry the LAST writer in (raster pixel, step)
+//     order wins, selected with an atomicMax on a 32-bit order key;
+//   * the commit recomputes the winner's block position and pops the voxel/excess free
+//     lists in ASCENDING ENTRY ORDER through ordered tile prefix sums (ballot-free wave64
+//     shuffle scans + a single-workgroup scan of tile sums);
+//   * the visible list is an ordered compaction, so visibleEntryIDs is ascending.
+#pragma once
+#include "dsr_device.h"
+
+namespace dsr {
+
+// ---------------------------------------------------------------------- K0: view
+
+// ITMViewBuilder.h convertDepthAffineToFloat: int16 mm -> float m, <=0 or >32000 -> -1.
+__global__ __launch_bounds__(256) void k_depth_to_float(const short *__restrict__ in, float *__restrict__ out, int n,
+                                                        float a, float b) {
+  // 4 pixels per thread: 8 B load, 16 B store
+  int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    short4 d = *reinterpret_cast<const short4 *>(in + i4);
+    float4 o;
+    o.x = (d.x <= 0 || d.x > 32000) ? -1.0f : (float)d.x * a + b;
+    o.y = (d.y <= 0 || d.y > 32000) ? -1.0f : (float)d.y * a + b;
+    o.z = (d.z <= 0 || d.z > 32000) ? -1.0f : (float)d.z * a + b;
+    o.w = (d.w <= 0 || d.w > 32000) ? -1.0f : (float)d.w * a + b;
+    *reinterpret_cast<float4 *>(out + i4) = o;
+  } else {
+    for (int i = i4; i < n; ++i) {
+      short d = in[i];
+      out[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
+  }
+}
+
+// ITMViewBuilder.h filterDepth (one bilateral pass); borders keep their old value.
+__global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
+  const float MEAN_SIGMA_L = 1.2232f;
+  int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x < 2 || x >= W - 2 || y < 2 || y >= H - 2) return;
+  float z = in[x + y * W];
+  if (z < 0.0f) { out[x + y * W] = -1.0f; return; }
+  float final_depth = 0.0f, w_sum = 0.0f;
+  float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+  for (int i = -2; i <= 2; i++)
+    for (int j = -2; j <= 2; j++) {
+      float tmpz = in[(x + j) + (y + i) * W];
+      if (tmpz < 0.0f) continue;
+      float dz = (tmpz - z); dz *= dz;
+      float w = expf(-0.5f * ((abs(i) + abs(j)) * MEAN_SIGMA_L * MEAN_SIGMA_L + dz * sigma_z * sigma_z));
+      w_sum += w;
+      final_depth += w * tmpz;
+    }
+  final_depth /= w_sum;
+  out[x + y * W] = final_depth;
+}
+
+// ------------------------------------------------------------- allocation ray
+
+struct AllocRay {
+  float px, py, pz;  // start point, block units
+  float dx, dy, dz;  // per-step increment
+  int noSteps;
+};
+
+// First half of buildHashAllocAndVisibleTypePP: the ray segment [d-mu, d+mu] in block units.
+__device__ __forceinline__ bool alloc_ray(const FrameP &p, const float *__restrict__ depth, int x, int y, AllocRay &r) {
+  float depth_measure = depth[x + y * p.W];
+  if (depth_measure <= 0 || (depth_measure - p.mu) < 0 || (depth_measure - p.mu) < p.vfMin ||
+      (depth_measure + p.mu) > p.vfMax)
+    return false;
+  const float oneOverVoxelSize = 1.0f / (p.voxelSize * (float)kBlockSize);
+  const float invFx = 1.0f / p.proj.x, invFy = 1.0f / p.proj.y;
+  float cz = depth_measure;
+  float cx = cz * (((float)x - p.proj.z) * invFx);
+  float cy = cz * (((float)y - p.proj.w) * invFy);
+  float norm = sqrtf(cx * cx + cy * cy + cz * cz);
+  float f1 = 1.0f - p.mu / norm;
+  float3 t = mat_mul3(p.invM, cx * f1, cy * f1, cz * f1, 1.0f);
+  r.px = t.x * oneOverVoxelSize; r.py = t.y * oneOverVoxelSize; r.pz = t.z * oneOverVoxelSize;
+  float f2 = 1.0f + p.mu / norm;
+  t = mat_mul3(p.invM, cx * f2, cy * f2, cz * f2, 1.0f);
+  float ex = t.x * oneOverVoxelSize, ey = t.y * oneOverVoxelSize, ez = t.z * oneOverVoxelSize;
+  float dx = ex - r.px, dy = ey - r.py, dz = ez - r.pz;
+  norm = sqrtf(dx * dx + dy * dy + dz * dz);
+  r.noSteps = f2i(ceilf(2.0f * norm));
+  float denom = (float)(r.noSteps - 1);
+  r.dx = dx / denom; r.dy = dy / denom; r.dz = dz / denom;
+  return true;
+}
+
+// mark every entry of last frame's visible list as type 3 ("visible at previous frame")
+__global__ __launch_bounds__(256) void k_mark_previous_visible(const int32_t *__restrict__ visibleIDs,
+                                                               const int32_t *__restrict__ ctr, int ctrIdx,
+                                                               uint8_t *__restrict__ visType) {
+  const int n = ctr[ctrIdx];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) visType[visibleIDs[i]] = 3;
+}
+
+// K1: per-pixel mark.  16x16 pixel tiles (a wave covers 16x4 pixels: neighbouring rays
+// probe the same buckets, which keeps the 16-byte entry gathers in L2).
+__global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                    uint8_t *__restrict__ visType) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  AllocRay r;
+  if (!alloc_ray(p, depth, x, y, r)) return;
+  const uint32_t keyBase = (uint32_t)(x + y * p.W) * p.maxSteps + 1u;
+  float px = r.px, py = r.py, pz = r.pz;
+  for (int i = 0; i < r.noSteps; i++) {
+    const short bx = f2s(floorf(px)), by = f2s(floorf(py)), bz = f2s(floorf(pz));
+    uint32_t hashIdx = hash_index(bx, by, bz, p.hashMask);
+    bool isFound = false;
+    int firstFree = -1;
+    dsr_hash_entry he = load_entry(s.table, hashIdx);
+    if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+      visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
+      isFound = true;
+    }
+    if (!isFound) {
+      if (he.ptr < -1) firstFree = (int)hashIdx;
+      while (he.offset >= 1) {
+        hashIdx = (uint32_t)(p.noBuckets + he.offset - 1);
+        he = load_entry(s.table, hashIdx);
+        if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
+          visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
+          isFound = true;
+          break;
+        }
+        if (he.ptr < -1 && firstFree < 0) firstFree = (int)hashIdx;
+      }
+      if (!isFound) {
+        const bool isExcess = firstFree < 0;
+        const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
+        if (!isExcess) visType[target] = 1;
+        uint32_t step = (uint32_t)i < p.maxSteps ? (uint32_t)i : p.maxSteps - 1u;
+        atomicMax(&s.allocKey[target], keyBase + step);
+      }
+    }
+    px += r.dx; py += r.dy; pz += r.dz;
+  }
+}
+
+// block position written by the winning (pixel, step) — replays the walk of that pixel
+__device__ __forceinline__ void alloc_winner_pos(const FrameP &p, const float *__restrict__ depth, uint32_t key,
+                                                 short &bx, short &by, short &bz) {
+  const uint32_t k = key - 1u;
+  const uint32_t pixel = k / p.maxSteps, step = k - pixel * p.maxSteps;
+  const int y = (int)(pixel / (uint32_t)p.W), x = (int)(pixel - (uint32_t)y * (uint32_t)p.W);
+  AllocRay r;
+  alloc_ray(p, depth, x, y, r);
+  float px = r.px, py = r.py, pz = r.pz;
+  for (uint32_t i = 0; i < step; ++i) { px += r.dx; py += r.dy; pz += r.dz; }
+  bx = f2s(floorf(px)); by = f2s(floorf(py)); bz = f2s(floorf(pz));
+}
+
+// K2a: per tile, number of entries to allocate (x) and of those the excess-list ones (y)
+__global__ __launch_bounds__(kTileThreads) void k_alloc_count(SceneP s, int noTotalEntries, int2 *__restrict__ tileSums) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  int2 c = make_int2(0, 0);
+  if (base + kTileItems <= noTotalEntries) {
+    uint4 k0 = *reinterpret_cast<const uint4 *>(s.allocKey + base);
+    uint4 k1 = *reinterpret_cast<const uint4 *>(s.allocKey + base + 4);
+    uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+#pragma unroll
+    for (int j = 0; j < kTileItems; ++j)
+      if (k[j]) { c.x++; if (s.table[base + j].ptr >= -1) c.y++; }
+  } else {
+    for (int j = 0; j < kTileItems; ++j) {
+      int t = base + j;
+      if (t < noTotalEntries && s.allocKey[t]) { c.x++; if (s.table[t].ptr >= -1) c.y++; }
+    }
+  }
+  int2 total;
+  wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+
+// Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
+enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5 };
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tileSums, int numTiles, SceneP s, int mode,
+                                                         int capacity) {
+  __shared__ int2 lds[1024 / 64];
+  int2 carry = make_int2(0, 0);
+  for (int base = 0; base < numTiles; base += 1024) {
+    int i = base + threadIdx.x;
+    int2 v = (i < numTiles) ? tileSums[i] : make_int2(0, 0);
+    int2 total;
+    int2 ex = wg_exclusive_scan2<1024>(v, total, lds);
+    if (i < numTiles) tileSums[i] = make_int2(carry.x + ex.x, carry.y + ex.y);
+    carry.x += total.x; carry.y += total.y;
+  }
+  if (threadIdx.x == 0) {
+    int32_t *ctr = s.ctr;
+    if (mode == SCAN_ALLOC) {
+      const int oldV = ctr[CTR_LAST_FREE_BLOCK], oldE = ctr[CTR_LAST_FREE_EXCESS];
+      ctr[CTR_ALLOC_OLD_HEAD_VBA] = oldV; ctr[CTR_ALLOC_OLD_HEAD_EXC] = oldE;
+      ctr[CTR_ALLOC_TOTAL12] = carry.x; ctr[CTR_ALLOC_TOTAL2] = carry.y;
+      int nv = oldV - carry.x, ne = oldE - carry.y;
+      ctr[CTR_LAST_FREE_BLOCK] = nv < -1 ? -1 : nv;
+      ctr[CTR_LAST_FREE_EXCESS] = ne < -1 ? -1 : ne;
+      if (carry.x > oldV + 1 || carry.y > oldE + 1) ctr[CTR_STATUS] = DSR_E_OUT_OF_BLOCKS;
+    } else if (mode == SCAN_VISIBLE_LIVE || mode == SCAN_VISIBLE_FREE || mode == SCAN_COMPACT_LIVE) {
+      int n = carry.x < capacity ? carry.x : capacity;
+      if (mode == SCAN_COMPACT_LIVE) ctr[CTR_TMP_OLD_NVIS] = ctr[CTR_NO_VISIBLE_LIVE];
+      ctr[mode == SCAN_VISIBLE_FREE ? CTR_NO_VISIBLE_FREE : CTR_NO_VISIBLE_LIVE] = n;
+    } else if (mode == SCAN_NCAND) {
+      ctr[CTR_DECAY_NCAND] = carry.x < capacity ? carry.x : capacity;
+    } else if (mode == SCAN_DECAY) {
+      ctr[CTR_DECAY_FREED] = carry.x;
+      ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];
+      ctr[CTR_LAST_FREE_BLOCK] += carry.x;
+      atomicAdd(&s.work[WORK_DECAYED_BLOCKS], (unsigned long long)carry.x);
+    }
+  }
+}
+
+// K2b: commit in ascending entry order (the serial loop of AllocateSceneFromDepth).
+__global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                               const int2 *__restrict__ tileOffsets,
+                                                               uint8_t *__restrict__ visType) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  uint32_t k[kTileItems];
+  uint8_t isExc[kTileItems];
+  int2 c = make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    int t = base + j;
+    k[j] = (t < p.noTotalEntries) ? s.allocKey[t] : 0u;
+    isExc[j] = 0;
+    if (k[j]) { c.x++; if (s.table[t].ptr >= -1) { isExc[j] = 1; c.y++; } }
+  }
+  int2 total;
+  int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (total.x == 0) return;
+  const int2 tileOff = tileOffsets[blockIdx.x];
+  int rank12 = tileOff.x + ex.x, rank2 = tileOff.y + ex.y;
+  const int oldV = s.ctr[CTR_ALLOC_OLD_HEAD_VBA], oldE = s.ctr[CTR_ALLOC_OLD_HEAD_EXC];
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    if (!k[j]) continue;
+    const int t = base + j;
+    s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
+    const int vbaIdx = oldV - rank12;
+    rank12++;
+    if (!isExc[j]) {  // type 1: in place (free head or tombstone); the chain link is kept
+      if (vbaIdx >= 0) {
+        short bx, by, bz;
+        alloc_winner_pos(p, depth, k[j], bx, by, bz);
+        dsr_hash_entry *he = s.table + t;
+        int2 w;
+        w.x = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
+        w.y = (int)(uint32_t)(uint16_t)bz;
+        *reinterpret_cast<int2 *>(he) = w;
+        he->ptr = s.voxelAllocList[vbaIdx];
+      }
+    } else {  // type 2: append a child from the excess list to this chain tail
+      const int exlIdx = oldE - rank2;
+      rank2++;
+      if (vbaIdx >= 0 && exlIdx >= 0) {
+        short bx, by, bz;
+        alloc_winner_pos(p, depth, k[j], bx, by, bz);
+        const int exlOffset = s.excessAllocList[exlIdx];
+        s.table[t].offset = exlOffset + 1;
+        int4 w;
+        w.x = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
+        w.y = (int)(uint32_t)(uint16_t)bz;
+        w.z = 0;
+        w.w = s.voxelAllocList[vbaIdx];
+        *reinterpret_cast<int4 *>(s.table + p.noBuckets + exlOffset) = w;
+        visType[p.noBuckets + exlOffset] = 1;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------- block visibility
+
+// ITMSceneReconstructionEngine.h checkPointVisibility / checkBlockVisibility (corner
+// order and the incremental +=factor arithmetic are part of the result).
+template <bool useSwapping>
+__device__ __forceinline__ void check_point_visibility(bool &isVisible, bool &isVisibleEnlarged, float x, float y, float z,
+                                                       const Mat4 &M, const float4 &proj, int W, int H) {
+  float3 b = mat_mul3(M, x, y, z, 1.0f);
+  if (b.z < 1e-10f) return;
+  float u = proj.x * b.x / b.z + proj.z;
+  float v = proj.y * b.y / b.z + proj.w;
+  if (u >= 0 && u < (float)W && v >= 0 && v < (float)H) {
+    isVisible = true; isVisibleEnlarged = true;
+  } else if (useSwapping) {
+    int lx = -W / 8, ly = W + W / 8, lz = -H / 8, lw = H + H / 8;
+    if (u >= (float)lx && u < (float)ly && v >= (float)lz && v < (float)lw) isVisibleEnlarged = true;
+  }
+}
+template <bool useSwapping>
+__device__ __forceinline__ void check_block_visibility(bool &isVisible, bool &isVisibleEnlarged, const short pos[3],
+                                                       const Mat4 &M, const float4 &proj, float voxelSize, int W, int H) {
+  const float factor = (float)kBlockSize * voxelSize;
+  isVisible = false; isVisibleEnlarged = false;
+  float x = (float)pos[0] * factor, y = (float)pos[1] * factor, z = (float)pos[2] * factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  z += factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  y += factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  x += factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  z -= factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  y -= factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  x -= factor; y += factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  x += factor; y -= factor; z += factor;
+  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H);
+}
+
+// K3a (live view): re-test type-3 entries, count the visible ones per tile.
+// K5a (free view): visible iff ptr >= 0 and inside the frustum (FindVisibleBlocks).
+template <bool FREEVIEW>
+__global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP s, uint8_t *__restrict__ visType,
+                                                                int2 *__restrict__ tileSums) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  int2 c = make_int2(0, 0);
+  uint8_t v[kTileItems];
+  if (!FREEVIEW) {
+    if (base + kTileItems <= p.noTotalEntries) {
+      uint2 raw = *reinterpret_cast<const uint2 *>(visType + base);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = (raw.x >> (8 * j)) & 0xff; v[4 + j] = (raw.y >> (8 * j)) & 0xff; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kTileItems; ++j) v[j] = (base + j < p.noTotalEntries) ? visType[base + j] : 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    const int t = base + j;
+    if (FREEVIEW) {
+      uint8_t vis = 0;
+      if (t < p.noTotalEntries) {
+        dsr_hash_entry he = load_entry(s.table, t);
+        if (he.ptr >= 0) {
+          bool isVisible, isVisibleEnlarged;
+          check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+          vis = isVisible ? 1 : 0;
+        }
+        visType[t] = vis;
+      }
+      if (vis) c.x++;
+    } else {
+      if (v[j] == 3) {
+        dsr_hash_entry he = load_entry(s.table, t);
+        bool isVisible, isVisibleEnlarged;
+        if (p.useSwapping) {
+          check_block_visibility<true>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+          if (!isVisibleEnlarged) v[j] = 0;
+        } else {
+          check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+          if (!isVisible) v[j] = 0;
+        }
+        visType[t] = v[j];
+      }
+      if (v[j] > 0) c.x++;
+    }
+  }
+  int2 total;
+  wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+
+// K3b: ordered compaction -> ascending visibleEntryIDs
+__global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntries, const uint8_t *__restrict__ visType,
+                                                                const int2 *__restrict__ tileOffsets,
+                                                                int32_t *__restrict__ visibleIDs, int capacity) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  uint8_t v[kTileItems];
+  int2 c = make_int2(0, 0);
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    v[j] = (base + j < noTotalEntries) ? visType[base + j] : 0;
+    if (v[j] > 0) c.x++;
+  }
+  int2 total;
+  int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (total.x == 0) return;
+  int rank = tileOffsets[blockIdx.x].x + ex.x;
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j)
+    if (v[j] > 0) {
+      if (rank < capacity) visibleIDs[rank] = base + j;
+      rank++;
+    }
+}
+
+}  // namespace dsr

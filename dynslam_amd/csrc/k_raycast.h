@@ -1,0 +1,413 @@
+// k_raycast.h — K6 expected depths, K7 raycast, K8 ICP maps / shading kernels.
+//
+// Replaces projectAndSplitBlocks/fillBlocks, genericRaycast, renderICP/renderGrey/renderColour/
+// renderColourFromNormal (+ the fork's depth / depth-weight shaders) of upstream's
+// ITMVisualisationEngine_CUDA.  Arithmetic follows ITMVisualisationEngine.h and
+// ITMRepresentationAccess.h expression by expression.
+//
+// CDNA4 notes: a wave64 is an 8x8 pixel tile = exactly one cell of the 8x-subsampled
+// range image, so all lanes of a wave share one [min,max] range (scalar load, uniform trip
+// count bound); the raycast touches only the 1 KiB sdf plane of a block.
+#pragma once
+#include "dsr_device.h"
+
+namespace dsr {
+
+// ------------------------------------------------------------------ voxel access
+
+struct VoxCache {  // ITMVoxelBlockHash::IndexCache
+  int bx, by, bz;
+  int ptr;  // block index
+};
+__device__ __forceinline__ void cache_init(VoxCache &c) { c.bx = c.by = c.bz = 0x7fffffff; c.ptr = -1; }
+
+// ITMRepresentationAccess.h readVoxel (with per-thread cache): returns the block index
+// holding voxel (x,y,z) or -1; linearIdx is the offset inside the block.
+__device__ __forceinline__ int find_block(const SceneP &s, const FrameP &p, int x, int y, int z, int &linearIdx,
+                                          VoxCache &cache) {
+  const int bx = x >> 3, by = y >> 3, bz = z >> 3;  // == pointToVoxelBlockPos for negatives too
+  linearIdx = (x & 7) + ((y & 7) << 3) + ((z & 7) << 6);
+  if (bx == cache.bx && by == cache.by && bz == cache.bz) return cache.ptr;
+  uint32_t hashIdx = hash_index(bx, by, bz, p.hashMask);
+  while (true) {
+    dsr_hash_entry he = load_entry(s.table, hashIdx);
+    if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= 0) {
+      cache.bx = bx; cache.by = by; cache.bz = bz; cache.ptr = he.ptr;
+      return he.ptr;
+    }
+    if (he.offset < 1) break;
+    hashIdx = (uint32_t)(p.noBuckets + he.offset - 1);
+  }
+  return -1;
+}
+
+// sdf of a voxel as float(short); missing voxels read as TVoxel() => 32767
+__device__ __forceinline__ float read_sdf_raw(const SceneP &s, const FrameP &p, int x, int y, int z, bool &found,
+                                              VoxCache &cache) {
+  int lin;
+  int ptr = find_block(s, p, x, y, z, lin, cache);
+  found = ptr >= 0;
+  if (!found) return 32767.0f;
+  return (float)*reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf + lin * 2);
+}
+
+__device__ __forceinline__ float roundf_itm(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }  // ROUND()
+
+__device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                         bool &found, VoxCache &cache) {
+  float v = read_sdf_raw(s, p, f2i(roundf_itm(x)), f2i(roundf_itm(y)), f2i(roundf_itm(z)), found, cache);
+  return sdf_to_float(v);
+}
+
+__device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                       VoxCache &cache) {
+  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+  const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
+  bool f;
+  float res1, res2, v1, v2;
+  v1 = read_sdf_raw(s, p, ix, iy, iz, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy, iz, f, cache);
+  res1 = (1.0f - cx) * v1 + cx * v2;
+  v1 = read_sdf_raw(s, p, ix, iy + 1, iz, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy + 1, iz, f, cache);
+  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
+  v1 = read_sdf_raw(s, p, ix, iy, iz + 1, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy, iz + 1, f, cache);
+  res2 = (1.0f - cx) * v1 + cx * v2;
+  v1 = read_sdf_raw(s, p, ix, iy + 1, iz + 1, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy + 1, iz + 1, f, cache);
+  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
+  return sdf_to_float((1.0f - cz) * res1 + cz * res2);
+}
+
+// --------------------------------------------------------- K6: expected depths
+
+__global__ __launch_bounds__(256) void k_minmax_init(float2 *__restrict__ minmax, int n, const int32_t *__restrict__ ctr,
+                                                     int skipIfZeroIdx) {
+  if (skipIfZeroIdx >= 0 && ctr[skipIfZeroIdx] <= 0) return;  // Prepare() is skipped without visible blocks
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) minmax[i] = make_float2(kFarAway, kVeryClose);
+}
+
+// ITMVisualisationEngine.h ProjectSingleBlock on the compact ceil(W/8) x ceil(H/8) image
+__device__ __forceinline__ bool project_single_block(const short pos[3], const FrameP &p, int imgW, int imgH, int2 &ul,
+                                                     int2 &lr, float2 &zr) {
+  ul = make_int2(imgW, imgH);
+  lr = make_int2(-1, -1);
+  zr = make_float2(kFarAway, kVeryClose);
+#pragma unroll
+  for (int corner = 0; corner < 8; ++corner) {
+    short tx = (short)(pos[0] + ((corner & 1) ? 1 : 0));
+    short ty = (short)(pos[1] + ((corner & 2) ? 1 : 0));
+    short tz = (short)(pos[2] + ((corner & 4) ? 1 : 0));
+    float3 q = mat_mul3(p.M, (float)tx * (float)kBlockSize * p.voxelSize, (float)ty * (float)kBlockSize * p.voxelSize,
+                        (float)tz * (float)kBlockSize * p.voxelSize, 1.0f);
+    if (q.z < 1e-6f) continue;
+    float px = (p.proj.x * q.x / q.z + p.proj.z) / (float)kMinmaxSubsample;
+    float py = (p.proj.y * q.y / q.z + p.proj.w) / (float)kMinmaxSubsample;
+    if ((float)ul.x > floorf(px)) ul.x = f2i(floorf(px));
+    if ((float)lr.x < ceilf(px)) lr.x = f2i(ceilf(px));
+    if ((float)ul.y > floorf(py)) ul.y = f2i(floorf(py));
+    if ((float)lr.y < ceilf(py)) lr.y = f2i(ceilf(py));
+    if (zr.x > q.z) zr.x = q.z;
+    if (zr.y < q.z) zr.y = q.z;
+  }
+  if (ul.x < 0) ul.x = 0;
+  if (ul.y < 0) ul.y = 0;
+  if (lr.x >= imgW) lr.x = imgW - 1;
+  if (lr.y >= imgH) lr.y = imgH - 1;
+  if (ul.x > lr.x) return false;
+  if (ul.y > lr.y) return false;
+  if (zr.x < kVeryClose) zr.x = kVeryClose;
+  if (zr.y < kVeryClose) return false;
+  return true;
+}
+
+// One thread per visible block: project, then min/max into the range image.  All values are
+// positive floats, so integer atomicMin/atomicMax on the bit patterns order them correctly and
+// the result is independent of the order of arrival.
+__global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, const int32_t *__restrict__ visibleIDs,
+                                                        int ctrIdx, int2 *__restrict__ minmax) {
+  const int n = s.ctr[ctrIdx];
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    dsr_hash_entry he = load_entry(s.table, visibleIDs[i]);
+    if (he.ptr < 0) continue;
+    int2 ul, lr; float2 zr;
+    if (!project_single_block(he.pos, p, mw, mh, ul, lr, zr)) continue;
+    const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
+    for (int y = ul.y; y <= lr.y; ++y)
+      for (int x = ul.x; x <= lr.x; ++x) {
+        int2 *px = minmax + x + y * mw;
+        atomicMin(&px->x, zmin);
+        atomicMax(&px->y, zmax);
+      }
+  }
+}
+
+// ----------------------------------------------------------------- K7: raycast
+
+// ITMVisualisationEngine.h castRay
+__device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int x, int y, float2 mm) {
+  const float oneOverVoxelSize = 1.0f / p.voxelSize;
+  const float invFx = 1.0f / p.proj.x, invFy = 1.0f / p.proj.y;
+  const float stepScale = p.mu * oneOverVoxelSize;
+  float cz = mm.x;
+  float cx = cz * (((float)x - p.proj.z) * invFx);
+  float cy = cz * (((float)y - p.proj.w) * invFy);
+  float totalLength = sqrtf(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
+  float3 t = mat_mul3(p.invM, cx, cy, cz, 1.0f);
+  float sx = t.x * oneOverVoxelSize, sy = t.y * oneOverVoxelSize, sz = t.z * oneOverVoxelSize;
+  cz = mm.y;
+  cx = cz * (((float)x - p.proj.z) * invFx);
+  cy = cz * (((float)y - p.proj.w) * invFy);
+  float totalLengthMax = sqrtf(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
+  t = mat_mul3(p.invM, cx, cy, cz, 1.0f);
+  float ex = t.x * oneOverVoxelSize, ey = t.y * oneOverVoxelSize, ez = t.z * oneOverVoxelSize;
+  float dx = ex - sx, dy = ey - sy, dz = ez - sz;
+  float direction_norm = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  dx *= direction_norm; dy *= direction_norm; dz *= direction_norm;
+
+  float rx = sx, ry = sy, rz = sz;
+  VoxCache cache; cache_init(cache);
+  float sdfValue = 1.0f, stepLength;
+  bool hash_found;
+  while (totalLength < totalLengthMax) {
+    sdfValue = read_sdf_uninterpolated(s, p, rx, ry, rz, hash_found, cache);
+    if (!hash_found) {
+      stepLength = (float)kBlockSize;
+    } else {
+      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = read_sdf_interpolated(s, p, rx, ry, rz, cache);
+      if (sdfValue <= 0.0f) break;
+      float ss = sdfValue * stepScale;
+      stepLength = (ss > 1.0f) ? ss : 1.0f;  // MAX(sdfValue * stepScale, 1.0f)
+    }
+    rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
+    totalLength += stepLength;
+  }
+  float4 out;
+  if (sdfValue <= 0.0f) {
+    stepLength = sdfValue * stepScale;
+    rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
+    sdfValue = read_sdf_interpolated(s, p, rx, ry, rz, cache);
+    stepLength = sdfValue * stepScale;
+    rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
+    out.w = 1.0f;
+  } else out.w = 0.0f;
+  out.x = rx; out.y = ry; out.z = rz;
+  return out;
+}
+
+// 8x8 pixel tile per wave (4 tiles per 256-thread workgroup, laid out 2x2 => 16x16 pixels)
+__global__ __launch_bounds__(256) void k_raycast(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
+                                                 float4 *__restrict__ raycastResult) {
+  if (s.ctr[ctrIdx] <= 0 && ctrIdx == CTR_NO_VISIBLE_LIVE) return;  // Prepare() is skipped without visible blocks
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= p.W || y >= p.H) return;
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];
+  raycastResult[x + y * p.W] = cast_ray(p, s, x, y, mm);
+}
+
+// ---------------------------------------------------------------- K8: ICP maps
+
+__device__ __forceinline__ uchar4 grey_px(float angle) {  // drawPixelGrey
+  float outRes = (0.8f * angle + 0.2f) * 255.0f;
+  uint8_t g = (uint8_t)f2i(outRes);
+  return make_uchar4(g, g, g, g);
+}
+
+// ITMVisualisationEngine.h processPixelICP<true> + computeNormalAndAngle<true> (image space)
+__global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const float4 *__restrict__ pointsRay,
+                                                  float4 *__restrict__ pointsMap, float4 *__restrict__ normalsMap,
+                                                  uchar4 *__restrict__ outRendering) {
+  if (s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int W = p.W, H = p.H;
+  const int locId = x + y * W;
+  const float lsx = -p.invM.m[8], lsy = -p.invM.m[9], lsz = -p.invM.m[10];
+  const float4 point = pointsRay[locId];
+  bool foundPoint = point.w > 0.0f;
+  float nx = 0, ny = 0, nz = 0, angle = 0;
+  if (foundPoint) {
+    if (y <= 2 || y >= H - 3 || x <= 2 || x >= W - 3) foundPoint = false;
+    else {
+      float4 xp1_y = pointsRay[(x + 2) + y * W], x_yp1 = pointsRay[x + (y + 2) * W];
+      float4 xm1_y = pointsRay[(x - 2) + y * W], x_ym1 = pointsRay[x + (y - 2) * W];
+      float4 diff_x = make_float4(0, 0, 0, 0), diff_y = make_float4(0, 0, 0, 0);
+      bool doPlus1 = false;
+      if (xp1_y.w <= 0 || x_yp1.w <= 0 || xm1_y.w <= 0 || x_ym1.w <= 0) doPlus1 = true;
+      else {
+        diff_x = make_float4(xp1_y.x - xm1_y.x, xp1_y.y - xm1_y.y, xp1_y.z - xm1_y.z, 0);
+        diff_y = make_float4(x_yp1.x - x_ym1.x, x_yp1.y - x_ym1.y, x_yp1.z - x_ym1.z, 0);
+        float a = diff_x.x * diff_x.x + diff_x.y * diff_x.y + diff_x.z * diff_x.z;
+        float b = diff_y.x * diff_y.x + diff_y.y * diff_y.y + diff_y.z * diff_y.z;
+        float length_diff = (a > b) ? a : b;  // MAX
+        if (length_diff * p.voxelSize * p.voxelSize > (0.15f * 0.15f)) doPlus1 = true;
+      }
+      if (doPlus1) {
+        xp1_y = pointsRay[(x + 1) + y * W]; x_yp1 = pointsRay[x + (y + 1) * W];
+        xm1_y = pointsRay[(x - 1) + y * W]; x_ym1 = pointsRay[x + (y - 1) * W];
+        diff_x = make_float4(xp1_y.x - xm1_y.x, xp1_y.y - xm1_y.y, xp1_y.z - xm1_y.z, 0);
+        diff_y = make_float4(x_yp1.x - x_ym1.x, x_yp1.y - x_ym1.y, x_yp1.z - x_ym1.z, 0);
+        if (xp1_y.w <= 0 || x_yp1.w <= 0 || xm1_y.w <= 0 || x_ym1.w <= 0) foundPoint = false;
+      }
+      if (foundPoint) {
+        nx = -(diff_x.y * diff_y.z - diff_x.z * diff_y.y);
+        ny = -(diff_x.z * diff_y.x - diff_x.x * diff_y.z);
+        nz = -(diff_x.x * diff_y.y - diff_x.y * diff_y.x);
+        float normScale = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+        nx *= normScale; ny *= normScale; nz *= normScale;
+        angle = nx * lsx + ny * lsy + nz * lsz;
+        if (!(angle > 0.0f)) foundPoint = false;
+      }
+    }
+  }
+  if (foundPoint) {
+    outRendering[locId] = grey_px(angle);
+    pointsMap[locId] = make_float4(point.x * p.voxelSize, point.y * p.voxelSize, point.z * p.voxelSize, 1.0f);
+    normalsMap[locId] = make_float4(nx, ny, nz, 0.0f);
+  } else {
+    float4 out4 = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    pointsMap[locId] = out4; normalsMap[locId] = out4;
+    outRendering[locId] = make_uchar4(0, 0, 0, 0);
+  }
+}
+
+// ------------------------------------------------------- free-view shading (K8)
+
+// ITMRepresentationAccess.h computeSingleNormalFromSDF
+__device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP &p, float x, float y, float z) {
+  VoxCache cache; cache_init(cache);
+  bool f;
+  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+  const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
+  const float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
+#define RD(dx, dy, dz) read_sdf_raw(s, p, ix + (dx), iy + (dy), iz + (dz), f, cache)
+  float4 front, back, tmp;
+  front.x = RD(0, 0, 0); front.y = RD(1, 0, 0); front.z = RD(0, 1, 0); front.w = RD(1, 1, 0);
+  back.x = RD(0, 0, 1); back.y = RD(1, 0, 1); back.z = RD(0, 1, 1); back.w = RD(1, 1, 1);
+  float p1, p2, v1;
+  float3 ret;
+  // gradient x
+  p1 = front.x * ny * nz + front.z * cy * nz + back.x * ny * cz + back.z * cy * cz;
+  tmp.x = RD(-1, 0, 0); tmp.y = RD(-1, 1, 0); tmp.z = RD(-1, 0, 1); tmp.w = RD(-1, 1, 1);
+  p2 = tmp.x * ny * nz + tmp.y * cy * nz + tmp.z * ny * cz + tmp.w * cy * cz;
+  v1 = p1 * cx + p2 * nx;
+  p1 = front.y * ny * nz + front.w * cy * nz + back.y * ny * cz + back.w * cy * cz;
+  tmp.x = RD(2, 0, 0); tmp.y = RD(2, 1, 0); tmp.z = RD(2, 0, 1); tmp.w = RD(2, 1, 1);
+  p2 = tmp.x * ny * nz + tmp.y * cy * nz + tmp.z * ny * cz + tmp.w * cy * cz;
+  ret.x = sdf_to_float(p1 * nx + p2 * cx - v1);
+  // gradient y
+  p1 = front.x * nx * nz + front.y * cx * nz + back.x * nx * cz + back.y * cx * cz;
+  tmp.x = RD(0, -1, 0); tmp.y = RD(1, -1, 0); tmp.z = RD(0, -1, 1); tmp.w = RD(1, -1, 1);
+  p2 = tmp.x * nx * nz + tmp.y * cx * nz + tmp.z * nx * cz + tmp.w * cx * cz;
+  v1 = p1 * cy + p2 * ny;
+  p1 = front.z * nx * nz + front.w * cx * nz + back.z * nx * cz + back.w * cx * cz;
+  tmp.x = RD(0, 2, 0); tmp.y = RD(1, 2, 0); tmp.z = RD(0, 2, 1); tmp.w = RD(1, 2, 1);
+  p2 = tmp.x * nx * nz + tmp.y * cx * nz + tmp.z * nx * cz + tmp.w * cx * cz;
+  ret.y = sdf_to_float(p1 * ny + p2 * cy - v1);
+  // gradient z
+  p1 = front.x * nx * ny + front.y * cx * ny + front.z * nx * cy + front.w * cx * cy;
+  tmp.x = RD(0, 0, -1); tmp.y = RD(1, 0, -1); tmp.z = RD(0, 1, -1); tmp.w = RD(1, 1, -1);
+  p2 = tmp.x * nx * ny + tmp.y * cx * ny + tmp.z * nx * cy + tmp.w * cx * cy;
+  v1 = p1 * cz + p2 * nz;
+  p1 = back.x * nx * ny + back.y * cx * ny + back.z * nx * cy + back.w * cx * cy;
+  tmp.x = RD(0, 0, 2); tmp.y = RD(1, 0, 2); tmp.z = RD(0, 1, 2); tmp.w = RD(1, 1, 2);
+  p2 = tmp.x * nx * ny + tmp.y * cx * ny + tmp.z * nx * cy + tmp.w * cx * cy;
+  ret.z = sdf_to_float(p1 * nz + p2 * cz - v1);
+#undef RD
+  return ret;
+}
+
+// ITMRepresentationAccess.h readFromSDF_color4u_interpolated (missing voxels: colour 0)
+__device__ __forceinline__ float3 color_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z) {
+  VoxCache cache; cache_init(cache);
+  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+  const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
+  float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+  auto acc = [&](int dx, int dy, int dz, float w) {
+    int lin;
+    int ptr = find_block(s, p, ix + dx, iy + dy, iz + dz, lin, cache);
+    uchar4 c = make_uchar4(0, 0, 0, 0);
+    if (ptr >= 0) c = *reinterpret_cast<const uchar4 *>(s.vba + (size_t)ptr * kBlockBytes + kOffClr + lin * 4);
+    rx += w * (float)c.x; ry += w * (float)c.y; rz += w * (float)c.z;
+  };
+  acc(0, 0, 0, (1.0f - cx) * (1.0f - cy) * (1.0f - cz));
+  acc(1, 0, 0, (cx) * (1.0f - cy) * (1.0f - cz));
+  acc(0, 1, 0, (1.0f - cx) * (cy) * (1.0f - cz));
+  acc(1, 1, 0, (cx) * (cy) * (1.0f - cz));
+  acc(0, 0, 1, (1.0f - cx) * (1.0f - cy) * cz);
+  acc(1, 0, 1, (cx) * (1.0f - cy) * cz);
+  acc(0, 1, 1, (1.0f - cx) * (cy) * cz);
+  acc(1, 1, 1, (cx) * (cy) * cz);
+  return make_float3(rx / 255.0f, ry / 255.0f, rz / 255.0f);
+}
+
+// RenderImage_common shading + the fork's FREECAMERA_DEPTH / COLOUR_FROM_DEPTH_WEIGHT
+// (definitions adopted in oracle/dsr_oracle.cpp render_image()).
+__global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, const float4 *__restrict__ pointsRay,
+                                                uchar4 *__restrict__ outRgba, float *__restrict__ outDepth) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int locId = x + y * p.W;
+  const float lsx = -p.invM.m[8], lsy = -p.invM.m[9], lsz = -p.invM.m[10];
+  const float4 pt = pointsRay[locId];
+  bool foundPoint = pt.w > 0;
+  uchar4 out = make_uchar4(0, 0, 0, 0);
+  switch (type) {
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME:
+      if (foundPoint) {
+        float3 c = color_interpolated(s, p, pt.x, pt.y, pt.z);
+        out.x = (uint8_t)f2i(c.x * 255.0f); out.y = (uint8_t)f2i(c.y * 255.0f); out.z = (uint8_t)f2i(c.z * 255.0f);
+        out.w = 255;
+      }
+      break;
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL:
+    case DSR_IMAGE_FREECAMERA_SHADED: {
+      float3 n = make_float3(0, 0, 0);
+      float angle = 0;
+      if (foundPoint) {
+        n = normal_from_sdf(s, p, pt.x, pt.y, pt.z);
+        float normScale = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+        n.x *= normScale; n.y *= normScale; n.z *= normScale;
+        angle = n.x * lsx + n.y * lsy + n.z * lsz;
+        if (!(angle > 0.0f)) foundPoint = false;
+      }
+      if (foundPoint) {
+        if (type == DSR_IMAGE_FREECAMERA_SHADED) out = grey_px(angle);
+        else {
+          out.x = (uint8_t)f2i((0.3f + (-n.x + 1.0f) * 0.35f) * 255.0f);
+          out.y = (uint8_t)f2i((0.3f + (-n.y + 1.0f) * 0.35f) * 255.0f);
+          out.z = (uint8_t)f2i((0.3f + (-n.z + 1.0f) * 0.35f) * 255.0f);
+          out.w = 0;
+        }
+      }
+    } break;
+    case DSR_IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT:
+      if (foundPoint) {
+        VoxCache cache; cache_init(cache);
+        int lin;
+        int ptr = find_block(s, p, f2i(roundf_itm(pt.x)), f2i(roundf_itm(pt.y)), f2i(roundf_itm(pt.z)), lin, cache);
+        float w = 0.0f;
+        if (ptr >= 0) w = (float)s.vba[(size_t)ptr * kBlockBytes + kOffWDepth + lin];
+        float t = w / (float)p.maxW;
+        t = (t > 0.0f) ? t : 0.0f;   // max(0, t)
+        t = (1.0f < t) ? 1.0f : t;   // min(1, .)
+        out.x = (uint8_t)f2i(255.0f * (1.0f - t)); out.y = 0; out.z = (uint8_t)f2i(255.0f * t); out.w = 255;
+      }
+      break;
+    default: break;
+  }
+  if (outRgba) outRgba[locId] = out;
+  if (outDepth) {
+    float d = 0.0f;
+    if (pt.w > 0) {
+      const float mx = pt.x * p.voxelSize, my = pt.y * p.voxelSize, mz = pt.z * p.voxelSize;
+      d = p.M.m[2] * mx + p.M.m[6] * my + p.M.m[10] * mz + p.M.m[14] * 1.0f;
+    }
+    outDepth[locId] = d;
+  }
+}
+
+}  // namespace dsr

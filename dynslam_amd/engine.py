@@ -1,0 +1,405 @@
+"""Host-side mirror of the reference's engine boundary, on top of the C ABI.
+
+`EngineCore` is a thin numpy-facing wrapper around the `dsr_*` entry points of
+include/dsr.h.  `InfiniTamDriver` re-creates the method names and argument
+meaning of the reference's `dynslam::drivers::InfiniTamDriver`
+(src/DynSLAM/InfiniTamDriver.h:79-300) so that tests read like calls the
+reference host makes.
+
+The product path is the HIP library `dynslam_amd/csrc/libdsr_hip.so`; loading
+fails loudly when it is missing (there is NO CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import (BLOCK_SIZE3, DSR_E_OUT_OF_BLOCKS, DSR_OK, Calib, Intrinsics, KernelTime,
+                    Settings, Stats)
+
+HASH_ENTRY_DTYPE = np.dtype([("pos", "<i2", (3,)), ("pad", "<i2"), ("offset", "<i4"), ("ptr", "<i4")])
+VOXEL_DTYPE = np.dtype([("sdf", "<i2"), ("w_depth", "u1"), ("clr", "u1", (3,)), ("w_color", "u1"), ("pad", "u1")])
+assert HASH_ENTRY_DTYPE.itemsize == 16 and VOXEL_DTYPE.itemsize == 8
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
+
+_hip_api = None
+
+
+class DsrError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"dsr status {status}: {message}")
+        self.status = status
+
+
+class OutOfBlocksError(DsrError):
+    """The fork's std::runtime_error on block exhaustion
+    (caught at InstanceReconstructor.cpp:662-671)."""
+
+
+def load_hip_api():
+    """Load libdsr_hip.so and bind every symbol of include/dsr.h.  No fallback."""
+    global _hip_api
+    if _hip_api is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise ImportError(
+                f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        lib = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
+        api = _capi.bind(lib, "dsr_")
+        if api.abi_version() != _capi.ABI_VERSION:
+            raise ImportError("libdsr_hip.so ABI version mismatch")
+        _hip_api = api
+    return _hip_api
+
+
+def default_settings(api=None, **overrides):
+    api = api or load_hip_api()
+    s = Settings()
+    api.default_settings(C.byref(s))
+    for k, v in overrides.items():
+        if not hasattr(s, k):
+            raise AttributeError(k)
+        setattr(s, k, v)
+    return s
+
+
+def make_calib(fx, fy, cx, cy, width, height):
+    """CreateItmCalib (InfiniTamDriver.cpp:49-79): identical rgb/depth intrinsics,
+    identity extrinsic, affine disparity calib (0.001, 0)."""
+    c = Calib()
+    for intr in (c.rgb, c.depth):
+        intr.fx, intr.fy, intr.cx, intr.cy = fx, fy, cx, cy
+        intr.width, intr.height = width, height
+    ident = np.eye(4, dtype=np.float32).T.reshape(-1)
+    c.trafo_rgb_to_depth[:] = ident.tolist()
+    c.disparity_calib[0] = 1.0 / 1000.0
+    c.disparity_calib[1] = 0.0
+    return c
+
+
+def _colmajor(m):
+    """4x4 math matrix -> float[16] column-major (ORUtils::Matrix4f::m)."""
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(4, 4).T).reshape(-1)
+    return a
+
+
+def _from_colmajor(buf):
+    return np.asarray(buf, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class EngineCore:
+    """One engine handle (an ITMMainEngine: scene + render states + view + pose)."""
+
+    def __init__(self, settings, calib, api=None):
+        self.api = api or load_hip_api()
+        self.settings = settings
+        self.calib = calib
+        self.W, self.H = calib.depth.width, calib.depth.height
+        self.no_total_entries = settings.hash_bucket_num + settings.excess_list_size
+        self.no_blocks = settings.sdf_local_block_num
+        h = C.c_void_p()
+        self._check(self.api.engine_create(C.byref(settings), C.byref(calib), C.byref(h)))
+        self._h = h
+
+    # -- plumbing -----------------------------------------------------------
+    def _check(self, status):
+        if status == DSR_OK:
+            return
+        msg = self.api.last_error()
+        msg = msg.decode() if msg else ""
+        if status == DSR_E_OUT_OF_BLOCKS:
+            raise OutOfBlocksError(status, msg)
+        raise DsrError(status, msg)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self.api.sync(self._h))
+
+    def reset_scene(self):
+        self._check(self.api.reset_scene(self._h))
+
+    # -- view ---------------------------------------------------------------
+    def update_view(self, rgba, depth_mm):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
+        assert rgba.shape == (self.H, self.W, 4) and depth_mm.shape == (self.H, self.W)
+        self._check(self.api.update_view(self._h, _ptr(rgba), _ptr(depth_mm)))
+
+    def update_view_dev(self, rgba_dev_ptr, depth_mm_dev_ptr):
+        self._check(self.api.update_view_dev(self._h, C.c_void_p(rgba_dev_ptr), C.c_void_p(depth_mm_dev_ptr)))
+
+    def set_view_float(self, rgba, depth_m):
+        rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        depth_m = np.ascontiguousarray(depth_m, dtype=np.float32)
+        assert rgba.shape == (self.H, self.W, 4) and depth_m.shape == (self.H, self.W)
+        self._check(self.api.set_view_float(self._h, _ptr(rgba), _ptr(depth_m)))
+
+    def set_view_float_dev(self, rgba_dev_ptr, depth_m_dev_ptr):
+        self._check(self.api.set_view_float_dev(self._h, C.c_void_p(rgba_dev_ptr), C.c_void_p(depth_m_dev_ptr)))
+
+    def get_view(self):
+        rgba = np.empty((self.H, self.W, 4), np.uint8)
+        depth = np.empty((self.H, self.W), np.float32)
+        self._check(self.api.get_view(self._h, _ptr(rgba), _ptr(depth)))
+        return rgba, depth
+
+    # -- pose ---------------------------------------------------------------
+    def set_pose_inv_m(self, inv_m):
+        a = _colmajor(inv_m)
+        self._check(self.api.set_pose_inv_m(self._h, _ptr(a)))
+
+    def set_pose_m(self, m):
+        a = _colmajor(m)
+        self._check(self.api.set_pose_m(self._h, _ptr(a)))
+
+    def get_pose(self):
+        m = np.empty(16, np.float32)
+        im = np.empty(16, np.float32)
+        self._check(self.api.get_pose(self._h, _ptr(m), _ptr(im)))
+        return _from_colmajor(m), _from_colmajor(im)
+
+    # -- fusion -------------------------------------------------------------
+    def set_fusion_weight_params(self, depth_weighting):
+        self._check(self.api.set_fusion_weight_params(self._h, int(bool(depth_weighting))))
+
+    def process_frame(self):
+        self._check(self.api.process_frame(self._h))
+
+    def allocate_scene_from_depth(self):
+        self._check(self.api.allocate_scene_from_depth(self._h))
+
+    def integrate_into_scene(self):
+        self._check(self.api.integrate_into_scene(self._h))
+
+    def prepare(self):
+        self._check(self.api.prepare(self._h))
+
+    def decay(self, max_weight, min_age, force_all_voxels=False):
+        self._check(self.api.decay(self._h, int(max_weight), int(min_age), int(bool(force_all_voxels))))
+
+    # -- rendering ----------------------------------------------------------
+    def get_image(self, image_type, pose_m=None, intrinsics=None, want_rgba=True, want_depth=False):
+        rgba = np.zeros((self.H, self.W, 4), np.uint8) if want_rgba else None
+        depth = np.zeros((self.H, self.W), np.float32) if want_depth else None
+        pm = _colmajor(pose_m) if pose_m is not None else None
+        intr = np.ascontiguousarray(intrinsics, dtype=np.float32) if intrinsics is not None else None
+        self._check(self.api.get_image(
+            self._h, int(image_type), _ptr(pm) if pm is not None else None,
+            _ptr(intr) if intr is not None else None,
+            _ptr(rgba) if rgba is not None else None, _ptr(depth) if depth is not None else None))
+        return rgba, depth
+
+    def get_image_dev(self, image_type, pose_m, intrinsics, rgba_dev_ptr, depth_dev_ptr):
+        pm = _colmajor(pose_m) if pose_m is not None else None
+        intr = np.ascontiguousarray(intrinsics, dtype=np.float32) if intrinsics is not None else None
+        self._check(self.api.get_image_dev(
+            self._h, int(image_type), _ptr(pm) if pm is not None else None,
+            _ptr(intr) if intr is not None else None,
+            C.c_void_p(rgba_dev_ptr) if rgba_dev_ptr else None,
+            C.c_void_p(depth_dev_ptr) if depth_dev_ptr else None))
+
+    # -- statistics and parity dumps -----------------------------------------
+    def get_stats(self):
+        st = Stats()
+        self._check(self.api.get_stats(self._h, C.byref(st)))
+        return st
+
+    def dump_hash_table(self):
+        out = np.empty(self.no_total_entries, HASH_ENTRY_DTYPE)
+        self._check(self.api.dump_hash_table(self._h, _ptr(out)))
+        return out
+
+    def dump_visible_list(self, freeview=False):
+        ids = np.empty(self.no_blocks, np.int32)
+        n = C.c_int32(0)
+        self._check(self.api.dump_visible_list(self._h, int(freeview), _ptr(ids), C.byref(n)))
+        return ids[: n.value].copy()
+
+    def dump_visible_types(self):
+        out = np.empty(self.no_total_entries, np.uint8)
+        self._check(self.api.dump_visible_types(self._h, _ptr(out)))
+        return out
+
+    def dump_voxel_blocks(self, first_block=0, n_blocks=None):
+        if n_blocks is None:
+            n_blocks = self.no_blocks - first_block
+        out = np.empty((n_blocks, BLOCK_SIZE3), VOXEL_DTYPE)
+        self._check(self.api.dump_voxel_blocks(self._h, int(first_block), int(n_blocks), _ptr(out)))
+        return out
+
+    def dump_allocation_lists(self):
+        v = np.empty(self.no_blocks, np.int32)
+        x = np.empty(self.settings.excess_list_size, np.int32)
+        self._check(self.api.dump_allocation_lists(self._h, _ptr(v), _ptr(x)))
+        return v, x
+
+    def dump_render_state(self, freeview=False):
+        mw, mh = (self.W + 7) // 8, (self.H + 7) // 8
+        out = {
+            "minmax": np.empty((mh, mw, 2), np.float32),
+            "raycast_result": np.empty((self.H, self.W, 4), np.float32),
+            "points": np.empty((self.H, self.W, 4), np.float32),
+            "normals": np.empty((self.H, self.W, 4), np.float32),
+            "raycast_image": np.empty((self.H, self.W, 4), np.uint8),
+        }
+        self._check(self.api.dump_render_state(
+            self._h, int(freeview), _ptr(out["minmax"]), _ptr(out["raycast_result"]), _ptr(out["points"]),
+            _ptr(out["normals"]), _ptr(out["raycast_image"])))
+        return out
+
+    # -- profiling ------------------------------------------------------------
+    def profile_enable(self, enable=True):
+        self._check(self.api.profile_enable(self._h, int(bool(enable))))
+
+    def profile_reset(self):
+        self._check(self.api.profile_reset(self._h))
+
+    def profile_get(self):
+        buf = (KernelTime * 64)()
+        n = self.api.profile_get(self._h, buf, 64)
+        return [dict(name=buf[i].name.decode(), total_ms=buf[i].total_ms, launches=buf[i].launches,
+                     bytes=buf[i].bytes) for i in range(n)]
+
+
+class VoxelDecayParams:
+    """src/DynSLAM/VoxelDecayParams.h"""
+
+    def __init__(self, enabled=True, min_decay_age=200, max_decay_weight=1):
+        self.enabled = enabled
+        self.min_decay_age = min_decay_age
+        self.max_decay_weight = max_decay_weight
+
+
+class PreviewType:
+    """src/DynSLAM/PreviewType.h"""
+    kDepth, kGray, kColor, kNormal, kWeight, kLatestRaycast = range(6)
+
+
+_PREVIEW_TO_IMAGE = {  # GetItmVisualization, InfiniTamDriver.cpp:16-34
+    PreviewType.kDepth: _capi.IMAGE_FREECAMERA_DEPTH,
+    PreviewType.kGray: _capi.IMAGE_FREECAMERA_SHADED,
+    PreviewType.kColor: _capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+    PreviewType.kNormal: _capi.IMAGE_FREECAMERA_COLOUR_FROM_NORMAL,
+    PreviewType.kWeight: _capi.IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT,
+    PreviewType.kLatestRaycast: _capi.IMAGE_SCENERAYCAST,
+}
+
+
+class InfiniTamDriver:
+    """Mirror of dynslam::drivers::InfiniTamDriver (InfiniTamDriver.h:79-300).
+
+    Same method names, argument meaning and error behaviour:
+      UpdateView(rgb, raw_depth)  .cpp:211-224   (rgb here is RGBA uint8, depth int16 mm)
+      SetPose(new_pose)           .h:131-135     (camera->world, sets pose_d.invM)
+      Integrate()                 .h:137-146     (raises OutOfBlocksError like the fork throws)
+      PrepareNextStep()           .h:148-158
+      Decay()/DecayCatchup()/Reap(w)  .h:201-235
+      GetImage/GetFloatImage      .cpp:165-209   (silent no-op before the first frame)
+      GetUsedMemoryBytes/GetSavedDecayMemoryBytes  .h:241-250
+      Reset()                     .h:282-284
+    """
+
+    def __init__(self, settings, calib, voxel_decay_params=None, use_depth_weighting=False, api=None):
+        self.core = EngineCore(settings, calib, api=api)
+        self.voxel_decay_params = voxel_decay_params or VoxelDecayParams(False, 0, 0)
+        self.use_depth_weighting = bool(use_depth_weighting)
+        self._has_view = False
+        self._last_egomotion = np.eye(4, dtype=np.float32)
+
+    def UpdateView(self, rgba_image, raw_depth_image):
+        self.core.update_view(rgba_image, raw_depth_image)
+        self._has_view = True
+
+    def SetView(self, rgba_image, depth_m):
+        """SetView(ITMView*) with the already converted instance view
+        (InstanceReconstructor.cpp:580)."""
+        self.core.set_view_float(rgba_image, depth_m)
+        self._has_view = True
+
+    def SetPose(self, new_pose):
+        _, old_inv = self.core.get_pose()
+        self._last_egomotion = np.linalg.inv(old_inv) @ np.asarray(new_pose, np.float32)
+        self.core.set_pose_inv_m(new_pose)
+
+    def GetPose(self):
+        return self.core.get_pose()[1]
+
+    def GetLastEgomotion(self):
+        return self._last_egomotion
+
+    def Integrate(self):
+        self.core.set_fusion_weight_params(self.use_depth_weighting)
+        self.core.process_frame()
+
+    def PrepareNextStep(self):
+        self.core.prepare()
+
+    def Decay(self):
+        p = self.voxel_decay_params
+        if p.enabled:
+            self.core.decay(p.max_decay_weight, p.min_decay_age, False)
+
+    def DecayCatchup(self):
+        p = self.voxel_decay_params
+        if p.enabled:
+            for _ in range(p.min_decay_age):
+                self.core.decay(p.max_decay_weight, 0, False)
+
+    def Reap(self, max_decay_weight):
+        if self.voxel_decay_params.enabled:
+            self.core.decay(max_decay_weight, 0, True)
+
+    def GetImage(self, preview_type, model_view=None):
+        if not self._has_view:
+            return None
+        if preview_type == PreviewType.kDepth:
+            return None  # "Cannot preview depth normally anymore." .cpp:171-175
+        rgba, _ = self.core.get_image(_PREVIEW_TO_IMAGE[preview_type], pose_m=model_view)
+        return rgba
+
+    def GetFloatImage(self, preview_type, model_view=None):
+        if not self._has_view:
+            return None
+        if preview_type != PreviewType.kDepth:
+            return None  # "Can only preview depth as float." .cpp:196-199
+        _, depth = self.core.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=model_view, want_rgba=False,
+                                       want_depth=True)
+        return depth
+
+    def GetVoxelSizeBytes(self):
+        return self.core.get_stats().voxel_bytes
+
+    def GetUsedMemoryBytes(self):
+        st = self.core.get_stats()
+        num_used_blocks = st.num_allocated_voxel_blocks - st.last_free_block_id
+        return st.voxel_bytes * st.block_voxels * num_used_blocks
+
+    def GetSavedDecayMemoryBytes(self):
+        st = self.core.get_stats()
+        return st.decayed_block_count * st.voxel_bytes * st.block_voxels
+
+    def IsDecayEnabled(self):
+        return self.voxel_decay_params.enabled
+
+    def IsUsingDepthWeights(self):
+        return self.use_depth_weighting
+
+    def Reset(self):
+        self.core.reset_scene()

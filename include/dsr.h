@@ -1,0 +1,281 @@
+/*
+ * dsr.h — C ABI of the MI355X-native dense scene reconstruction (DSR) engine.
+ *
+ * This is the drop-in boundary for DynSLAM's voxel-hashed TSDF hot path
+ * (allocation -> integration -> [swap/decay] -> raycast).  In the reference the
+ * boundary is C++ inheritance: `class InfiniTamDriver : public ITMMainEngine`
+ * (src/DynSLAM/InfiniTamDriver.h:79) poking at ITMLib's protected members.  There
+ * is no FFI layer in the reference, so every entry point below cites the ITMLib
+ * call (as seen from DynSLAM's call sites) that it replaces.  The header-only C++
+ * shim in shim/ re-creates the ITMLib class/method names on top of these calls.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types.
+ *   - 4x4 matrices are float[16] COLUMN-MAJOR, exactly ORUtils::Matrix4f::m
+ *     (InfiniTamDriver.cpp:146-163).
+ *   - RGBA images are uint8[4*W*H] in R,G,B,A order (InfiniTamDriver.cpp:89-94).
+ *   - raw depth is int16 millimetres (InfiniTamDriver.cpp:52,77), float depth is
+ *     metres with <=0 meaning "invalid" (InstanceReconstructor.cpp:97,165).
+ *   - every call returns a dsr_status (0 == DSR_OK) unless stated otherwise.
+ *   - calls on one engine handle must come from one thread at a time; distinct
+ *     handles are independent (each owns its HIP stream).
+ *   - "_dev" variants take pointers to device (HBM) memory on the engine's GPU.
+ *
+ * The same signatures, with the prefix `orc_` instead of `dsr_`, are exported by
+ * the CPU oracle (oracle/dsr_oracle.cpp), which is TEST INFRASTRUCTURE only.
+ */
+#ifndef DSR_H_
+#define DSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSR_ABI_VERSION 1
+
+/* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
+#define DSR_BLOCK_SIZE 8
+#define DSR_BLOCK_SIZE3 512
+/* Upstream ITMLibDefines.h compile-time sizes; runtime-configurable here because
+ * the fork already made sdfLocalBlockNum a runtime setting
+ * (InstanceReconstructor.cpp:379). */
+#define DSR_DEFAULT_BUCKET_NUM 0x100000
+#define DSR_DEFAULT_EXCESS_LIST_SIZE 0x20000
+#define DSR_DEFAULT_LOCAL_BLOCK_NUM 0x40000
+#define DSR_TRANSFER_BLOCK_NUM 0x1000
+
+typedef enum dsr_status {
+  DSR_OK = 0,
+  DSR_E_ARG = 1,           /* bad argument / unsupported combination          */
+  DSR_E_DEVICE = 2,        /* HIP runtime error (ITMSafeCall in the reference) */
+  DSR_E_OUT_OF_BLOCKS = 3, /* voxel block array or excess list exhausted; the
+                              fork throws std::runtime_error, caught at
+                              InstanceReconstructor.cpp:662-671                */
+  DSR_E_NO_VIEW = 4,       /* no frame given yet (InfiniTamDriver.cpp:168,185) */
+  DSR_E_NOMEM = 5
+} dsr_status;
+
+/* ITMHashEntry (ITMLib/Objects/ITMVoxelBlockHash.h): 16 bytes.
+ * pos: block coordinates; offset-1 = index into the excess list of the next
+ * entry of the chain (<1: end); ptr >= 0: block index in the voxel block array,
+ * -1: swapped out, < -1: unallocated. */
+typedef struct dsr_hash_entry {
+  int16_t pos[3];
+  int16_t _pad;
+  int32_t offset;
+  int32_t ptr;
+} dsr_hash_entry;
+
+/* ITMVoxel_s_rgb (ITMLib/Utils/ITMLibDefines.h), 8 bytes; the array-of-structs
+ * exchange format used by the dump/load/swap entry points.  (The HIP engine
+ * stores blocks plane-wise in HBM; this is the interchange
+ * layout.) */
+typedef struct dsr_voxel {
+  int16_t sdf;     /* float value = sdf / 32767                */
+  uint8_t w_depth; /* integration weight                       */
+  uint8_t clr[3];  /* running mean colour                      */
+  uint8_t w_color;
+  uint8_t _pad;
+} dsr_voxel;
+
+/* ITMSceneParams + the ITMLibSettings fields DynSLAM touches
+ * (DynSLAMGUI.cpp:1214-1219; InstanceReconstructor.cpp:365-380). */
+typedef struct dsr_settings {
+  float voxel_size;        /* sceneParams.voxelSize [m]                       */
+  float mu;                /* sceneParams.mu, truncation band [m]             */
+  int32_t max_w;           /* sceneParams.maxW                                */
+  float view_frustum_min;  /* sceneParams.viewFrustum_min [m]                 */
+  float view_frustum_max;  /* sceneParams.viewFrustum_max [m]                 */
+  int32_t stop_integrating_at_max_w;
+  int32_t sdf_local_block_num; /* settings->sdfLocalBlockNum (fork)           */
+  int32_t hash_bucket_num;     /* SDF_BUCKET_NUM, power of two                */
+  int32_t excess_list_size;    /* SDF_EXCESS_LIST_SIZE                        */
+  int32_t use_swapping;        /* settings->useSwapping                       */
+  int32_t use_bilateral_filter;/* settings->useBilateralFilter                */
+  int32_t device;              /* HIP device ordinal; -1 = current device     */
+  int32_t sync_status;         /* 1: dsr_process_frame synchronises and returns
+                                  DSR_E_OUT_OF_BLOCKS itself (shim behaviour);
+                                  0: fully asynchronous, poll dsr_get_stats   */
+  int32_t reserved[7];
+} dsr_settings;
+
+/* ITMIntrinsics::projectionParamsSimple + image size
+ * (InfiniTamDriver.cpp:55-68). */
+typedef struct dsr_intrinsics {
+  float fx, fy, cx, cy;
+  int32_t width, height;
+} dsr_intrinsics;
+
+/* ITMRGBDCalib (InfiniTamDriver.cpp:49-79): rgb and depth intrinsics, the
+ * rgb->depth extrinsic and the affine disparity calibration (0.001, 0). */
+typedef struct dsr_calib {
+  dsr_intrinsics rgb;
+  dsr_intrinsics depth;
+  float trafo_rgb_to_depth[16]; /* column-major; identity in DynSLAM          */
+  float disparity_calib[2];     /* depth_m = raw * [0] + [1]                  */
+} dsr_calib;
+
+/* ITMMainEngine::GetImageType values reached through
+ * GetItmVisualization (InfiniTamDriver.cpp:16-34). */
+typedef enum dsr_image_type {
+  DSR_IMAGE_ORIGINAL_RGB = 0,
+  DSR_IMAGE_ORIGINAL_DEPTH = 1,
+  DSR_IMAGE_SCENERAYCAST = 2,                       /* kLatestRaycast */
+  DSR_IMAGE_FREECAMERA_SHADED = 3,                  /* kGray          */
+  DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME = 4,      /* kColor         */
+  DSR_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL = 5,      /* kNormal        */
+  DSR_IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT = 6,/* kWeight (fork) */
+  DSR_IMAGE_FREECAMERA_DEPTH = 7                    /* kDepth (fork, float) */
+} dsr_image_type;
+
+/* Counters the host reads for its memory statistics
+ * (InfiniTamDriver.h:237-250) plus launch-free status. */
+typedef struct dsr_stats {
+  int32_t num_allocated_voxel_blocks; /* scene->index.getNumAllocatedVoxelBlocks() == sdf_local_block_num */
+  int32_t last_free_block_id;         /* scene->localVBA.lastFreeBlockId            */
+  int32_t last_free_excess_list_id;
+  int32_t no_visible_blocks;          /* renderState_live->noVisibleBlocks          */
+  int32_t no_total_entries;           /* hash_bucket_num + excess_list_size         */
+  int32_t voxel_bytes;                /* sizeof(ITMVoxel) == 8                      */
+  int32_t block_voxels;               /* SDF_BLOCK_SIZE3 == 512                     */
+  int32_t sticky_status;              /* DSR_OK or DSR_E_OUT_OF_BLOCKS seen so far  */
+  int64_t decayed_block_count;        /* denseMapper->GetDecayedBlockCount()        */
+  int64_t frames_processed;
+  int32_t no_visible_blocks_freeview;
+  int32_t reserved[5];
+} dsr_stats;
+
+typedef struct dsr_engine dsr_engine; /* opaque: one ITMMainEngine (scene + render
+                                         states + view + tracking state)        */
+
+/* ---- lifetime --------------------------------------------------------------- */
+
+int dsr_abi_version(void);
+/* Fills upstream ITMLibSettings/ITMSceneParams defaults (voxel 0.005, mu 0.02,
+ * maxW 100, frustum [0.2,3.0] are upstream's indoor values; DynSLAM overrides
+ * them: DynSLAMGUI.cpp:1214-1219). */
+void dsr_default_settings(dsr_settings *s);
+/* Thread-local text of the last failure. */
+const char *dsr_last_error(void);
+
+/* ITMMainEngine::ITMMainEngine(settings, calib, imgSize_rgb, imgSize_d)
+ * (InfiniTamDriver.h:84-91; InstanceReconstructor.cpp:382-389).  Allocates the
+ * scene (hash table, excess list, voxel block array), both render states, the
+ * view and the tracking state, then resets the scene. */
+int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_engine **out);
+void dsr_engine_destroy(dsr_engine *e);
+/* denseMapper->ResetScene(scene) (InfiniTamDriver.h:282-284). */
+int dsr_reset_scene(dsr_engine *e);
+/* Blocks until all work queued on the engine's stream is done
+ * (cudaDeviceSynchronize at DynSlam.cpp:165-172). */
+int dsr_sync(dsr_engine *e);
+
+/* ---- view ------------------------------------------------------------------- */
+
+/* viewBuilder->UpdateView(&view, rgb, rawDepth, useBilateralFilter, ...)
+ * (InfiniTamDriver.cpp:222-223): copies RGBA, converts int16 mm -> float m
+ * (<=0 or >32000 -> -1), optional bilateral filter.  Host pointers. */
+int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm);
+/* Same with inputs already resident in HBM (no PCIe copy). */
+int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev);
+/* SetView() with an already converted view: RGBA + float depth in metres.  This
+ * is what InstanceReconstructor builds per instance
+ * (InstanceReconstructor.cpp:238-263,580) and what it writes back into the main
+ * view after masking (:196-197). */
+int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m);
+int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m_dev);
+/* view->rgb / view->depth ->UpdateHostFromDevice()
+ * (InstanceReconstructor.cpp:180-181; InfiniTamDriver.h:155-156).  Either
+ * pointer may be NULL. */
+int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out);
+
+/* ---- pose (trackingState->pose_d) ------------------------------------------- */
+
+/* pose_d->SetInvM(invM) (InfiniTamDriver.h:131-134): invM = camera->world. */
+int dsr_set_pose_inv_m(dsr_engine *e, const float inv_m[16]);
+/* pose_d->SetM(M): M = world->camera. */
+int dsr_set_pose_m(dsr_engine *e, const float m[16]);
+int dsr_get_pose(dsr_engine *e, float m_out[16], float inv_m_out[16]);
+
+/* ---- fusion ------------------------------------------------------------------ */
+
+/* denseMapper->SetFusionWeightParams(params) (InfiniTamDriver.h:138). */
+int dsr_set_fusion_weight_params(dsr_engine *e, int depth_weighting);
+/* denseMapper->ProcessFrame(view, trackingState, scene, renderState_live)
+ * (InfiniTamDriver.h:140-145): AllocateSceneFromDepth + IntegrateIntoScene
+ * (+ swapping if enabled). */
+int dsr_process_frame(dsr_engine *e);
+/* The two halves of ProcessFrame, for tests and per-stage timing. */
+int dsr_allocate_scene_from_depth(dsr_engine *e);
+int dsr_integrate_into_scene(dsr_engine *e);
+/* trackingController->Prepare(trackingState, view, renderState_live)
+ * (InfiniTamDriver.h:152): CreateExpectedDepths + CreateICPMaps.  A no-op when
+ * noVisibleBlocks == 0 (InfiniTamDriver.h:150). */
+int dsr_prepare(dsr_engine *e);
+
+/* denseMapper->Decay(scene, renderState, maxWeight, minAge, forceAllVoxels)
+ * (InfiniTamDriver.h:201-235): voxel garbage collection. */
+int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels);
+
+/* ---- rendering --------------------------------------------------------------- */
+
+/* ITMMainEngine::GetImage(out, outFloat, type, pose, intrinsics)
+ * (InfiniTamDriver.cpp:178-183,202-207).  pose_m: world->camera of the free
+ * camera (NULL: current pose_d); intrinsics: fx,fy,cx,cy (NULL: depth calib).
+ * rgba_out (4*W*H bytes) and/or depth_out (W*H floats; metres, 0 = miss) are HOST
+ * buffers; either may be NULL. */
+int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4],
+                  uint8_t *rgba_out, float *depth_out);
+/* Same, results left in caller-provided HBM buffers (for the multi-GPU
+ * composite: the RCCL all-gather reads them in place). */
+int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4],
+                      void *rgba_out_dev, void *depth_out_dev);
+
+/* ---- statistics / parity dumps ------------------------------------------------ */
+
+/* Synchronises. */
+int dsr_get_stats(dsr_engine *e, dsr_stats *out);
+
+/* Copies of the engine state for parity tests against the oracle.  All host
+ * buffers, caller-sized:
+ *   hash entries      : no_total_entries * sizeof(dsr_hash_entry)
+ *   visible ids       : up to sdf_local_block_num int32 (returns count via *n)
+ *   visible types     : no_total_entries uint8
+ *   voxel blocks      : sdf_local_block_num * 512 * sizeof(dsr_voxel)  (AoS)
+ *   allocation lists  : sdf_local_block_num int32, excess_list_size int32
+ */
+int dsr_dump_hash_table(dsr_engine *e, dsr_hash_entry *out);
+int dsr_dump_visible_list(dsr_engine *e, int freeview, int32_t *ids_out, int32_t *n);
+int dsr_dump_visible_types(dsr_engine *e, uint8_t *out);
+int dsr_dump_voxel_blocks(dsr_engine *e, int first_block, int n_blocks, dsr_voxel *out);
+int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t *excess_alloc_list);
+/* Render-state buffers: which = 0 live, 1 freeview.  Any pointer may be NULL.
+ *   minmax        : 2 * ceil(W/8) * ceil(H/8) floats (renderingRangeImage)
+ *   raycast_result: 4*W*H floats (voxel units, w = found)
+ *   points/normals: 4*W*H floats (trackingState->pointCloud; live only)
+ *   raycast_image : 4*W*H bytes */
+int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result,
+                          float *points, float *normals, uint8_t *raycast_image);
+
+/* ---- per-kernel timing (roofline harness) -------------------------------------- */
+
+typedef struct dsr_kernel_time {
+  char name[32];
+  double total_ms;   /* sum of HIP-event durations on the engine's stream */
+  int64_t launches;
+  double bytes;      /* algorithmic bytes accumulated (SURVEY.md 8d model) */
+} dsr_kernel_time;
+/* enable != 0 brackets every kernel launch with HIP events (adds sync points:
+ * for measurement only). */
+int dsr_profile_enable(dsr_engine *e, int enable);
+int dsr_profile_reset(dsr_engine *e);
+/* Returns the number of records written (<= cap). */
+int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSR_H_ */
