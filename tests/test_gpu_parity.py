@@ -38,7 +38,8 @@ def test_hash_collisions_and_excess_list(hip_api):
     for i in range(4):
         feed((g, o), sc, i)
         assert_scene_equal(g, o, voxels=False)
-    assert o.get_stats().last_free_excess_list_id < 0x8000 - 1000
+    # one allocation per chain tail per frame: 3 frames x 256 chains go through the excess list
+    assert o.get_stats().last_free_excess_list_id <= 0x8000 - 1 - 3 * 256
     assert_scene_equal(g, o)
     assert_render_equal(g, o)
 
