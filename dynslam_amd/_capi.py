@@ -2,7 +2,7 @@
 
 `bind(lib, prefix)` attaches argtypes/restypes for every entry point the header
 declares; the product binds `dsr_` from libdsr_hip.so (engine.py), the test
-infrastructure binds `orc_` from oracle/liboracle.so (oracle/oracle.py).
+infrastructure binds the same signatures with the prefix `orc_` from the CPU checker library.
 """
 import ctypes as C
 from types import SimpleNamespace
@@ -104,6 +104,8 @@ SIGNATURES = {
     "decay": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
     "get_image": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
     "get_image_dev": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
+    "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "dump_hash_table": (C.c_int, [_H, _P]),
     "dump_visible_list": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int32)]),

@@ -20,6 +20,7 @@
 
 #include "dsr_device.h"
 #include "k_alloc.h"
+#include "k_composite.h"
 #include "k_decay.h"
 #include "k_integrate.h"
 #include "k_raycast.h"
@@ -734,6 +735,62 @@ int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const flo
                       void *depth_out_dev) {
   CHECK_E(e);
   return render_common(e, type, pose_m, intrinsics, rgba_out_dev, depth_out_dev, true);
+}
+
+// ---- instance compositing
+
+static const unsigned char kMatplotlib2Palette[10][3] = {  // InstanceReconstructor.cpp:44-55
+    {0x1f, 0x77, 0xb4}, {0xff, 0x7f, 0x0e}, {0x2c, 0xa0, 0x2c}, {0xd6, 0x27, 0x28}, {0x94, 0x67, 0xbd},
+    {0x8c, 0x56, 0x4b}, {0xe3, 0x77, 0xc2}, {0x71, 0x71, 0x71}, {0xbc, 0xbd, 0x22}, {0x17, 0xbe, 0xcf}};
+
+int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
+                                int n_layers, int n_pixels, float tint_strength, int dim_background) {
+  if (!target_depth_dev || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
+  if (n_layers > 0 && (!layers_depth_dev || !track_ids || (target_rgba_dev && !layers_rgba_dev)))
+    return fail(DSR_E_ARG, "null layer buffers");
+  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  CompositeP c;
+  memset(&c, 0, sizeof c);
+  c.nLayers = n_layers; c.nPixels = n_pixels; c.dimBackground = dim_background; c.tintStrength = tint_strength;
+  for (int l = 0; l < n_layers; ++l) {
+    const unsigned char *t = kMatplotlib2Palette[((track_ids[l] % 10) + 10) % 10];
+    c.tint[l] = make_uchar4(t[0], t[1], t[2], 255);
+  }
+  hipLaunchKernelGGL(k_composite, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
+                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
+                     (const float *)layers_depth_dev);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
+                            const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
+                            float tint_strength, int dim_background) {
+  if (!target_depth || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
+  const size_t P = (size_t)n_pixels, L = (size_t)n_layers;
+  uchar4 *tR = nullptr, *lR = nullptr;
+  float *tD = nullptr, *lD = nullptr;
+  int st = DSR_OK;
+  auto cleanup = [&]() { if (tR) (void)hipFree(tR); if (lR) (void)hipFree(lR); if (tD) (void)hipFree(tD); if (lD) (void)hipFree(lD); };
+  if ((st = dmalloc(&tD, P))) { cleanup(); return st; }
+  if (L && (st = dmalloc(&lD, P * L))) { cleanup(); return st; }
+  if (target_rgba && (st = dmalloc(&tR, P))) { cleanup(); return st; }
+  if (target_rgba && L && (st = dmalloc(&lR, P * L))) { cleanup(); return st; }
+#define CP(expr) if ((expr) != hipSuccess) { cleanup(); return fail(DSR_E_DEVICE, "composite copy failed"); }
+  CP(hipMemcpy(tD, target_depth, P * 4, hipMemcpyHostToDevice));
+  if (L) CP(hipMemcpy(lD, layers_depth, P * L * 4, hipMemcpyHostToDevice));
+  if (tR) CP(hipMemcpy(tR, target_rgba, P * 4, hipMemcpyHostToDevice));
+  if (lR) CP(hipMemcpy(lR, layers_rgba, P * L * 4, hipMemcpyHostToDevice));
+  st = dsr_composite_instances_dev(-1, nullptr, tR, tD, lR, lD, track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  if (st) { cleanup(); return st; }
+  CP(hipDeviceSynchronize());
+  CP(hipMemcpy(target_depth, tD, P * 4, hipMemcpyDeviceToHost));
+  if (tR) CP(hipMemcpy(target_rgba, tR, P * 4, hipMemcpyDeviceToHost));
+#undef CP
+  cleanup();
+  return DSR_OK;
 }
 
 // ---- statistics / dumps

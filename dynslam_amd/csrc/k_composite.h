@@ -1,0 +1,55 @@
+// k_composite.h — on-GPU instance compositing.
+//
+// Replaces the host loops CompositeInstances / CompositeColor / CompositeDepth
+// (InstanceReconstructor.cpp:851-990): software z-buffer over the per-instance raycast
+// renders, in the host's iteration order.  One thread per pixel walks the layers
+// sequentially, so the strict "t > s" rule is applied exactly as the serial code does.
+// Colour arithmetic is in double like the reference (uchar * double literals).
+#pragma once
+#include "dsr_device.h"
+
+namespace dsr {
+
+constexpr int kMaxCompositeLayers = 64;
+
+struct CompositeP {
+  int nLayers, nPixels, dimBackground;
+  float tintStrength;
+  uchar4 tint[kMaxCompositeLayers];  // kMatplotlib2Palette[track_id % 10], resolved on the host
+};
+
+__global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
+                                                   const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.nPixels) return;
+  float t = tDepth[i];
+  uchar4 col = make_uchar4(0, 0, 0, 0);
+  if (tRgba) {
+    col = tRgba[i];
+    if (c.dimBackground) {
+      const double f = 1.0 - (double)0.10f;
+      col.x = (unsigned char)((double)col.x * f);
+      col.y = (unsigned char)((double)col.y * f);
+      col.z = (unsigned char)((double)col.z * f);
+    }
+  }
+  const double colStrength = 1.0 + (double)0.50f - (double)c.tintStrength;
+  for (int l = 0; l < c.nLayers; ++l) {
+    const float s = lDepth[(size_t)l * c.nPixels + i];
+    const bool onTop = (s != 0.0f) && (t == 0.0f || t > s);
+    if (!onTop) continue;
+    t = s;
+    if (tRgba) {
+      const uchar4 sc = lRgba[(size_t)l * c.nPixels + i];
+      const uchar4 tint = c.tint[l];
+      const double r = fmin(255.0, (double)sc.x * colStrength + (double)tint.x * (double)c.tintStrength);
+      const double g = fmin(255.0, (double)sc.y * colStrength + (double)tint.y * (double)c.tintStrength);
+      const double b = fmin(255.0, (double)sc.z * colStrength + (double)tint.z * (double)c.tintStrength);
+      col.x = (unsigned char)r; col.y = (unsigned char)g; col.z = (unsigned char)b;
+    }
+  }
+  tDepth[i] = t;
+  if (tRgba) tRgba[i] = col;
+}
+
+}  // namespace dsr

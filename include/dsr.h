@@ -234,6 +234,29 @@ int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float i
 int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4],
                       void *rgba_out_dev, void *depth_out_dev);
 
+/* ---- instance compositing (the fused preview) ------------------------------------ */
+
+/* InstanceReconstructor::CompositeInstances (InstanceReconstructor.cpp:933-990) and
+ * CompositeInstanceDepthMaps (:911-931) on n_layers instance renders of n_pixels pixels:
+ *   - if dim_background: target colour *= (1.0 - 0.10f) in double, truncated (:945-954);
+ *   - for each layer IN THE GIVEN ORDER (the host iterates tracks by ascending id): the
+ *     instance wins a pixel iff s != 0 && (t == 0 || t > s) (CompositeColor :875-908),
+ *     then t = s and colour = min(255, c*(1.0+0.5-tint_strength) + tint*tint_strength) with
+ *     tint = kMatplotlib2Palette[track_id % 10] (:44-55), double arithmetic, truncated.
+ *   - target_rgba == NULL: depth only (CompositeDepth :851-871; same depth result).
+ * layers_rgba: [n_layers][n_pixels][4] bytes, layers_depth: [n_layers][n_pixels] floats
+ * (metres, 0 = miss); target_*: [n_pixels], updated in place; track_ids: host int32[n_layers].
+ * The _dev variant takes HBM pointers on `device` and enqueues on `hip_stream` (a
+ * hipStream_t, NULL = the default stream) without synchronising — it is what runs after
+ * the RCCL all-gather of the per-GPU raycast buffers.  The host variant synchronises. */
+int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                const void *layers_rgba_dev, const void *layers_depth_dev,
+                                const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
+                                int dim_background);
+int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
+                            const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
+                            float tint_strength, int dim_background);
+
 /* ---- statistics / parity dumps ------------------------------------------------ */
 
 /* Synchronises. */

@@ -1292,6 +1292,45 @@ int orc_get_image_dev(dsr_engine *h, int type, const float pose_m[16], const flo
   return orc_get_image(h, type, pose_m, intrinsics, (uint8_t *)rgba_out, (float *)depth_out);
 }
 
+/* InstanceReconstructor::CompositeInstances / CompositeColor / CompositeDepth
+ * (InstanceReconstructor.cpp:851-990), restated on raw buffers. */
+int orc_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
+                            const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
+                            float tint_strength, int dim_background) {
+  static const int pal[10][3] = {{0x1f, 0x77, 0xb4}, {0xff, 0x7f, 0x0e}, {0x2c, 0xa0, 0x2c}, {0xd6, 0x27, 0x28},
+                                 {0x94, 0x67, 0xbd}, {0x8c, 0x56, 0x4b}, {0xe3, 0x77, 0xc2}, {0x71, 0x71, 0x71},
+                                 {0xbc, 0xbd, 0x22}, {0x17, 0xbe, 0xcf}};
+  if (!target_depth || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
+  if (target_rgba && dim_background) {
+    float dim_factor = 0.10f;
+    for (int i = 0; i < n_pixels; i++)
+      for (int ch = 0; ch < 3; ch++) target_rgba[4 * i + ch] = static_cast<uint8_t>(target_rgba[4 * i + ch] * (1.0 - dim_factor));
+  }
+  const float kColorBoost = 0.50f;
+  for (int l = 0; l < n_layers; l++) {
+    const float *s_depth = layers_depth + (size_t)l * n_pixels;
+    const uint8_t *s_col = layers_rgba ? layers_rgba + (size_t)l * n_pixels * 4 : nullptr;
+    const int *tint = pal[((track_ids[l] % 10) + 10) % 10];
+    for (int idx = 0; idx < n_pixels; idx++) {
+      bool instance_on_top = (s_depth[idx] != 0 && (target_depth[idx] == 0 || target_depth[idx] > s_depth[idx]));
+      if (!instance_on_top) continue;
+      target_depth[idx] = s_depth[idx];
+      if (target_rgba) {
+        double col_strength = 1.0 + kColorBoost - tint_strength;
+        for (int ch = 0; ch < 3; ch++)
+          target_rgba[4 * idx + ch] = static_cast<uint8_t>(std::min(255.0, s_col[4 * idx + ch] * col_strength + tint[ch] * tint_strength));
+      }
+    }
+  }
+  return DSR_OK;
+}
+int orc_composite_instances_dev(int, void *, void *target_rgba, void *target_depth, const void *layers_rgba,
+                                const void *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
+                                float tint_strength, int dim_background) {
+  return orc_composite_instances((uint8_t *)target_rgba, (float *)target_depth, (const uint8_t *)layers_rgba,
+                                 (const float *)layers_depth, track_ids, n_layers, n_pixels, tint_strength, dim_background);
+}
+
 int orc_get_stats(dsr_engine *h, dsr_stats *out) {
   if (!h || !out) return fail(DSR_E_ARG, "null");
   memset(out, 0, sizeof *out);

@@ -1,0 +1,27 @@
+"""Committed golden digests (tests/golden/state_digests.json, made by make_golden.py):
+the oracle must keep reproducing them (CPU), the HIP engine must match them (-m gpu)."""
+import json
+import os
+
+import pytest
+
+from tests.golden.make_golden import CASES, oracle_factory, run_case
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "state_digests.json")))["cases"]
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_golden(oracle_lib, name):
+    assert run_case(oracle_factory, CASES[name]) == GOLD[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_matches_golden(hip_api, name):
+    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+
+    def hip_factory(settings, calib_args):
+        return EngineCore(default_settings(**settings), make_calib(*calib_args))
+    got = run_case(hip_factory, CASES[name])
+    diff = {k: (got[k], GOLD[name][k]) for k in got if got[k] != GOLD[name][k]}
+    assert not diff, f"fields differing from the golden fixture: {sorted(diff)}"

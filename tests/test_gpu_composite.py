@@ -1,0 +1,93 @@
+"""-m gpu: the HIP compositing kernel (dsr_composite_instances[_dev]) vs the oracle's
+restatement of CompositeInstances / CompositeColor / CompositeDepth — bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _case(P, L, seed):
+    rng = np.random.default_rng(seed)
+    t_c = rng.integers(0, 256, (P, 4)).astype(np.uint8)
+    t_d = rng.uniform(1, 20, P).astype(np.float32); t_d[rng.random(P) < 0.3] = 0
+    l_c = rng.integers(0, 256, (L, P, 4)).astype(np.uint8)
+    l_d = rng.uniform(1, 20, (L, P)).astype(np.float32); l_d[rng.random((L, P)) < 0.5] = 0
+    # exact ties between layers and with the target exercise the strict '>' rule
+    l_d[:, ::7] = t_d[::7]
+    if L > 1:
+        l_d[1, ::5] = l_d[0, ::5]
+    ids = rng.integers(0, 50, L).astype(np.int32)
+    return t_c, t_d, l_c, l_d, ids
+
+
+@pytest.mark.parametrize("P,L,tint,dim", [(1242 * 375, 4, 1.0, 1), (1000, 7, 0.35, 0), (333, 1, 1.0, 1), (64, 0, 1.0, 1)])
+def test_composite_colour_and_depth(hip_api, oracle_lib, P, L, tint, dim):
+    t_c, t_d, l_c, l_d, ids = _case(P, L, 3)
+    g_c, g_d, o_c, o_d = t_c.copy(), t_d.copy(), t_c.copy(), t_d.copy()
+    assert hip_api.composite_instances(vp(g_c), vp(g_d), vp(l_c), vp(l_d), vp(ids), L, P, tint, dim) == 0
+    assert oracle_lib.composite_instances(vp(o_c), vp(o_d), vp(l_c), vp(l_d), vp(ids), L, P, tint, dim) == 0
+    assert np.array_equal(g_d, o_d) and np.array_equal(g_c, o_c)
+    if L:
+        assert not np.array_equal(g_d, t_d)
+
+
+def test_composite_depth_only(hip_api, oracle_lib):
+    P, L = 5000, 3
+    t_c, t_d, l_c, l_d, ids = _case(P, L, 9)
+    g_d, o_d = t_d.copy(), t_d.copy()
+    assert hip_api.composite_instances(None, vp(g_d), None, vp(l_d), vp(ids), L, P, 1.0, 0) == 0
+    assert oracle_lib.composite_instances(None, vp(o_d), None, vp(l_d), vp(ids), L, P, 1.0, 0) == 0
+    assert np.array_equal(g_d, o_d)
+    # CompositeDepth (InstanceReconstructor.cpp:851-871) gives the same depth: min over non-zero
+    e = t_d.copy()
+    for l in range(L):
+        s = l_d[l]
+        e = np.where(e == 0, s, np.where(s != 0, np.minimum(e, s), e))
+    assert np.array_equal(g_d, e)
+
+
+def test_preview_exchange_single_gpu(hip_api, oracle_lib):
+    """PreviewExchange end to end on one GPU: two instance volumes rendered with
+    dsr_get_image_dev straight into the exchange buffers, composited on the GPU."""
+    import torch
+    from dynslam_amd import _capi
+    from dynslam_amd.multigpu import PreviewExchange
+    from tests.common import feed, make_pair
+    dev = torch.device("cuda", 0)
+    sc, g, o = make_pair(W=256, H=80)
+    sc2, g2, o2 = make_pair(W=256, H=80, voxel_size=0.035, mu=1.0, sdf_local_block_num=7142, view_frustum_max=12.0)
+    for i in range(3):
+        feed((g, o), sc, i)
+        feed((g2, o2), sc2, i, ignore_oob=True)
+    P = 256 * 80
+    ex = PreviewExchange(P, 3, 1, 0, dev)
+    pose = np.linalg.inv(sc.pose(2).astype(np.float64)).astype(np.float32)
+    bg_c = torch.zeros((P, 4), dtype=torch.uint8, device=dev)
+    bg_d = torch.zeros((P,), dtype=torch.float32, device=dev)
+    g.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose, None, bg_c.data_ptr(), 0)
+    g.get_image_dev(_capi.IMAGE_FREECAMERA_DEPTH, pose, None, 0, bg_d.data_ptr())
+    for slot, eng in enumerate((g2, g)):
+        rp, dp = ex.slot_ptrs(slot)
+        eng.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose, None, rp, 0)
+        eng.get_image_dev(_capi.IMAGE_FREECAMERA_DEPTH, pose, None, 0, dp)
+    for eng in (g, g2):
+        eng.sync()
+    ex.gather()
+    ex.composite(bg_c, bg_d, {0: 7, 1: 3})
+    torch.cuda.synchronize()
+    # oracle: same renders, serial composite in ascending track id (instance 1 -> id 3 first)
+    oc, _ = o.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=pose)
+    _, od = o.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=pose, want_rgba=False, want_depth=True)
+    layers_c, layers_d = [], []
+    for eng in (o, o2):  # instance 1 (= volume g / o, track id 3) first, then instance 0 (g2 / o2, id 7)
+        c, _ = eng.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=pose)
+        _, d = eng.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=pose, want_rgba=False, want_depth=True)
+        layers_c.append(c.reshape(P, 4)); layers_d.append(d.reshape(P))
+    t_c, t_d = oc.reshape(P, 4).copy(), od.reshape(P).copy()
+    lc, ld = np.ascontiguousarray(np.stack(layers_c)), np.ascontiguousarray(np.stack(layers_d))
+    ids = np.array([3, 7], np.int32)
+    assert oracle_lib.composite_instances(vp(t_c), vp(t_d), vp(lc), vp(ld), vp(ids), 2, P, 1.0, 1) == 0
+    assert np.array_equal(bg_d.cpu().numpy(), t_d) and np.array_equal(bg_c.cpu().numpy(), t_c)
