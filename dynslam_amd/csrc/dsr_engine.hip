@@ -793,6 +793,63 @@ int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uin
   return DSR_OK;
 }
 
+// ---- self-test
+
+__global__ __launch_bounds__(256) void k_selftest_division(unsigned long long n, unsigned long long seed,
+                                                           unsigned long long *mismatches) {
+  const float y32767 = rcp_refined(32767.0f), y255 = rcp_refined(255.0f);
+  unsigned long long bad = 0;
+  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  // exhaustive small domains
+  if (tid < 65536) {
+    const float a = (float)(short)(int)(tid - 32768);
+    if (__float_as_uint(div_with_rcp(a, 32767.0f, y32767)) != __float_as_uint(a / 32767.0f)) bad++;
+  }
+  if (tid < 256) {
+    const float a = (float)(int)tid;
+    if (__float_as_uint(div_with_rcp(a, 255.0f, y255)) != __float_as_uint(a / 255.0f)) bad++;
+  }
+  for (unsigned long long i = tid; i < n; i += stride) {
+    // splitmix64
+    unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    // a: sign, exponent in [-40, 40]; b: sign, exponent in [-14, 40] (>= 1e-4 as on the hot path),
+    // random mantissas; every 16th pair uses small integers (weights) as divisor
+    const unsigned ma = (unsigned)(z & 0x7fffffu), mb = (unsigned)((z >> 23) & 0x7fffffu);
+    const int ea = (int)((z >> 46) % 81) - 40, eb = (int)((z >> 53) % 55) - 14;
+    float a = __uint_as_float(((unsigned)(ea + 127) << 23) | ma);
+    float b = __uint_as_float(((unsigned)(eb + 127) << 23) | mb);
+    if (z >> 63) a = -a;
+    if ((z >> 62) & 1) b = -b;
+    if ((i & 15) == 0) b = (float)(1 + (int)((z >> 23) & 0x1ff));
+    if ((i & 255) == 1) a = 0.0f;
+    const float q = a / b;
+    if (!(fabsf(q) == 0.0f || (fabsf(q) >= 1.17549435e-38f && fabsf(q) < 3.0e38f))) continue;  // not tame
+    if (__float_as_uint(fdiv_tame(a, b)) != __float_as_uint(q)) bad++;
+    const float yb = rcp_refined(b);
+    if (__float_as_uint(div_with_rcp(a, b, yb)) != __float_as_uint(q)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *mismatches) {
+  if (!mismatches) return fail(DSR_E_ARG, "null");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  unsigned long long *d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8));
+  HIP_TRY(hipMemset(d, 0, 8));
+  hipLaunchKernelGGL(k_selftest_division, dim3(4096), dim3(256), 0, 0, (unsigned long long)n, (unsigned long long)seed, d);
+  unsigned long long h = 0;
+  hipError_t err = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, "selftest failed to run");
+  *mismatches = h;
+  return DSR_OK;
+}
+
 // ---- statistics / dumps
 
 int dsr_get_stats(dsr_engine *e, dsr_stats *out) {

@@ -4,7 +4,8 @@
 // (InstanceReconstructor.cpp:851-990): software z-buffer over the per-instance raycast
 // renders, in the host's iteration order.  One thread per pixel walks the layers
 // sequentially, so the strict "t > s" rule is applied exactly as the serial code does.
-// Colour arithmetic is in double like the reference (uchar * double literals).
+// Colour arithmetic follows the reference's C++ promotions: uchar * double for the colour
+// term, int * float (then widened) for the tint term.
 #pragma once
 #include "dsr_device.h"
 
@@ -42,9 +43,9 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
     if (tRgba) {
       const uchar4 sc = lRgba[(size_t)l * c.nPixels + i];
       const uchar4 tint = c.tint[l];
-      const double r = fmin(255.0, (double)sc.x * colStrength + (double)tint.x * (double)c.tintStrength);
-      const double g = fmin(255.0, (double)sc.y * colStrength + (double)tint.y * (double)c.tintStrength);
-      const double b = fmin(255.0, (double)sc.z * colStrength + (double)tint.z * (double)c.tintStrength);
+      const double r = fmin(255.0, (double)sc.x * colStrength + (double)((float)tint.x * c.tintStrength));
+      const double g = fmin(255.0, (double)sc.y * colStrength + (double)((float)tint.y * c.tintStrength));
+      const double b = fmin(255.0, (double)sc.z * colStrength + (double)((float)tint.z * c.tintStrength));
       col.x = (unsigned char)r; col.y = (unsigned char)g; col.z = (unsigned char)b;
     }
   }

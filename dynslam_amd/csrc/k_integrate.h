@@ -1,13 +1,21 @@
 // k_integrate.h — K4: SDF / colour integration of every visible voxel block.
 //
 // Replaces integrateIntoScene_device (upstream: one 512-thread CUDA block per voxel block,
-// 8 B array-of-structs voxels).  CDNA4 formulation: ONE WAVE64 PER VOXEL BLOCK, lane = (y,z)
-// row of the 8^3 block, 8 voxels along x per lane.  With the plane-wise block layout
-// (dsr_device.h) every lane moves 16 B of sdf, 8 B of w_depth, 8 B of w_color and 32 B of
-// colour with fully coalesced dwordx4/dwordx2 accesses (1 KiB per wave instruction on the
-// sdf plane).  A fixed persistent grid strides over the visible list whose length is read
-// from device memory, so the host never synchronises to learn noVisibleBlocks.
-// Planes a lane did not change are not written back.
+// 8 B array-of-structs voxels).  CDNA4 formulation:
+//   * ONE WAVE64 PER VOXEL BLOCK, lane = (y,z) row of the 8^3 block, 8 voxels along x per
+//     lane.  With the plane-wise block layout (dsr_device.h) a lane moves 16 B of sdf and 8 B
+//     of w_depth with fully coalesced dwordx4/dwordx2 accesses (1 KiB per wave instruction).
+//   * PHASE A (depth): all 512 voxels, SDF running mean.  Voxels that also pass the colour gate
+//     (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended to a per-wave LDS
+//     list (wave64 ballot + prefix popcount) together with their image position.
+//   * PHASE B (colour): the wave walks that list DENSELY, 64 voxels per pass: gathers the 4 B
+//     colour + 1 B weight of each listed voxel, bilinear RGB sample, running mean, scatter back.
+//     The divergent colour branch of the per-voxel formulation (every lane paying for the few
+//     that need it) is gone and the colour planes of untouched voxels are never read.
+//   * A fixed persistent grid strides over the visible list whose length is read from device
+//     memory: the host never synchronises to learn noVisibleBlocks.
+//   * Divisions use the shared-reciprocal form of the IEEE sequence (dsr_device.h
+//     "correctly rounded division for tame operands"): same rounding, ~half the instructions.
 //
 // Arithmetic follows ITMSceneReconstructionEngine.h computeUpdatedVoxelDepthInfo /
 // computeUpdatedVoxelColorInfo / ComputeUpdatedVoxelInfo<true> expression by expression.
@@ -32,126 +40,167 @@ __device__ __forceinline__ float3 bilinear_rgb(const uchar4 *__restrict__ src, f
   return r;
 }
 
-// fork: WeightParams.depthWeighting; adopted definition max(1, round(10/z)) (see oracle)
+// fork: WeightParams.depthWeighting; adopted definition max(1, round(10/z))
 __device__ __forceinline__ int depth_weight(float depth_measure) {
   int w = f2i(10.0f / depth_measure + 0.5f);
   return w < 1 ? 1 : w;
 }
 
+constexpr int kIntegrateWaves = 4;  // waves (= voxel blocks in flight) per workgroup
+
 template <bool RGB_SAME>
-__global__ __launch_bounds__(256) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                   const uchar4 *__restrict__ rgb,
-                                                   const int32_t *__restrict__ visibleIDs) {
+__global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                                    const uchar4 *__restrict__ rgb,
+                                                                    const int32_t *__restrict__ visibleIDs) {
+  // per-wave colour work list: image position + voxel index of every voxel passing the gate
+  __shared__ float2 s_uv[kIntegrateWaves][kBlockSize3];
+  __shared__ unsigned short s_idx[kIntegrateWaves][kBlockSize3];
+
   const int noVisible = s.ctr[CTR_NO_VISIBLE_LIVE];
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_INTEGRATED], (unsigned long long)noVisible);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wavesInGrid = gridDim.x * 4;
+  const int wavesInGrid = gridDim.x * kIntegrateWaves;
   const int ly = lane & 7, lz = lane >> 3;
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
+  float2 *uvList = s_uv[wave];
+  unsigned short *idxList = s_idx[wave];
 
-  for (int b = blockIdx.x * 4 + wave; b < noVisible; b += wavesInGrid) {
+  // reciprocals of the constant divisors (uniform)
+  const float yMu = rcp_refined(p.mu), y32767 = rcp_refined(32767.0f), y255 = rcp_refined(255.0f);
+  // gate of ComputeUpdatedVoxelInfo<true> for voxels the depth step rejected with eta = -1
+  const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
+  const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
+  const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
+
+  for (int b = blockIdx.x * kIntegrateWaves + wave; b < noVisible; b += wavesInGrid) {
     const int entryId = __builtin_amdgcn_readfirstlane(visibleIDs[b]);
     const dsr_hash_entry he = load_entry(s.table, entryId);
     if (he.ptr < 0) continue;
     uint8_t *blk = s.vba + (size_t)he.ptr * kBlockBytes;
 
-    uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
-    uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
-    uint2 wcRaw = *reinterpret_cast<const uint2 *>(blk + kOffWColor + lane * 8);
-    uint4 c0 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32);
-    uint4 c1 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32 + 16);
-
+    const uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
+    const uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
     uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
     uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
-    uint32_t wcW[2] = {wcRaw.x, wcRaw.y};
-    uint32_t clrW[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    bool dirtyDepth = false, dirtyColor = false;
+    bool dirtyDepth = false;
+    int nColor = 0;  // wave-uniform length of the colour list
 
     const int gx = he.pos[0] * kBlockSize, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
     const float my = (float)(gy + ly) * p.voxelSize;
     const float mz = (float)(gz + lz) * p.voxelSize;
 
+    // ------------------------------------------------------------- phase A: depth
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       short sdf = (short)((sdfW[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
-      int wDepth = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
-      if (p.stopAtMaxW && wDepth == p.maxW) continue;
+      const int wDepth = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
       const float mx = (float)(gx + x) * p.voxelSize;
-
-      // ---- computeUpdatedVoxelDepthInfo
-      float eta;
-      float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
-      float u = 0.0f, v = 0.0f;
-      bool projected = false;
-      if (pc.z <= 0) eta = -1.0f;
-      else {
-        u = p.proj.x * pc.x / pc.z + p.proj.z;
-        v = p.proj.y * pc.y / pc.z + p.proj.w;
-        projected = true;
-        if ((u < 1) || (u > (float)(p.W - 2)) || (v < 1) || (v > (float)(p.H - 2))) eta = -1.0f;
-        else {
-          float depth_measure = depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W];
-          if (depth_measure <= 0.0f) eta = -1.0f;
-          else {
-            eta = depth_measure - pc.z;
-            if (!(eta < -p.mu)) {
-              float oldF = sdf_to_float((float)sdf);
-              int oldW = wDepth;
-              const float q = eta / p.mu;
-              float newF = (1.0f < q) ? 1.0f : q;  // MIN(1.0f, eta / mu)
-              int newW = p.depthWeighting ? depth_weight(depth_measure) : 1;
-              newF = (float)oldW * oldF + (float)newW * newF;
-              newW = oldW + newW;
-              newF /= (float)newW;
-              newW = newW < p.maxW ? newW : p.maxW;
-              sdf = sdf_from_float(newF);
-              sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | ((uint32_t)(uint16_t)sdf << ((x & 1) * 16));
-              wdW[x >> 2] = (wdW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
-              dirtyDepth = true;
+      bool wantColor = false;
+      float uc = 0.0f, vc = 0.0f;
+      if (!(p.stopAtMaxW && wDepth == p.maxW)) {
+        // ---- computeUpdatedVoxelDepthInfo
+        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+        float u = 0.0f, v = 0.0f;
+        bool projected = false, rejected = true;
+        float q = 0.0f, eta = -1.0f;
+        if (pc.z > 0) {
+          if (pc.z >= 1e-4f) {  // tame divisor: shared refined reciprocal
+            const float yz = rcp_refined(pc.z);
+            u = div_with_rcp(p.proj.x * pc.x, pc.z, yz) + p.proj.z;
+            v = div_with_rcp(p.proj.y * pc.y, pc.z, yz) + p.proj.w;
+          } else {
+            u = p.proj.x * pc.x / pc.z + p.proj.z;
+            v = p.proj.y * pc.y / pc.z + p.proj.w;
+          }
+          projected = true;
+          if (!((u < 1) || (u > wLim) || (v < 1) || (v > hLim))) {
+            const float depth_measure = depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W];
+            if (!(depth_measure <= 0.0f)) {
+              eta = depth_measure - pc.z;
+              rejected = false;
+              q = div_with_rcp(eta, p.mu, yMu);  // eta / mu
+              if (!(eta < -p.mu)) {
+                const float oldF = div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
+                const int oldW = wDepth;
+                float newF = (1.0f < q) ? 1.0f : q;  // MIN(1.0f, eta / mu)
+                int newW = p.depthWeighting ? depth_weight(depth_measure) : 1;
+                newF = (float)oldW * oldF + (float)newW * newF;
+                newW = oldW + newW;
+                newF = fdiv_tame(newF, (float)newW);
+                newW = newW < p.maxW ? newW : p.maxW;
+                sdf = sdf_from_float(newF);
+                sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | ((uint32_t)(uint16_t)sdf << ((x & 1) * 16));
+                wdW[x >> 2] = (wdW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
+                dirtyDepth = true;
+              }
             }
           }
         }
+        // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25)
+        const bool gate = rejected ? rejectedPassGate : !((eta > p.mu) || (fabsf(q) > 0.25f));
+        if (gate) {
+          // ---- computeUpdatedVoxelColorInfo, projection + bounds
+          if (RGB_SAME && projected) { uc = u; vc = v; }
+          else {
+            const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
+            uc = projr.x * pr.x / pr.z + projr.z;
+            vc = projr.y * pr.y / pr.z + projr.w;
+          }
+          wantColor = !((uc < 1) || (uc > (float)(Wc - 2)) || (vc < 1) || (vc > (float)(Hc - 2)));
+        }
       }
-      // ---- ComputeUpdatedVoxelInfo<true>::compute gate
-      if ((eta > p.mu) || (fabsf(eta / p.mu) > 0.25f)) continue;
-
-      // ---- computeUpdatedVoxelColorInfo
-      float uc, vc;
-      if (RGB_SAME && projected) { uc = u; vc = v; }
-      else {
-        float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
-        uc = projr.x * pr.x / pr.z + projr.z;
-        vc = projr.y * pr.y / pr.z + projr.w;
+      // append to the wave's colour list (ordered compaction across the 64 lanes)
+      const unsigned long long m = __ballot(wantColor);
+      if (m) {
+        if (wantColor) {
+          const int pos = nColor + __popcll(m & laneMaskLt);
+          uvList[pos] = make_float2(uc, vc);
+          idxList[pos] = (unsigned short)(lane * 8 + x);
+        }
+        nColor += __popcll(m);
       }
-      if ((uc < 1) || (uc > (float)(Wc - 2)) || (vc < 1) || (vc > (float)(Hc - 2))) continue;
-      const uint32_t cw = clrW[x];
-      const float oldWc = (float)((wcW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
-      float ocx = (float)(cw & 0xffu) / 255.0f, ocy = (float)((cw >> 8) & 0xffu) / 255.0f, ocz = (float)((cw >> 16) & 0xffu) / 255.0f;
-      float3 m = bilinear_rgb(rgb, uc, vc, Wc);
-      float rx = m.x / 255.0f, ry = m.y / 255.0f, rz = m.z / 255.0f;
-      float newWc = 1.0f;
-      float ncx = ocx * oldWc + rx * newWc, ncy = ocy * oldWc + ry * newWc, ncz = ocz * oldWc + rz * newWc;
-      newWc = oldWc + newWc;
-      ncx /= newWc; ncy /= newWc; ncz /= newWc;
-      newWc = (newWc < (float)p.maxW) ? newWc : (float)p.maxW;  // MIN(newW, maxW)
-      uint32_t r8 = (uint32_t)f2i(ncx * 255.0f) & 0xffu, g8 = (uint32_t)f2i(ncy * 255.0f) & 0xffu, b8 = (uint32_t)f2i(ncz * 255.0f) & 0xffu;
-      clrW[x] = r8 | (g8 << 8) | (b8 << 16);
-      wcW[x >> 2] = (wcW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | (((uint32_t)f2i(newWc) & 0xffu) << ((x & 3) * 8));
-      dirtyColor = true;
     }
 
     if (dirtyDepth) {
       *reinterpret_cast<uint4 *>(blk + kOffSdf + lane * 16) = make_uint4(sdfW[0], sdfW[1], sdfW[2], sdfW[3]);
       *reinterpret_cast<uint2 *>(blk + kOffWDepth + lane * 8) = make_uint2(wdW[0], wdW[1]);
     }
-    if (dirtyColor) {
-      *reinterpret_cast<uint2 *>(blk + kOffWColor + lane * 8) = make_uint2(wcW[0], wcW[1]);
-      *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32) = make_uint4(clrW[0], clrW[1], clrW[2], clrW[3]);
-      *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32 + 16) = make_uint4(clrW[4], clrW[5], clrW[6], clrW[7]);
+
+    // ------------------------------------------------------------ phase B: colour
+    // the list was written and is read by this wave only; LDS operations of one wave execute
+    // in order, the fences keep the compiler from reordering across the phase boundary.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = lane; i < nColor; i += 64) {
+      const float2 uv = uvList[i];
+      const int vox = idxList[i];
+      uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
+      uint8_t *wcPtr = blk + kOffWColor + vox;
+      const uint32_t cw = *clrPtr;
+      const float oldWc = (float)*wcPtr;
+      const float ocx = div_with_rcp((float)(cw & 0xffu), 255.0f, y255);
+      const float ocy = div_with_rcp((float)((cw >> 8) & 0xffu), 255.0f, y255);
+      const float ocz = div_with_rcp((float)((cw >> 16) & 0xffu), 255.0f, y255);
+      const float3 mm = bilinear_rgb(rgb, uv.x, uv.y, Wc);
+      const float rx = div_with_rcp(mm.x, 255.0f, y255), ry = div_with_rcp(mm.y, 255.0f, y255),
+                  rz = div_with_rcp(mm.z, 255.0f, y255);
+      float newWc = 1.0f;
+      float ncx = ocx * oldWc + rx * newWc, ncy = ocy * oldWc + ry * newWc, ncz = ocz * oldWc + rz * newWc;
+      newWc = oldWc + newWc;
+      const float yW = rcp_refined(newWc);
+      ncx = div_with_rcp(ncx, newWc, yW); ncy = div_with_rcp(ncy, newWc, yW); ncz = div_with_rcp(ncz, newWc, yW);
+      newWc = (newWc < (float)p.maxW) ? newWc : (float)p.maxW;  // MIN(newW, maxW)
+      const uint32_t r8 = (uint32_t)f2i(ncx * 255.0f) & 0xffu, g8 = (uint32_t)f2i(ncy * 255.0f) & 0xffu,
+                     b8 = (uint32_t)f2i(ncz * 255.0f) & 0xffu;
+      *clrPtr = r8 | (g8 << 8) | (b8 << 16);
+      *wcPtr = (uint8_t)f2i(newWc);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

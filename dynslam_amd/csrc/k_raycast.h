@@ -136,8 +136,12 @@ __global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, cons
     for (int y = ul.y; y <= lr.y; ++y)
       for (int x = ul.x; x <= lr.x; ++x) {
         int2 *px = minmax + x + y * mw;
-        atomicMin(&px->x, zmin);
-        atomicMax(&px->y, zmax);
+        // min only decreases / max only increases, so a (possibly stale) plain read can only
+        // over-estimate the need for an atomic: skipping on it is safe and removes almost all
+        // of the same-address atomic traffic (a cell settles after O(log n) updates).
+        const int2 cur = *px;
+        if (zmin < cur.x) atomicMin(&px->x, zmin);
+        if (zmax > cur.y) atomicMax(&px->y, zmax);
       }
   }
 }

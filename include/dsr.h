@@ -283,6 +283,15 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result,
                           float *points, float *normals, uint8_t *raycast_image);
 
+/* ---- self-test ------------------------------------------------------------------- */
+
+/* Compares the engine's shared-reciprocal division (dsr_device.h: the IEEE fp32 divide
+ * sequence without its scale/fix-up instructions, used on the integrate path) with the
+ * device's IEEE `/` on n pseudo-random "tame" operand pairs, plus the exhaustive small
+ * domains short/32767 and uchar/255.  *mismatches receives the number of differing bit
+ * patterns (must be 0).  Synchronises. */
+int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *mismatches);
+
 /* ---- per-kernel timing (roofline harness) -------------------------------------- */
 
 typedef struct dsr_kernel_time {

@@ -167,3 +167,11 @@ def test_no_view_errors(hip_api):
         with pytest.raises(DsrError) as ei:
             e.process_frame()
         assert ei.value.status == _capi.DSR_E_NO_VIEW
+
+
+def test_division_selftest(hip_api):
+    """The shared-reciprocal division of the integrate path == the device's IEEE divide."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    assert hip_api.selftest_division(0, 200_000_000, 12345, C.byref(bad)) == 0
+    assert bad.value == 0
