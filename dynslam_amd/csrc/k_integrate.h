@@ -48,11 +48,15 @@ __device__ __forceinline__ int depth_weight(float depth_measure) {
 
 constexpr int kIntegrateWaves = 4;  // waves (= voxel blocks in flight) per workgroup
 
+// LDS slot of voxel v (= lane*8 + x) in the per-wave image-position table: x-major so that the
+// 64 lanes of one ds_write_b64 hit consecutive 8-byte slots (conflict-free).
+__device__ __forceinline__ int uv_slot(int vox) { return ((vox & 7) << 6) | (vox >> 3); }
+
 template <bool RGB_SAME>
 __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                     const uchar4 *__restrict__ rgb,
                                                                     const int32_t *__restrict__ visibleIDs) {
-  // per-wave colour work list: image position + voxel index of every voxel passing the gate
+  // per wave: image position of every voxel of the block + the list of voxels needing colour
   __shared__ float2 s_uv[kIntegrateWaves][kBlockSize3];
   __shared__ unsigned short s_idx[kIntegrateWaves][kBlockSize3];
 
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
-  float2 *uvList = s_uv[wave];
+  float2 *uvTab = s_uv[wave];
   unsigned short *idxList = s_idx[wave];
 
   // reciprocals of the constant divisors (uniform)
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
   // gate of ComputeUpdatedVoxelInfo<true> for voxels the depth step rejected with eta = -1
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
+  const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
   const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
 
   for (int b = blockIdx.x * kIntegrateWaves + wave; b < noVisible; b += wavesInGrid) {
@@ -85,83 +90,98 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
     const uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
     uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
     uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
-    bool dirtyDepth = false;
-    int nColor = 0;  // wave-uniform length of the colour list
 
     const int gx = he.pos[0] * kBlockSize, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
     const float my = (float)(gy + ly) * p.voxelSize;
     const float mz = (float)(gz + lz) * p.voxelSize;
 
-    // ------------------------------------------------------------- phase A: depth
+    // ---------------------------------------------- phase A1: project, issue the 8 depth gathers
+    // Branch-free: every lane computes every voxel, rejected voxels read pixel 0 and are masked
+    // later.  (The scalar unit is shared by the CU's 4 SIMDs; per-voxel branching made it a
+    // bottleneck.)
+    float pz[8], dm[8];
+    uint32_t inbMask = 0, posMask = 0;  // bit x: voxel projects inside the image / has z > 0
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
-      short sdf = (short)((sdfW[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
-      const int wDepth = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
       const float mx = (float)(gx + x) * p.voxelSize;
-      bool wantColor = false;
-      float uc = 0.0f, vc = 0.0f;
-      if (!(p.stopAtMaxW && wDepth == p.maxW)) {
-        // ---- computeUpdatedVoxelDepthInfo
-        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
-        float u = 0.0f, v = 0.0f;
-        bool projected = false, rejected = true;
-        float q = 0.0f, eta = -1.0f;
-        if (pc.z > 0) {
-          if (pc.z >= 1e-4f) {  // tame divisor: shared refined reciprocal
-            const float yz = rcp_refined(pc.z);
-            u = div_with_rcp(p.proj.x * pc.x, pc.z, yz) + p.proj.z;
-            v = div_with_rcp(p.proj.y * pc.y, pc.z, yz) + p.proj.w;
-          } else {
-            u = p.proj.x * pc.x / pc.z + p.proj.z;
-            v = p.proj.y * pc.y / pc.z + p.proj.w;
-          }
-          projected = true;
-          if (!((u < 1) || (u > wLim) || (v < 1) || (v > hLim))) {
-            const float depth_measure = depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W];
-            if (!(depth_measure <= 0.0f)) {
-              eta = depth_measure - pc.z;
-              rejected = false;
-              q = div_with_rcp(eta, p.mu, yMu);  // eta / mu
-              if (!(eta < -p.mu)) {
-                const float oldF = div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
-                const int oldW = wDepth;
-                float newF = (1.0f < q) ? 1.0f : q;  // MIN(1.0f, eta / mu)
-                int newW = p.depthWeighting ? depth_weight(depth_measure) : 1;
-                newF = (float)oldW * oldF + (float)newW * newF;
-                newW = oldW + newW;
-                newF = fdiv_tame(newF, (float)newW);
-                newW = newW < p.maxW ? newW : p.maxW;
-                sdf = sdf_from_float(newF);
-                sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | ((uint32_t)(uint16_t)sdf << ((x & 1) * 16));
-                wdW[x >> 2] = (wdW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
-                dirtyDepth = true;
-              }
-            }
-          }
+      const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+      const bool pos = pc.z > 0;
+      const bool tame = pc.z >= 1e-4f;
+      const float zs = tame ? pc.z : 1.0f;
+      const float yz = rcp_refined(zs);
+      float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
+      float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
+      if (__builtin_expect(__any(pos && !tame), 0)) {  // camera-plane grazing voxels: plain IEEE divide
+        if (pos && !tame) {
+          u = p.proj.x * pc.x / pc.z + p.proj.z;
+          v = p.proj.y * pc.y / pc.z + p.proj.w;
         }
-        // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25)
-        const bool gate = rejected ? rejectedPassGate : !((eta > p.mu) || (fabsf(q) > 0.25f));
-        if (gate) {
-          // ---- computeUpdatedVoxelColorInfo, projection + bounds
-          if (RGB_SAME && projected) { uc = u; vc = v; }
-          else {
-            const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
-            uc = projr.x * pr.x / pr.z + projr.z;
-            vc = projr.y * pr.y / pr.z + projr.w;
-          }
-          wantColor = !((uc < 1) || (uc > (float)(Wc - 2)) || (vc < 1) || (vc > (float)(Hc - 2)));
+      }
+      const bool inb = pos && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+      const int pix = inb ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0;
+      dm[x] = depth[pix];
+      pz[x] = pc.z;
+      uvTab[(x << 6) | lane] = make_float2(u, v);
+      inbMask |= inb ? (1u << x) : 0u;
+      posMask |= pos ? (1u << x) : 0u;
+    }
+
+    // ---------------------------------------------- phase A2: SDF running mean, colour gate
+    bool dirtyDepth = false;
+    int nColor = 0;  // wave-uniform length of the colour list
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      const short sdf = (short)((sdfW[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
+      const int wDepth = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
+      const bool skip = p.stopAtMaxW && wDepth == p.maxW;
+      const float depth_measure = dm[x];
+      // ---- computeUpdatedVoxelDepthInfo
+      const bool ok = !skip && ((inbMask >> x) & 1u) && !(depth_measure <= 0.0f);
+      const float eta = depth_measure - pz[x];
+      const float q = div_with_rcp(eta, p.mu, yMu);  // eta / mu
+      const bool upd = ok && !(eta < -p.mu);
+      const float oldF = div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
+      float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
+      int newW = p.depthWeighting ? depth_weight(ok ? depth_measure : 1.0f) : 1;
+      newF = (float)wDepth * oldF + (float)newW * newF;
+      newW = wDepth + newW;
+      newF = fdiv_tame(newF, (float)newW);
+      newW = newW < p.maxW ? newW : p.maxW;
+      const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
+      const uint32_t sw = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
+      const uint32_t ww = (wdW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
+      sdfW[x >> 1] = upd ? sw : sdfW[x >> 1];
+      wdW[x >> 2] = upd ? ww : wdW[x >> 2];
+      dirtyDepth |= upd;
+      // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
+      //      voxels the depth step rejected carry eta = -1
+      const bool gate = !skip && (ok ? !((eta > p.mu) || (fabsf(q) > 0.25f)) : rejectedPassGate);
+      // ---- computeUpdatedVoxelColorInfo: projection + bounds.  With identical rgb/depth
+      //      cameras the projection is the one of phase A1 (already in the LDS table).
+      const bool reuse = RGB_SAME && ((posMask >> x) & 1u);
+      bool wantColor;
+      if (__builtin_expect(__any(gate && !reuse), 0)) {
+        float uc = 0.0f, vc = 0.0f;
+        if (gate && !reuse) {
+          const float mx = (float)(gx + x) * p.voxelSize;
+          const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
+          uc = projr.x * pr.x / pr.z + projr.z;
+          vc = projr.y * pr.y / pr.z + projr.w;
+          uvTab[(x << 6) | lane] = make_float2(uc, vc);
+        } else {
+          const float2 t = uvTab[(x << 6) | lane];
+          uc = t.x; vc = t.y;
         }
+        wantColor = gate && !((uc < 1) || (uc > wcLim) || (vc < 1) || (vc > hcLim));
+      } else {
+        // gate implies ok implies in depth bounds; the rgb bounds are the same numbers here
+        const float2 t = uvTab[(x << 6) | lane];
+        wantColor = gate && !((t.x < 1) || (t.x > wcLim) || (t.y < 1) || (t.y > hcLim));
       }
       // append to the wave's colour list (ordered compaction across the 64 lanes)
       const unsigned long long m = __ballot(wantColor);
-      if (m) {
-        if (wantColor) {
-          const int pos = nColor + __popcll(m & laneMaskLt);
-          uvList[pos] = make_float2(uc, vc);
-          idxList[pos] = (unsigned short)(lane * 8 + x);
-        }
-        nColor += __popcll(m);
-      }
+      if (wantColor) idxList[nColor + __popcll(m & laneMaskLt)] = (unsigned short)(lane * 8 + x);
+      nColor += __popcll(m);
     }
 
     if (dirtyDepth) {
@@ -170,14 +190,14 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
     }
 
     // ------------------------------------------------------------ phase B: colour
-    // the list was written and is read by this wave only; LDS operations of one wave execute
-    // in order, the fences keep the compiler from reordering across the phase boundary.
+    // the tables were written and are read by this wave only; LDS operations of one wave
+    // execute in order, the fences keep the compiler from reordering across the boundary.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (int i = lane; i < nColor; i += 64) {
-      const float2 uv = uvList[i];
       const int vox = idxList[i];
+      const float2 uv = uvTab[uv_slot(vox)];
       uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
       uint8_t *wcPtr = blk + kOffWColor + vox;
       const uint32_t cw = *clrPtr;
