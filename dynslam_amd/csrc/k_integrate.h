@@ -5,17 +5,22 @@
 //   * ONE WAVE64 PER VOXEL BLOCK, lane = (y,z) row of the 8^3 block, 8 voxels along x per
 //     lane.  With the plane-wise block layout (dsr_device.h) a lane moves 16 B of sdf and 8 B
 //     of w_depth with fully coalesced dwordx4/dwordx2 accesses (1 KiB per wave instruction).
-//   * PHASE A (depth): all 512 voxels, SDF running mean.  Voxels that also pass the colour gate
-//     (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended to a per-wave LDS
-//     list (wave64 ballot + prefix popcount) together with their image position.
+//   * PHASE A1 (project): branch-free; all 8 depth-image gathers of a lane are issued before
+//     any is consumed; image positions go to a per-wave LDS table.
+//   * PHASE A2 (depth): branch-free SDF running mean on all 512 voxels.  Voxels that also pass
+//     the colour gate (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended
+//     to a per-wave LDS list (wave64 ballot + prefix popcount).
 //   * PHASE B (colour): the wave walks that list DENSELY, 64 voxels per pass: gathers the 4 B
 //     colour + 1 B weight of each listed voxel, bilinear RGB sample, running mean, scatter back.
 //     The divergent colour branch of the per-voxel formulation (every lane paying for the few
 //     that need it) is gone and the colour planes of untouched voxels are never read.
 //   * A fixed persistent grid strides over the visible list whose length is read from device
-//     memory: the host never synchronises to learn noVisibleBlocks.
+//     memory (the host never synchronises to learn noVisibleBlocks); hash entries are fetched
+//     two blocks ahead and voxel planes one block ahead of the arithmetic.
 //   * Divisions use the shared-reciprocal form of the IEEE sequence (dsr_device.h
 //     "correctly rounded division for tame operands"): same rounding, ~half the instructions.
+//   * The scalar unit is shared by the 4 SIMDs of a CU: per-voxel branching (exec-mask
+//     bookkeeping) made it a bottleneck, hence selects instead of nested ifs.
 //
 // Arithmetic follows ITMSceneReconstructionEngine.h computeUpdatedVoxelDepthInfo /
 // computeUpdatedVoxelColorInfo / ComputeUpdatedVoxelInfo<true> expression by expression.
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_INTEGRATED], (unsigned long long)noVisible);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wavesInGrid = gridDim.x * kIntegrateWaves;
+  const int stride = gridDim.x * kIntegrateWaves;
   const int ly = lane & 7, lz = lane >> 3;
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
@@ -75,32 +80,52 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
   // reciprocals of the constant divisors (uniform)
   const float yMu = rcp_refined(p.mu), y32767 = rcp_refined(32767.0f), y255 = rcp_refined(255.0f);
   // gate of ComputeUpdatedVoxelInfo<true> for voxels the depth step rejected with eta = -1
+  // (true only for mu >= 4 m)
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
+  // common case: the colour projection is the depth projection and only depth-accepted voxels
+  // can pass the gate => the colour bounds test is implied by the depth one
+  const bool colourFollowsDepth = RGB_SAME && !rejectedPassGate;
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
   const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
 
-  for (int b = blockIdx.x * kIntegrateWaves + wave; b < noVisible; b += wavesInGrid) {
-    const int entryId = __builtin_amdgcn_readfirstlane(visibleIDs[b]);
-    const dsr_hash_entry he = load_entry(s.table, entryId);
-    if (he.ptr < 0) continue;
-    uint8_t *blk = s.vba + (size_t)he.ptr * kBlockBytes;
+  // software pipeline over this wave's blocks: entries two ahead, voxel planes one ahead
+  const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
+  int b = blockIdx.x * kIntegrateWaves + wave;
+  dsr_hash_entry heCur = (b < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b])) : kNone;
+  dsr_hash_entry heNext =
+      (b + stride < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b + stride])) : kNone;
+  uint4 sdfRaw = make_uint4(0, 0, 0, 0);
+  uint2 wdRaw = make_uint2(0, 0);
+  if (heCur.ptr >= 0) {
+    const uint8_t *blk0 = s.vba + (size_t)heCur.ptr * kBlockBytes;
+    sdfRaw = *reinterpret_cast<const uint4 *>(blk0 + kOffSdf + lane * 16);
+    wdRaw = *reinterpret_cast<const uint2 *>(blk0 + kOffWDepth + lane * 8);
+  }
 
-    const uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
-    const uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
+  for (; b < noVisible; b += stride) {
+    const dsr_hash_entry he = heCur;
+    const dsr_hash_entry heAfter =
+        (b + 2 * stride < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b + 2 * stride])) : kNone;
     uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
     uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
+    if (heNext.ptr >= 0) {  // prefetch the next block's depth planes
+      const uint8_t *blkN = s.vba + (size_t)heNext.ptr * kBlockBytes;
+      sdfRaw = *reinterpret_cast<const uint4 *>(blkN + kOffSdf + lane * 16);
+      wdRaw = *reinterpret_cast<const uint2 *>(blkN + kOffWDepth + lane * 8);
+    }
+    heCur = heNext;
+    heNext = heAfter;
+    if (he.ptr < 0) continue;
+    uint8_t *blk = s.vba + (size_t)he.ptr * kBlockBytes;
 
     const int gx = he.pos[0] * kBlockSize, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
     const float my = (float)(gy + ly) * p.voxelSize;
     const float mz = (float)(gz + lz) * p.voxelSize;
 
     // ---------------------------------------------- phase A1: project, issue the 8 depth gathers
-    // Branch-free: every lane computes every voxel, rejected voxels read pixel 0 and are masked
-    // later.  (The scalar unit is shared by the CU's 4 SIMDs; per-voxel branching made it a
-    // bottleneck.)
     float pz[8], dm[8];
-    uint32_t inbMask = 0, posMask = 0;  // bit x: voxel projects inside the image / has z > 0
+    uint32_t inbMask = 0, posMask = 0, grazeMask = 0;  // per-lane bit x: inside image / z > 0 / 0 < z < 1e-4
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
       const float mx = (float)(gx + x) * p.voxelSize;
@@ -109,21 +134,33 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
       const bool tame = pc.z >= 1e-4f;
       const float zs = tame ? pc.z : 1.0f;
       const float yz = rcp_refined(zs);
-      float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
-      float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
-      if (__builtin_expect(__any(pos && !tame), 0)) {  // camera-plane grazing voxels: plain IEEE divide
-        if (pos && !tame) {
-          u = p.proj.x * pc.x / pc.z + p.proj.z;
-          v = p.proj.y * pc.y / pc.z + p.proj.w;
-        }
-      }
-      const bool inb = pos && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+      const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
+      const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
+      const bool inb = pos && tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
       const int pix = inb ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0;
       dm[x] = depth[pix];
       pz[x] = pc.z;
       uvTab[(x << 6) | lane] = make_float2(u, v);
       inbMask |= inb ? (1u << x) : 0u;
       posMask |= pos ? (1u << x) : 0u;
+      grazeMask |= (pos && !tame) ? (1u << x) : 0u;
+    }
+    if (__builtin_expect(__any(grazeMask != 0), 0)) {
+      // voxels grazing the camera plane (0 < z < 1e-4): the divisor is not tame, redo them
+      // with the plain IEEE divide
+      for (int x = 0; x < 8; ++x) {
+        if (!((grazeMask >> x) & 1u)) continue;
+        const float mx = (float)(gx + x) * p.voxelSize;
+        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+        const float u = p.proj.x * pc.x / pc.z + p.proj.z;
+        const float v = p.proj.y * pc.y / pc.z + p.proj.w;
+        const bool inb = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+        const float d = depth[inb ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0];
+        uvTab[(x << 6) | lane] = make_float2(u, v);
+        inbMask |= inb ? (1u << x) : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (k == x) dm[k] = d;
+      }
     }
 
     // ---------------------------------------------- phase A2: SDF running mean, colour gate
@@ -156,26 +193,18 @@ __global__ __launch_bounds__(64 * kIntegrateWaves) void k_integrate(FrameP p, Sc
       // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
       //      voxels the depth step rejected carry eta = -1
       const bool gate = !skip && (ok ? !((eta > p.mu) || (fabsf(q) > 0.25f)) : rejectedPassGate);
-      // ---- computeUpdatedVoxelColorInfo: projection + bounds.  With identical rgb/depth
-      //      cameras the projection is the one of phase A1 (already in the LDS table).
-      const bool reuse = RGB_SAME && ((posMask >> x) & 1u);
-      bool wantColor;
-      if (__builtin_expect(__any(gate && !reuse), 0)) {
-        float uc = 0.0f, vc = 0.0f;
+      // ---- computeUpdatedVoxelColorInfo: projection + bounds
+      bool wantColor = gate;
+      if (!colourFollowsDepth) {  // uniform branch
+        const bool reuse = RGB_SAME && ((posMask >> x) & 1u);
+        float2 t = uvTab[(x << 6) | lane];
         if (gate && !reuse) {
           const float mx = (float)(gx + x) * p.voxelSize;
           const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
-          uc = projr.x * pr.x / pr.z + projr.z;
-          vc = projr.y * pr.y / pr.z + projr.w;
-          uvTab[(x << 6) | lane] = make_float2(uc, vc);
-        } else {
-          const float2 t = uvTab[(x << 6) | lane];
-          uc = t.x; vc = t.y;
+          t.x = projr.x * pr.x / pr.z + projr.z;
+          t.y = projr.y * pr.y / pr.z + projr.w;
+          uvTab[(x << 6) | lane] = t;
         }
-        wantColor = gate && !((uc < 1) || (uc > wcLim) || (vc < 1) || (vc > hcLim));
-      } else {
-        // gate implies ok implies in depth bounds; the rgb bounds are the same numbers here
-        const float2 t = uvTab[(x << 6) | lane];
         wantColor = gate && !((t.x < 1) || (t.x > wcLim) || (t.y < 1) || (t.y > hcLim));
       }
       // append to the wave's colour list (ordered compaction across the 64 lanes)
