@@ -1,0 +1,397 @@
+// shim/ITMLib.h — header-only C++ shim: the ITMLib / ORUtils names DynSLAM's host uses,
+// implemented on top of the C ABI of include/dsr.h (libdsr_hip.so).
+//
+// Purpose: src/DynSLAM/InfiniTamDriver.{h,cpp}, InstRecLib/InstanceReconstructor.cpp and
+// DynSlam.{h,cpp} include "../InfiniTAM/InfiniTAM/ITMLib/Engine/ITMMainEngine.h"
+// (InfiniTamDriver.h:13) and then reach into ITMMainEngine's protected members
+// (InfiniTamDriver.h:115-156,190,203,242-248,283).  Pointing that include at this header
+// gives them the same class / member / method names; every engine operation forwards 1:1 to a
+// dsr_* call.  Only what those call sites touch is provided.
+//
+// Memory model: images hold HOST buffers; the device copies live inside the engine.
+//   UpdateDeviceFromHost() -> marks the view dirty; the next engine call uploads it
+//                             (dsr_set_view_float);
+//   UpdateHostFromDevice() -> dsr_get_view;
+// which is exactly the round trip InstanceReconstructor.cpp:180-197,262-263 performs.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <future>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../include/dsr.h"
+
+#ifndef SDF_BLOCK_SIZE
+#define SDF_BLOCK_SIZE DSR_BLOCK_SIZE
+#define SDF_BLOCK_SIZE3 DSR_BLOCK_SIZE3
+#endif
+
+typedef unsigned char uchar;
+
+enum MemoryDeviceType { MEMORYDEVICE_CPU, MEMORYDEVICE_CUDA };
+
+namespace ORUtils {
+
+template <class T> struct Vector2 {
+  union { struct { T x, y; }; struct { T width, height; }; T v[2]; };
+  Vector2() : x(0), y(0) {}
+  Vector2(T a, T b) : x(a), y(b) {}
+  T &operator[](int i) { return v[i]; }
+  const T &operator[](int i) const { return v[i]; }
+  bool operator==(const Vector2 &o) const { return x == o.x && y == o.y; }
+};
+template <class T> struct Vector3 {
+  union { struct { T x, y, z; }; struct { T r, g, b; }; T v[3]; };
+  Vector3() : x(0), y(0), z(0) {}
+  Vector3(T a, T b_, T c) : x(a), y(b_), z(c) {}
+};
+template <class T> struct Vector4 {
+  union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; T v[4]; };
+  Vector4() : x(0), y(0), z(0), w(0) {}
+  Vector4(T a_, T b_, T c, T d) : x(a_), y(b_), z(c), w(d) {}
+};
+
+// column-major 4x4, m[col*4 + row] (InfiniTamDriver.cpp:146-163)
+template <class T> struct Matrix4 {
+  T m[16];
+  Matrix4() { std::memset(m, 0, sizeof m); }
+  Matrix4(T a0, T a1, T a2, T a3, T a4, T a5, T a6, T a7, T a8, T a9, T a10, T a11, T a12, T a13, T a14, T a15) {
+    T t[16] = {a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15};
+    std::memcpy(m, t, sizeof m);
+  }
+  void setIdentity() { std::memset(m, 0, sizeof m); m[0] = m[5] = m[10] = m[15] = 1; }
+  T &at(int x, int y) { return m[x * 4 + y]; }
+  const T &at(int x, int y) const { return m[x * 4 + y]; }
+  T &operator()(int x, int y) { return at(x, y); }
+  const T &operator()(int x, int y) const { return at(x, y); }
+  friend Matrix4 operator*(const Matrix4 &l, const Matrix4 &r) {
+    Matrix4 o;
+    for (int x = 0; x < 4; x++)
+      for (int y = 0; y < 4; y++) {
+        T s = 0;
+        for (int k = 0; k < 4; k++) s += l.m[k * 4 + y] * r.m[x * 4 + k];
+        o.m[x * 4 + y] = s;
+      }
+    return o;
+  }
+  // general inverse via the engine's own convention is done inside dsr_set_pose_*; the host
+  // only needs inv() for rigid transforms (InfiniTamDriver.h:120-122): Gauss-Jordan.
+  bool inv(Matrix4 &out) const {
+    double a[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = at(c, r); a[r][4 + c] = (r == c); }
+    for (int i = 0; i < 4; i++) {
+      int p = i;
+      for (int r = i + 1; r < 4; r++) if (std::abs(a[r][i]) > std::abs(a[p][i])) p = r;
+      if (a[p][i] == 0) return false;
+      for (int c = 0; c < 8; c++) std::swap(a[i][c], a[p][c]);
+      double d = a[i][i];
+      for (int c = 0; c < 8; c++) a[i][c] /= d;
+      for (int r = 0; r < 4; r++) if (r != i) { double f = a[r][i]; for (int c = 0; c < 8; c++) a[r][c] -= f * a[i][c]; }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out.at(c, r) = (T)a[r][4 + c];
+    return true;
+  }
+};
+
+template <class T> class MemoryBlock {
+ public:
+  enum MemoryCopyDirection { CPU_TO_CPU, CPU_TO_CUDA, CUDA_TO_CPU, CUDA_TO_CUDA };
+  size_t dataSize = 0;
+  explicit MemoryBlock(size_t n = 0) : dataSize(n), data_(n) {}
+  T *GetData(MemoryDeviceType) { return data_.data(); }
+  const T *GetData(MemoryDeviceType) const { return data_.data(); }
+  void Clear(unsigned char v = 0) { if (!data_.empty()) std::memset(static_cast<void *>(data_.data()), v, data_.size() * sizeof(T)); }
+  void SetFrom(const MemoryBlock *src, MemoryCopyDirection) { data_ = src->data_; dataSize = src->dataSize; }
+ protected:
+  std::vector<T> data_;
+};
+
+template <class T> class Image : public MemoryBlock<T> {
+ public:
+  Vector2<int> noDims;
+  // hooks installed by ITMView so that the host<->device calls reach the engine
+  void (*toHost)(void *ctx) = nullptr;
+  void (*toDevice)(void *ctx) = nullptr;
+  void *ctx = nullptr;
+  Image(Vector2<int> dims, bool /*allocate_CPU*/, bool /*allocate_CUDA*/) : MemoryBlock<T>((size_t)dims.x * dims.y), noDims(dims) {}
+  Image(Vector2<int> dims, MemoryDeviceType) : Image(dims, true, false) {}
+  void ChangeDims(Vector2<int> d) { if (!(d == noDims)) { noDims = d; this->data_.assign((size_t)d.x * d.y, T()); this->dataSize = this->data_.size(); } }
+  void UpdateHostFromDevice() { if (toHost) toHost(ctx); }
+  void UpdateDeviceFromHost() { if (toDevice) toDevice(ctx); }
+};
+
+}  // namespace ORUtils
+
+typedef ORUtils::Vector2<int> Vector2i;
+typedef ORUtils::Vector2<float> Vector2f;
+typedef ORUtils::Vector3<float> Vector3f;
+typedef ORUtils::Vector4<float> Vector4f;
+typedef ORUtils::Vector4<uchar> Vector4u;
+typedef ORUtils::Matrix4<float> Matrix4f;
+typedef ORUtils::Image<Vector4u> ITMUChar4Image;
+typedef ORUtils::Image<float> ITMFloatImage;
+typedef ORUtils::Image<short> ITMShortImage;
+
+struct ITMVoxel { short sdf; uchar w_depth; uchar clr[3]; uchar w_color; uchar _pad; };  // ITMVoxel_s_rgb, 8 bytes
+struct ITMVoxelIndex {};
+static_assert(sizeof(ITMVoxel) == sizeof(dsr_voxel), "voxel size");
+
+#define ITMSafeCall(x) (x)
+
+namespace ITMLib {
+namespace Objects {
+
+struct ITMIntrinsics {
+  struct { Vector4f all; float &fx() { return all.x; } } projectionParamsSimple;
+  Vector2i size;
+  void SetFrom(float fx, float fy, float cx, float cy, float sizeX, float sizeY) {
+    projectionParamsSimple.all = Vector4f(fx, fy, cx, cy);
+    size = Vector2i((int)sizeX, (int)sizeY);
+  }
+};
+struct ITMExtrinsics {
+  Matrix4f calib, calib_inv;
+  ITMExtrinsics() { calib.setIdentity(); calib_inv.setIdentity(); }
+  void SetFrom(const Matrix4f &m) { calib = m; m.inv(calib_inv); }
+};
+struct ITMDisparityCalib {
+  enum TrafoType { TRAFO_KINECT, TRAFO_AFFINE };
+  Vector2f params; TrafoType type = TRAFO_AFFINE;
+  void SetFrom(float a, float b, TrafoType t) { params = Vector2f(a, b); type = t; }
+};
+struct ITMRGBDCalib {
+  ITMIntrinsics intrinsics_rgb, intrinsics_d;
+  ITMExtrinsics trafo_rgb_to_depth;
+  ITMDisparityCalib disparityCalib;
+};
+
+struct ITMSceneParams {
+  float mu = 0.02f; int maxW = 100; float voxelSize = 0.005f;
+  float viewFrustum_min = 0.2f, viewFrustum_max = 3.0f; bool stopIntegratingAtMaxW = false;
+};
+struct ITMLibSettings {
+  enum DeviceType { DEVICE_CPU, DEVICE_CUDA, DEVICE_METAL };
+  DeviceType deviceType = DEVICE_CUDA;
+  ITMSceneParams sceneParams;
+  bool useSwapping = false, useBilateralFilter = false, modelSensorNoise = false, createMeshingEngine = true;
+  long sdfLocalBlockNum = DSR_DEFAULT_LOCAL_BLOCK_NUM;  // fork (InstanceReconstructor.cpp:379)
+  int maxWDynamic = 10;                                 // fork (DynSLAMGUI.cpp:1217-1219)
+  // engine table sizes (upstream compile-time constants)
+  int hashBucketNum = DSR_DEFAULT_BUCKET_NUM, excessListSize = DSR_DEFAULT_EXCESS_LIST_SIZE;
+  std::string groundTruthPoseFpath; int groundTruthPoseOffset = 0;
+};
+
+class ITMPose {
+ public:
+  ITMPose() { M.setIdentity(); invMSet.setIdentity(); }
+  const Matrix4f &GetM() const { return M; }
+  Matrix4f GetInvM() const { if (fromInv) return invMSet; Matrix4f r; M.inv(r); return r; }
+  void SetM(const Matrix4f &m) { M = m; fromInv = false; }
+  // pose_d->SetInvM(...) is how the host sets poses (InfiniTamDriver.h:131-134): the matrix is
+  // handed to the engine unchanged, which derives M with ORUtils' own inverse
+  void SetInvM(const Matrix4f &im) { invMSet = im; fromInv = true; im.inv(M); }
+  void SetFrom(const ITMPose *p) { *this = *p; }
+  void Coerce() {}  // re-orthonormalisation: the engine takes M as given
+  int apply(dsr_engine *e) const { return fromInv ? dsr_set_pose_inv_m(e, invMSet.m) : dsr_set_pose_m(e, M.m); }
+ private:
+  Matrix4f M, invMSet;
+  bool fromInv = false;
+};
+
+struct ITMTrackingState { ITMPose *pose_d = new ITMPose; ~ITMTrackingState() { delete pose_d; } };
+
+struct ITMRenderState { virtual ~ITMRenderState() {} };
+struct ITMRenderState_VH : ITMRenderState { int noVisibleBlocks = 0; };
+
+class ITMView {
+ public:
+  ITMRGBDCalib *calib;
+  ITMUChar4Image *rgb;
+  ITMFloatImage *depth;
+  dsr_engine *owner = nullptr;  // engine whose device view mirrors this host view (may be null)
+  bool deviceStale = true;      // host buffers are newer than the engine's copy
+  // takes ownership of calib (InstanceReconstructor.cpp:782-785)
+  ITMView(const ITMRGBDCalib *c, Vector2i imgSize_rgb, Vector2i imgSize_d, bool /*useGPU*/)
+      : calib(new ITMRGBDCalib(*c)), rgb(new ITMUChar4Image(imgSize_rgb, true, true)), depth(new ITMFloatImage(imgSize_d, true, true)) {
+    for (auto *hook : {(void *)rgb, (void *)depth}) (void)hook;
+    rgb->ctx = depth->ctx = this;
+    rgb->toHost = depth->toHost = [](void *v) { static_cast<ITMView *>(v)->pull(); };
+    rgb->toDevice = depth->toDevice = [](void *v) { static_cast<ITMView *>(v)->deviceStale = true; };
+  }
+  ~ITMView() { delete calib; delete rgb; delete depth; }
+  void pull() {
+    if (owner && !deviceStale)
+      dsr_get_view(owner, reinterpret_cast<uint8_t *>(rgb->GetData(MEMORYDEVICE_CPU)), depth->GetData(MEMORYDEVICE_CPU));
+  }
+};
+
+}  // namespace Objects
+
+namespace Engine {
+struct WeightParams { bool depthWeighting = false; };
+
+inline void dsr_throw(int st) {
+  if (st == DSR_OK) return;
+  // block exhaustion is a runtime_error in the fork (caught at InstanceReconstructor.cpp:662-671)
+  throw std::runtime_error(std::string("dsr: ") + dsr_last_error());
+}
+}  // namespace Engine
+}  // namespace ITMLib
+
+using namespace ITMLib::Objects;
+using ITMLib::Engine::WeightParams;
+
+// scene facade: only the counters the host reads (InfiniTamDriver.h:241-244)
+template <class TVoxel, class TIndex> struct ITMScene {
+  dsr_engine *e = nullptr;
+  const ITMSceneParams *sceneParams = nullptr;
+  struct Index { ITMScene *s; int getNumAllocatedVoxelBlocks() const { dsr_stats st; dsr_get_stats(s->e, &st); return st.num_allocated_voxel_blocks; } } index{this};
+  struct VBA { ITMScene *s; struct Proxy { ITMScene *s; operator int() const { dsr_stats st; dsr_get_stats(s->e, &st); return st.last_free_block_id; } } lastFreeBlockId; } localVBA{this, {this}};
+};
+
+class ITMMainEngine;
+
+// ITMDenseMapper facade (InfiniTamDriver.h:138-145,203,248,283)
+template <class TVoxel, class TIndex> class ITMDenseMapper {
+ public:
+  explicit ITMDenseMapper(dsr_engine *e) : e_(e) {}
+  void SetFusionWeightParams(const WeightParams &p) { ITMLib::Engine::dsr_throw(dsr_set_fusion_weight_params(e_, p.depthWeighting)); }
+  void ProcessFrame(ITMView *view, ITMTrackingState *ts, ITMScene<TVoxel, TIndex> *, ITMRenderState *rs) {
+    push_view(view);
+    ITMLib::Engine::dsr_throw(ts->pose_d->apply(e_));
+    int st = dsr_process_frame(e_);
+    dsr_stats s; dsr_get_stats(e_, &s);
+    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks = s.no_visible_blocks;
+    ITMLib::Engine::dsr_throw(st);
+  }
+  void Decay(ITMScene<TVoxel, TIndex> *, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
+    ITMLib::Engine::dsr_throw(dsr_decay(e_, maxWeight, minAge, forceAllVoxels));
+    dsr_stats s; dsr_get_stats(e_, &s);
+    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks = s.no_visible_blocks;
+  }
+  size_t GetDecayedBlockCount() const { dsr_stats s; dsr_get_stats(e_, &s); return (size_t)s.decayed_block_count; }
+  void ResetScene(ITMScene<TVoxel, TIndex> *) { ITMLib::Engine::dsr_throw(dsr_reset_scene(e_)); }
+  void push_view(ITMView *view) {
+    if (view->owner != e_ || view->deviceStale) {
+      ITMLib::Engine::dsr_throw(dsr_set_view_float(e_, reinterpret_cast<const uint8_t *>(view->rgb->GetData(MEMORYDEVICE_CPU)),
+                                                   view->depth->GetData(MEMORYDEVICE_CPU)));
+      view->owner = e_; view->deviceStale = false;
+    }
+  }
+ private:
+  dsr_engine *e_;
+};
+
+// ITMTrackingController facade: Prepare only (InfiniTamDriver.h:152); Track() (ICP) is not on the path
+class ITMTrackingController {
+ public:
+  explicit ITMTrackingController(dsr_engine *e) : e_(e) {}
+  void Prepare(ITMTrackingState *ts, const ITMView *, ITMRenderState *) {
+    ITMLib::Engine::dsr_throw(ts->pose_d->apply(e_));
+    ITMLib::Engine::dsr_throw(dsr_prepare(e_));
+  }
+  void Track(ITMTrackingState *, const ITMView *) { throw std::runtime_error("ICP tracking is outside the dsr hot path (DynSLAM uses libviso2 poses)"); }
+ private:
+  dsr_engine *e_;
+};
+
+// ITMViewBuilder facade (InfiniTamDriver.cpp:177,222-223)
+class ITMViewBuilder {
+ public:
+  ITMViewBuilder(dsr_engine *e, const ITMRGBDCalib *c) : e_(e), calib_(c) {}
+  const ITMRGBDCalib *GetCalib() const { return calib_; }
+  void UpdateView(ITMView **view, ITMUChar4Image *rgb, ITMShortImage *rawDepth, bool /*useBilateral*/, bool /*modelSensorNoise*/ = false) {
+    if (*view == nullptr) *view = new ITMView(calib_, rgb->noDims, rawDepth->noDims, true);
+    ITMLib::Engine::dsr_throw(dsr_update_view(e_, reinterpret_cast<const uint8_t *>(rgb->GetData(MEMORYDEVICE_CPU)), rawDepth->GetData(MEMORYDEVICE_CPU)));
+    (*view)->owner = e_; (*view)->deviceStale = false;
+    // keep the host colour copy current; the converted depth is fetched on UpdateHostFromDevice()
+    (*view)->rgb->SetFrom(rgb, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
+  }
+ private:
+  dsr_engine *e_;
+  const ITMRGBDCalib *calib_;
+};
+
+struct IITMVisualisationEngine {};
+
+class ITMMainEngine {
+ public:
+  enum GetImageType {
+    InfiniTAM_IMAGE_ORIGINAL_RGB = DSR_IMAGE_ORIGINAL_RGB, InfiniTAM_IMAGE_ORIGINAL_DEPTH = DSR_IMAGE_ORIGINAL_DEPTH,
+    InfiniTAM_IMAGE_SCENERAYCAST = DSR_IMAGE_SCENERAYCAST, InfiniTAM_IMAGE_FREECAMERA_SHADED = DSR_IMAGE_FREECAMERA_SHADED,
+    InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME = DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+    InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL = DSR_IMAGE_FREECAMERA_COLOUR_FROM_NORMAL,
+    InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT = DSR_IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT,
+    InfiniTAM_IMAGE_FREECAMERA_DEPTH = DSR_IMAGE_FREECAMERA_DEPTH
+  };
+
+  // ITMMainEngine(settings, calib, imgSize_rgb, imgSize_d) (InfiniTamDriver.h:84-91)
+  ITMMainEngine(const ITMLibSettings *settings_, const ITMRGBDCalib *calib, Vector2i imgSize_rgb, Vector2i imgSize_d)
+      : settings(settings_), imgSize_(imgSize_d) {
+    dsr_settings s; dsr_default_settings(&s);
+    s.voxel_size = settings->sceneParams.voxelSize; s.mu = settings->sceneParams.mu; s.max_w = settings->sceneParams.maxW;
+    s.view_frustum_min = settings->sceneParams.viewFrustum_min; s.view_frustum_max = settings->sceneParams.viewFrustum_max;
+    s.stop_integrating_at_max_w = settings->sceneParams.stopIntegratingAtMaxW;
+    s.sdf_local_block_num = (int32_t)settings->sdfLocalBlockNum;
+    s.hash_bucket_num = settings->hashBucketNum; s.excess_list_size = settings->excessListSize;
+    s.use_swapping = settings->useSwapping; s.use_bilateral_filter = settings->useBilateralFilter; s.sync_status = 1;
+    dsr_calib c; std::memset(&c, 0, sizeof c);
+    auto fill = [](dsr_intrinsics &o, const ITMIntrinsics &i, Vector2i sz) {
+      o.fx = i.projectionParamsSimple.all.x; o.fy = i.projectionParamsSimple.all.y; o.cx = i.projectionParamsSimple.all.z;
+      o.cy = i.projectionParamsSimple.all.w; o.width = sz.x; o.height = sz.y; };
+    fill(c.rgb, calib->intrinsics_rgb, imgSize_rgb); fill(c.depth, calib->intrinsics_d, imgSize_d);
+    std::memcpy(c.trafo_rgb_to_depth, calib->trafo_rgb_to_depth.calib.m, sizeof c.trafo_rgb_to_depth);
+    c.disparity_calib[0] = calib->disparityCalib.params.x; c.disparity_calib[1] = calib->disparityCalib.params.y;
+    ITMLib::Engine::dsr_throw(dsr_engine_create(&s, &c, &engine_));
+    scene = new ITMScene<ITMVoxel, ITMVoxelIndex>(); scene->e = engine_; scene->sceneParams = &settings->sceneParams;
+    denseMapper = new ITMDenseMapper<ITMVoxel, ITMVoxelIndex>(engine_);
+    trackingController = new ITMTrackingController(engine_);
+    viewBuilder = new ITMViewBuilder(engine_, calib);
+    trackingState = new ITMTrackingState();
+    renderState_live = new ITMRenderState_VH();
+    visualisationEngine = new IITMVisualisationEngine();
+    view = nullptr;
+  }
+  virtual ~ITMMainEngine() {
+    delete view;  // the host nulls it first when it does not own it (InstanceTracker.cpp:44-50)
+    delete scene; delete denseMapper; delete trackingController; delete viewBuilder; delete trackingState;
+    delete renderState_live; delete visualisationEngine;
+    dsr_engine_destroy(engine_);
+  }
+
+  ITMView *GetView() { return view; }
+  ITMScene<ITMVoxel, ITMVoxelIndex> *GetScene() { return scene; }
+  Vector2i GetImageSize() const { return imgSize_; }
+  dsr_engine *GetDsrEngine() { return engine_; }
+
+  // ITMMainEngine::GetImage(out, outFloat, type, pose, intrinsics) (InfiniTamDriver.cpp:178-183,202-207)
+  void GetImage(ITMUChar4Image *out, ITMFloatImage *outFloat, GetImageType type, ITMPose *pose = nullptr, ITMIntrinsics *intrinsics = nullptr) {
+    if (view == nullptr) return;
+    denseMapper->push_view(view);
+    float intr[4];
+    if (intrinsics) { intr[0] = intrinsics->projectionParamsSimple.all.x; intr[1] = intrinsics->projectionParamsSimple.all.y; intr[2] = intrinsics->projectionParamsSimple.all.z; intr[3] = intrinsics->projectionParamsSimple.all.w; }
+    if (out) out->Clear();
+    ITMLib::Engine::dsr_throw(dsr_get_image(engine_, (int)type, pose ? pose->GetM().m : nullptr, intrinsics ? intr : nullptr,
+                                            out ? reinterpret_cast<uint8_t *>(out->GetData(MEMORYDEVICE_CPU)) : nullptr,
+                                            outFloat ? outFloat->GetData(MEMORYDEVICE_CPU) : nullptr));
+  }
+  void SaveSceneToMesh(const char *) { throw std::runtime_error("meshing is not part of the dsr hot path yet (SURVEY.md 8f rank 4)"); }
+
+ protected:
+  const ITMLibSettings *settings;
+  ITMScene<ITMVoxel, ITMVoxelIndex> *scene;
+  ITMView *view;
+  ITMViewBuilder *viewBuilder;
+  ITMTrackingState *trackingState;
+  ITMTrackingController *trackingController;
+  ITMDenseMapper<ITMVoxel, ITMVoxelIndex> *denseMapper;
+  ITMRenderState *renderState_live;
+  IITMVisualisationEngine *visualisationEngine;
+  std::future<void> write_result;
+
+ private:
+  dsr_engine *engine_ = nullptr;
+  Vector2i imgSize_;
+};
