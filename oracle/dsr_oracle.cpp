@@ -660,6 +660,10 @@ static inline float readFromSDF_float_interpolated(const Engine &e, const V3f &p
   return sdf_to_float((1.0f - coeff.z) * res1 + coeff.z * res2);
 }
 
+/* oracle-only diagnostics of the ray march (orc_debug_raycast_stats) */
+static long long g_rc_stats[8];
+static bool g_rc_stats_on = false;
+
 /* ITMVisualisationEngine.h castRay */
 static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 &invM, const V4f &invProj,
                            float oneOverVoxelSize, float mu, const V2f &minmax) {
@@ -694,12 +698,15 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
   pt_result = pt_block_s;
   IndexCache cache;
 
+  long long nMiss = 0, nFar = 0, nTri = 0;
   while (totalLength < totalLengthMax) {
     sdfValue = readFromSDF_float_uninterpolated(e, pt_result, hash_found, cache);
     if (!hash_found) {
       stepLength = DSR_BLOCK_SIZE;
+      nMiss++;
     } else {
-      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = readFromSDF_float_interpolated(e, pt_result, hash_found, cache);
+      nFar++;
+      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) { nTri++; sdfValue = readFromSDF_float_interpolated(e, pt_result, hash_found, cache); }
       if (sdfValue <= 0.0f) break;
       stepLength = std::max(sdfValue * stepScale, 1.0f);
     }
@@ -716,6 +723,16 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
     pt_found = true;
   } else pt_found = false;
 
+  if (g_rc_stats_on) {
+#pragma omp critical
+    {
+      g_rc_stats[0]++; g_rc_stats[1] += nMiss; g_rc_stats[2] += nFar; g_rc_stats[3] += nTri;
+      if (nMiss + nFar > g_rc_stats[4]) g_rc_stats[4] = nMiss + nFar;
+      if (pt_found) g_rc_stats[5]++;
+      if (nMiss + nFar > 200) g_rc_stats[6]++;
+      if (nMiss + nFar > 50) g_rc_stats[7]++;
+    }
+  }
   pt_out.x = pt_result.x; pt_out.y = pt_result.y; pt_out.z = pt_result.z;
   pt_out.w = pt_found ? 1.0f : 0.0f;
   return pt_found;
@@ -1395,6 +1412,15 @@ int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (m
 int orc_profile_enable(dsr_engine *h, int) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_reset(dsr_engine *h) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_get(dsr_engine *, dsr_kernel_time *, int) { return 0; }
+
+/* oracle-only: ray-march statistics since the last call with reset != 0:
+ * rays, miss steps, found steps, trilinear samples, max steps of a ray, hits, rays > 200 steps, rays > 50 steps */
+int orc_debug_raycast_stats(int enable, int reset, long long out[8]) {
+  g_rc_stats_on = enable != 0;
+  if (out) memcpy(out, g_rc_stats, sizeof g_rc_stats);
+  if (reset) memset(g_rc_stats, 0, sizeof g_rc_stats);
+  return DSR_OK;
+}
 
 /* oracle-only: number of OpenMP threads for the data-parallel loops (integrate,
  * raycast, shading).  Results do not depend on it. */

@@ -1,0 +1,178 @@
+"""-m gpu: BASELINE.json's full size (1242x375, 5 mm voxels, 2^23-entry table) — the oracle
+only checks the first two frames here (seconds with OpenMP); beyond that the engine state is
+checked through size-independent properties of the data structure."""
+import numpy as np
+import pytest
+
+from dynslam_amd import _capi
+from dynslam_amd.engine import EngineCore, default_settings, make_calib
+from dynslam_amd.synth import StreetScene
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1242, 375
+KW = dict(voxel_size=0.005, mu=0.02, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+          sdf_local_block_num=1 << 21, hash_bucket_num=1 << 22, excess_list_size=1 << 20)
+
+
+def np_hash(pos, mask):
+    p = pos.astype(np.int64).astype(np.uint32)
+    return ((p[:, 0] * np.uint32(73856093)) ^ (p[:, 1] * np.uint32(19349669)) ^ (p[:, 2] * np.uint32(83492791))) & np.uint32(mask)
+
+
+def check_structure(e, n_blocks, n_buckets):
+    st = e.get_stats()
+    ht = e.dump_hash_table()
+    used = np.nonzero(ht["ptr"] >= 0)[0]
+    # free-list accounting (InfiniTamDriver.h:241-244)
+    assert n_blocks - 1 - st.last_free_block_id == len(used)
+    # block pointers unique, disjoint from the live free list
+    ptrs = ht["ptr"][used]
+    assert len(np.unique(ptrs)) == len(ptrs)
+    val, exl = e.dump_allocation_lists()
+    free = val[: st.last_free_block_id + 1]
+    assert len(np.unique(free)) == len(free) and not np.intersect1d(free, ptrs).size
+    # no block position stored twice
+    key = ht["pos"][used].astype(np.int64)
+    packed = (key[:, 0] + 32768) | ((key[:, 1] + 32768) << 16) | ((key[:, 2] + 32768) << 32)
+    assert len(np.unique(packed)) == len(packed)
+    # bucket entries sit in the bucket their position hashes to
+    in_bucket = used[used < n_buckets]
+    assert np.array_equal(np_hash(ht["pos"][in_bucket], n_buckets - 1), in_bucket.astype(np.uint32))
+    # every used excess entry is linked from exactly one entry whose position hashes to the same bucket
+    in_excess = used[used >= n_buckets]
+    link_src = np.nonzero(ht["offset"] >= 1)[0]
+    targets = n_buckets + ht["offset"][link_src] - 1
+    assert len(np.unique(targets)) == len(targets)
+    assert np.isin(in_excess, targets).all()
+    src_of = dict(zip(targets.tolist(), link_src.tolist()))
+    sample = in_excess[:: max(1, len(in_excess) // 2000)]
+    for t in sample.tolist():
+        h = int(np_hash(ht["pos"][t:t + 1], n_buckets - 1)[0])
+        cur, ok = t, False
+        for _ in range(64):
+            cur = src_of.get(cur, -1)
+            if cur == h:
+                ok = True
+                break
+            if cur < 0:
+                break
+        assert ok, f"excess entry {t} not chained from its bucket"
+    # excess free list: live part unique and not in use
+    xfree = exl[: st.last_free_excess_list_id + 1]
+    assert len(np.unique(xfree)) == len(xfree)
+    assert not np.isin(n_buckets + xfree, targets).any()
+    # visible list: ascending, entries marked visible
+    vis = e.dump_visible_list()
+    assert (np.diff(vis) > 0).all()
+    vt = e.dump_visible_types()
+    assert (vt[vis] > 0).all() and int((vt > 0).sum()) == len(vis)
+    return st, ht, used
+
+
+def test_full_size_oracle_two_frames_then_properties(hip_api):
+    from oracle.oracle import OracleEngine, oracle_settings
+    sc = StreetScene(W, H)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    g = EngineCore(default_settings(**KW), calib)
+    o = OracleEngine(oracle_settings(**KW), calib, threads=16)
+    for i in range(2):
+        rgba, d, T, _ = sc.frame(i)
+        for e in (g, o):
+            e.update_view(rgba, d)
+            e.set_pose_inv_m(T)
+            e.process_frame()
+            e.prepare()
+    assert np.array_equal(g.dump_hash_table(), o.dump_hash_table())
+    assert np.array_equal(g.dump_visible_list(), o.dump_visible_list())
+    n_used = (1 << 21) - 1 - o.get_stats().last_free_block_id
+    assert n_used > 300_000
+    ho = o.dump_hash_table()
+    used_ptrs = np.sort(ho["ptr"][ho["ptr"] >= 0])
+    lo, hi = int(used_ptrs[0]), int(used_ptrs[-1]) + 1
+    assert np.array_equal(g.dump_voxel_blocks(lo, hi - lo), o.dump_voxel_blocks(lo, hi - lo))
+    rg, ro = g.dump_render_state(), o.dump_render_state()
+    for k in ("minmax", "raycast_result", "points", "normals", "raycast_image"):
+        assert np.array_equal(rg[k], ro[k]), k
+    o.close()
+    # continue on the GPU only
+    for i in range(2, 8):
+        rgba, d, T, _ = sc.frame(i)
+        g.update_view(rgba, d)
+        g.set_pose_inv_m(T)
+        g.process_frame()
+        g.prepare()
+        g.decay(1, 3, False)
+    st, ht, used = check_structure(g, 1 << 21, 1 << 22)
+    assert st.sticky_status == 0 and st.decayed_block_count > 0
+    # raycast sanity at full size: near rays hit where the analytic scene is (the stereo noise
+    # model exceeds mu = 2 cm beyond a few metres, so only the near field is asserted)
+    rs = g.dump_render_state()
+    z_true = sc.render(7)[0]
+    rr = rs["raycast_result"]
+    hit = rr[..., 3] > 0
+    M = np.linalg.inv(sc.pose(7).astype(np.float64))
+    cam_z = ((rr[..., :3].astype(np.float64) * 0.005) @ M[:3, :3].T + M[:3, 3])[..., 2]
+    near = np.isfinite(z_true) & (z_true < 8.0)
+    assert (hit & near).sum() > 0.5 * near.sum()
+    assert np.median(np.abs(cam_z[hit & near] - z_true[hit & near])) < 0.05
+
+
+def test_full_size_split_calls_equal_process_frame(hip_api):
+    """checksum of checksums: ProcessFrame == AllocateSceneFromDepth + IntegrateIntoScene, and
+    re-fusing an identical frame allocates nothing on the third pass."""
+    sc = StreetScene(W, H)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    a = EngineCore(default_settings(**KW), calib)
+    b = EngineCore(default_settings(**KW), calib)
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        for e in (a, b):
+            e.update_view(rgba, d)
+            e.set_pose_inv_m(T)
+        a.process_frame()
+        b.allocate_scene_from_depth()
+        b.integrate_into_scene()
+    assert np.array_equal(a.dump_hash_table(), b.dump_hash_table())
+    sa = a.get_stats()
+    n = (1 << 21) - 1 - sa.last_free_block_id
+    va, vb = a.dump_voxel_blocks(0, 4096), b.dump_voxel_blocks(0, 4096)
+    assert np.array_equal(va, vb)
+    ha = a.dump_hash_table()
+    some = np.sort(ha["ptr"][ha["ptr"] >= 0])[:: max(1, n // 64)][:64]
+    for ptr in some.tolist():
+        assert np.array_equal(a.dump_voxel_blocks(ptr, 1), b.dump_voxel_blocks(ptr, 1))
+    # idempotence of allocation on an unchanged view
+    a.allocate_scene_from_depth()
+    mid = a.get_stats().last_free_block_id
+    a.allocate_scene_from_depth()
+    a.allocate_scene_from_depth()
+    assert a.get_stats().last_free_block_id <= mid
+    last = a.get_stats().last_free_block_id
+    a.allocate_scene_from_depth()
+    assert a.get_stats().last_free_block_id == last
+    check_structure(a, 1 << 21, 1 << 22)
+
+
+def test_full_size_free_view_and_reset(hip_api):
+    sc = StreetScene(W, H)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    g = EngineCore(default_settings(**KW), calib)
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        g.update_view(rgba, d); g.set_pose_inv_m(T); g.process_frame(); g.prepare()
+    pose = np.linalg.inv(sc.pose(2).astype(np.float64)).astype(np.float32)
+    # the live raycast and a free-view render from the same pose see the same geometry
+    _, dep = g.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=pose, want_rgba=False, want_depth=True)
+    live = g.dump_render_state()["raycast_result"][..., 3] > 0
+    assert ((dep > 0) == live).mean() > 0.995
+    col, _ = g.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=pose)
+    rgba, _, _, _ = sc.frame(2)
+    m = (col[..., 3] == 255)
+    assert m.mean() > 0.5
+    err = np.abs(col[m][:, :3].astype(int) - rgba[m][:, :3].astype(int))
+    assert np.median(err) <= 30  # the fused colour resembles the input image (checker texture + depth noise)
+    g.reset_scene()
+    st = g.get_stats()
+    assert st.last_free_block_id == (1 << 21) - 1 and st.no_visible_blocks == 0
+    assert (g.dump_hash_table()["ptr"] == -2).all()
