@@ -104,6 +104,10 @@ SIGNATURES = {
     "decay": (C.c_int, [_H, C.c_int, C.c_int, C.c_int]),
     "get_image": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
     "get_image_dev": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
+    "depth_from_disparity": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "depth_from_disparity_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "view_extract_silhouette": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "view_remove_silhouette": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),

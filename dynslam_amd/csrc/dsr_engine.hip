@@ -22,6 +22,7 @@
 #include "k_alloc.h"
 #include "k_composite.h"
 #include "k_decay.h"
+#include "k_edges.h"
 #include "k_integrate.h"
 #include "k_raycast.h"
 
@@ -143,6 +144,10 @@ struct dsr_engine {
   int32_t *fifoCounts = nullptr;     // device, one int per slot
   int fifoCap = 0, fifoHead = 0, fifoLen = 0;
   int32_t *decayCand = nullptr;      // forceAll candidate list
+  // silhouette masks (instance view split)
+  uint8_t *maskScratch = nullptr;
+  size_t maskCap = 0;
+  hipEvent_t xEvent = nullptr;       // orders the instance stream after a view split
   uint8_t *decayFlags = nullptr;
 
   // profiling
@@ -256,7 +261,8 @@ void free_all(dsr_engine *e) {
   F(e->tileSums); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
-  F(e->fifoCounts); F(e->decayCand); F(e->decayFlags);
+  F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
+  if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -735,6 +741,89 @@ int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const flo
                       void *depth_out_dev) {
   CHECK_E(e);
   return render_common(e, type, pose_m, intrinsics, rgba_out_dev, depth_out_dev, true);
+}
+
+// ---- edges of the path: depth ingest, instance view split
+
+int dsr_depth_from_disparity_dev(int device, void *hip_stream, const void *disparity_dev, void *depth_mm_out_dev, int n,
+                                 float baseline_m, float focal_px, float scale, float min_depth_m, float max_depth_m) {
+  if (!disparity_dev || !depth_mm_out_dev || n <= 0) return fail(DSR_E_ARG, "bad disparity arguments");
+  const int minMm = (int)(min_depth_m * 1000.0f), maxMm = (int)(max_depth_m * 1000.0f);
+  if (maxMm >= 32767) return fail(DSR_E_ARG, "maximum depth does not fit an int16 millimetre map (DepthProvider.h:110-116)");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_depth_from_disparity, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream,
+                     (const float *)disparity_dev, (short *)depth_mm_out_dev, n, baseline_m, focal_px, scale, minMm, maxMm);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int dsr_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int n, float baseline_m, float focal_px,
+                             float scale, float min_depth_m, float max_depth_m) {
+  if (!disparity || !depth_mm_out || n <= 0) return fail(DSR_E_ARG, "bad disparity arguments");
+  float *d = nullptr; short *o = nullptr;
+  int st = dmalloc(&d, (size_t)n);
+  if (st) return st;
+  if ((st = dmalloc(&o, (size_t)n))) { (void)hipFree(d); return st; }
+  hipError_t err = hipMemcpy(d, disparity, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    st = dsr_depth_from_disparity_dev(-1, nullptr, d, o, n, baseline_m, focal_px, scale, min_depth_m, max_depth_m);
+    if (st == DSR_OK) err = hipMemcpy(depth_mm_out, o, (size_t)n * 2, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d); (void)hipFree(o);
+  if (st) return st;
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, "disparity conversion copy failed");
+  return DSR_OK;
+}
+
+static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h) {
+  const size_t n = (size_t)box_w * box_h;
+  if (e->maskCap < n) {
+    if (e->maskScratch) (void)hipFree(e->maskScratch);
+    e->maskScratch = nullptr; e->maskCap = 0;
+    int st = dmalloc(&e->maskScratch, n);
+    if (st) return st;
+    e->maskCap = n;
+  }
+  HIP_TRY(hipMemcpyAsync(e->maskScratch, mask, n, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the caller may reuse its (pageable) mask buffer
+  return DSR_OK;
+}
+
+int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
+                                int box_w, int box_h) {
+  CHECK_E(main_engine);
+  if (!instance || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  if (!main_engine->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (instance->device != main_engine->device || instance->W != main_engine->W || instance->H != main_engine->H ||
+      instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
+    return fail(DSR_E_ARG, "main and instance engines must share GPU and image size");
+  int st = upload_mask(main_engine, mask, box_w, box_h);
+  if (st) return st;
+  dsr_engine *e = main_engine;
+  // runs on the MAIN engine's stream (ordered after the view's producer and before any later
+  // blanking); the instance stream then waits for it
+  LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
+         (const uchar4 *)e->rgb, (const float *)e->depth, instance->rgb, instance->depth, e->W, e->H,
+         (const uint8_t *)e->maskScratch, x0, y0, box_w, box_h);
+  HIP_TRY(hipGetLastError());
+  if (!e->xEvent) HIP_TRY(hipEventCreateWithFlags(&e->xEvent, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->xEvent, e->stream));
+  HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent, 0));
+  instance->hasView = true;
+  return DSR_OK;
+}
+
+int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
+  CHECK_E(e);
+  if (!mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
+  int st = upload_mask(e, mask, box_w, box_h);
+  if (st) return st;
+  LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
+         e->depth, e->W, e->H, (const uint8_t *)e->maskScratch, x0, y0, box_w, box_h);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
 }
 
 // ---- instance compositing

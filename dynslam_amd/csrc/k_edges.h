@@ -1,0 +1,57 @@
+// k_edges.h — the per-pixel steps right before the hot path, moved to the GPU:
+//   * disparity -> int16-mm depth      (DepthProvider::DepthFromDisparityMap, DepthProvider.h:94-137)
+//   * instance view split / blanking   (ProcessSilhouette_CPU / RemoveSilhouette_CPU,
+//                                       InstanceReconstructor.cpp:59-170)
+// so that a frame never leaves HBM between depth ingest and fusion.
+#pragma once
+#include "dsr_device.h"
+
+namespace dsr {
+
+__global__ __launch_bounds__(256) void k_depth_from_disparity(const float *__restrict__ disp, short *__restrict__ out,
+                                                              int n, float baseline, float focal, float scale,
+                                                              int minDepthMm, int maxDepthMm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = disp[i];
+  // kMetersToMillimeters * scale * DepthFromDisparity(disp): ((1000*scale) * ((b*f)/d)), float
+  int depth_mm = f2i(1000.0f * scale * ((baseline * focal) / d));
+  if ((double)fabsf(d) < 1e-5) depth_mm = 0;
+  if (depth_mm > maxDepthMm || depth_mm < minDepthMm) depth_mm = 0;
+  out[i] = (short)depth_mm;
+}
+
+// dest (instance view) := default everywhere, source pixel where the bbox-local mask is 1
+__global__ __launch_bounds__(256) void k_extract_silhouette(const uchar4 *__restrict__ srcRgb,
+                                                            const float *__restrict__ srcDepth,
+                                                            uchar4 *__restrict__ dstRgb, float *__restrict__ dstDepth,
+                                                            int W, int H, const uint8_t *__restrict__ mask, int x0,
+                                                            int y0, int bw, int bh) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= W || y >= H) return;
+  const int idx = x + y * W;
+  const int col = x - x0, row = y - y0;
+  const bool inBox = col >= 0 && col < bw && row >= 0 && row < bh;
+  if (inBox && mask[row * bw + col] == 1) {
+    dstRgb[idx] = srcRgb[idx];
+    dstDepth[idx] = srcDepth[idx];
+  } else {
+    dstRgb[idx] = make_uchar4(255, 255, 255, 255);
+    dstDepth[idx] = 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_remove_silhouette(uchar4 *__restrict__ rgb, float *__restrict__ depth, int W,
+                                                           int H, const uint8_t *__restrict__ mask, int x0, int y0,
+                                                           int bw, int bh) {
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15), row = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (col >= bw || row >= bh) return;
+  const int x = col + x0, y = row + y0;
+  if (x < 0 || x >= W || y < 0 || y >= H) return;
+  if (mask[row * bw + col] == 1) {
+    rgb[x + y * W] = make_uchar4(0, 0, 0, 0);
+    depth[x + y * W] = 0.0f;
+  }
+}
+
+}  // namespace dsr

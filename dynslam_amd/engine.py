@@ -160,6 +160,18 @@ class EngineCore:
         self._check(self.api.get_view(self._h, _ptr(rgba), _ptr(depth)))
         return rgba, depth
 
+    def extract_silhouette(self, instance, mask, x0, y0):
+        """ProcessSilhouette (InstanceReconstructor.cpp:59-133): `instance`'s view := this
+        engine's view under the bbox-local uint8 mask placed at (x0, y0)."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.api.view_extract_silhouette(self._h, instance._h, _ptr(mask), int(x0), int(y0),
+                                                     mask.shape[1], mask.shape[0]))
+
+    def remove_silhouette(self, mask, x0, y0):
+        """RemoveSilhouette (InstanceReconstructor.cpp:135-170)."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._check(self.api.view_remove_silhouette(self._h, _ptr(mask), int(x0), int(y0), mask.shape[1], mask.shape[0]))
+
     # -- pose ---------------------------------------------------------------
     def set_pose_inv_m(self, inv_m):
         a = _colmajor(inv_m)

@@ -234,6 +234,31 @@ int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float i
 int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4],
                       void *rgba_out_dev, void *depth_out_dev);
 
+/* ---- edges of the path: depth ingest and instance view split ("next" rows) -- */
+
+/* DepthProvider::DepthFromDisparityMap (src/DynSLAM/DepthProvider.h:94-137):
+ *   depth_mm = (int32)(1000.0f * scale * ((baseline_m * focal_px) / disparity));
+ *   |disparity| < 1e-5 -> 0;  depth_mm outside [ (int32)(min_depth_m*1000), (int32)(max_depth_m*1000) ] -> 0
+ * disparity: float[n] (DispNet .pfm / ELAS), out: int16 mm — the format dsr_update_view takes.
+ * The _dev variant works on HBM buffers of `device` and enqueues on hip_stream (NULL = default). */
+int dsr_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int n, float baseline_m, float focal_px,
+                             float scale, float min_depth_m, float max_depth_m);
+int dsr_depth_from_disparity_dev(int device, void *hip_stream, const void *disparity_dev, void *depth_mm_out_dev,
+                                 int n, float baseline_m, float focal_px, float scale, float min_depth_m,
+                                 float max_depth_m);
+
+/* ProcessSilhouette_CPU (InstanceReconstructor.cpp:59-133) on the GPU: the view of `instance`
+ * becomes the pixels of `main`'s current view that lie under the copy mask, everything else
+ * rgba (255,255,255,255) / depth 0.  mask: HOST uint8[box_h][box_w] (1 = copy), placed at
+ * (x0,y0) in the frame (Mask::GetBoundingBox; may stick out of the frame).  Both engines must
+ * live on the same GPU and have the same image size.  Replaces the D2H -> CPU loop -> H2D round
+ * trip of InstanceReconstructor.cpp:180-197,238-263. */
+int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
+                                int box_w, int box_h);
+/* RemoveSilhouette_CPU (InstanceReconstructor.cpp:135-170): pixels of the engine's view under
+ * the mask become rgba 0 / depth 0.0f. */
+int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h);
+
 /* ---- instance compositing (the fused preview) ------------------------------------ */
 
 /* InstanceReconstructor::CompositeInstances (InstanceReconstructor.cpp:933-990) and

@@ -1309,6 +1309,70 @@ int orc_get_image_dev(dsr_engine *h, int type, const float pose_m[16], const flo
   return orc_get_image(h, type, pose_m, intrinsics, (uint8_t *)rgba_out, (float *)depth_out);
 }
 
+/* DepthProvider::DepthFromDisparityMap (src/DynSLAM/DepthProvider.h:94-137), restated. */
+int orc_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int n, float baseline_m, float focal_px,
+                             float scale, float min_depth_m, float max_depth_m) {
+  if (!disparity || !depth_mm_out || n <= 0) return fail(DSR_E_ARG, "bad disparity arguments");
+  const float kMetersToMillimeters = 1000.0f;
+  int32_t min_depth_mm = static_cast<int32_t>(min_depth_m * kMetersToMillimeters);
+  int32_t max_depth_mm = static_cast<int32_t>(max_depth_m * kMetersToMillimeters);
+  if (max_depth_mm >= 32767) return fail(DSR_E_ARG, "maximum depth does not fit an int16 millimetre map");
+  for (int i = 0; i < n; i++) {
+    float disp = disparity[i];
+    /* static_cast<int32_t>(float) is undefined out of range in C++; the adopted definition is
+     * the saturating one (f2i), which yields the same final value: both extremes are clipped to 0 */
+    int32_t depth_mm = f2i(kMetersToMillimeters * scale * ((baseline_m * focal_px) / disp));
+    if (std::abs(disp) < 1e-5) depth_mm = 0;
+    if (depth_mm > max_depth_mm || depth_mm < min_depth_mm) depth_mm = 0;
+    depth_mm_out[i] = static_cast<int16_t>(depth_mm);
+  }
+  return DSR_OK;
+}
+int orc_depth_from_disparity_dev(int, void *, const void *d, void *o, int n, float b, float f, float s, float mn, float mx) {
+  return orc_depth_from_disparity((const float *)d, (int16_t *)o, n, b, f, s, mn, mx);
+}
+
+/* ProcessSilhouette_CPU (InstanceReconstructor.cpp:59-133), restated on the engines' views. */
+int orc_view_extract_silhouette(dsr_engine *m, dsr_engine *inst, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
+  if (!m || !inst || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  Engine &src = m->e, &dst = inst->e;
+  if (!src.hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (src.W != dst.W || src.H != dst.H || src.Wr != dst.Wr || src.Hr != dst.Hr || src.W != src.Wr) return fail(DSR_E_ARG, "size mismatch");
+  const int frame_width = src.W, frame_height = src.H;
+  memset(dst.rgb.data(), 255, (size_t)frame_width * frame_height * sizeof(V4u));
+  memset(dst.depth.data(), 0, (size_t)frame_width * frame_height * sizeof(float));
+  for (int row = 0; row < box_h; ++row)
+    for (int col = 0; col < box_w; ++col) {
+      int copy_row = row + y0, copy_col = col + x0;
+      if (copy_row < 0 || copy_row >= frame_height || copy_col < 0 || copy_col >= frame_width) continue;
+      int copy_idx = copy_row * frame_width + copy_col;
+      if (mask[row * box_w + col] == 1) {
+        dst.rgb[copy_idx] = src.rgb[copy_idx];
+        dst.depth[copy_idx] = src.depth[copy_idx];
+      } else {
+        dst.rgb[copy_idx].x = 255; dst.rgb[copy_idx].y = 255; dst.rgb[copy_idx].z = 255;
+      }
+    }
+  dst.hasView = true;
+  return DSR_OK;
+}
+/* RemoveSilhouette_CPU (InstanceReconstructor.cpp:135-170), restated. */
+int orc_view_remove_silhouette(dsr_engine *h, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
+  if (!h || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  if (!E.hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  for (int row = 0; row < box_h; ++row)
+    for (int col = 0; col < box_w; ++col) {
+      int frame_row = row + y0, frame_col = col + x0;
+      if (frame_row < 0 || frame_row >= E.H || frame_col < 0 || frame_col >= E.W) continue;
+      int frame_idx = frame_row * E.W + frame_col;
+      if (mask[row * box_w + col] == 1) {
+        E.rgb[frame_idx] = {0, 0, 0, 0};
+        E.depth[frame_idx] = 0.0f;
+      }
+    }
+  return DSR_OK;
+}
+
 /* InstanceReconstructor::CompositeInstances / CompositeColor / CompositeDepth
  * (InstanceReconstructor.cpp:851-990), restated on raw buffers. */
 int orc_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,

@@ -1,0 +1,168 @@
+"""The steps right before the path: disparity -> depth ingest
+(DepthProvider.h:94-137) and the instance view split (InstanceReconstructor.cpp:59-170).
+The reference's source for these IS in /root/reference, so the oracle restates real code;
+CPU tests pin it against numpy statements, -m gpu tests compare the HIP kernels bit-exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dynslam_amd.engine import make_calib
+from dynslam_amd.synth import KITTI_BASELINE_M, StreetScene
+
+vp = lambda a: a.ctypes.data_as(C.c_void_p)
+f32 = np.float32
+
+
+def disparity_case(n=200_000, seed=5):
+    rng = np.random.default_rng(seed)
+    d = rng.uniform(0.5, 200.0, n).astype(np.float32)
+    d[::97] = 0.0
+    d[1::97] = -3.0
+    d[2::97] = 1e-6
+    d[3::97] = np.float32(707.0912 * KITTI_BASELINE_M / 20.0)  # exactly at the far limit
+    d[4::97] = np.inf
+    d[5::97] = np.nan
+    return d
+
+
+def numpy_depth_from_disparity(d, b, f, scale, mn, mx):
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        x = (f32(1000.0) * f32(scale)) * ((f32(b) * f32(f)) / d)
+    x = x.astype(np.float32)
+    mm = np.where(np.isnan(x), 0, np.clip(np.trunc(x.astype(np.float64)), -2**31, 2**31 - 1)).astype(np.int64)
+    mm[np.abs(d.astype(np.float64)) < 1e-5] = 0
+    lo, hi = int(f32(mn) * f32(1000.0)), int(f32(mx) * f32(1000.0))
+    mm[(mm > hi) | (mm < lo)] = 0
+    return mm.astype(np.int16)
+
+
+def test_oracle_depth_from_disparity(oracle_lib):
+    d = disparity_case()
+    out = np.empty(len(d), np.int16)
+    assert oracle_lib.depth_from_disparity(vp(d), vp(out), len(d), KITTI_BASELINE_M, 707.0912, 1.0, 0.5, 20.0) == 0
+    want = numpy_depth_from_disparity(d, KITTI_BASELINE_M, 707.0912, 1.0, 0.5, 20.0)
+    assert np.array_equal(out, want)
+    assert (out > 0).mean() > 0.5 and out.max() <= 20000 and out[out > 0].min() >= 500
+    # a maximum depth that does not fit int16 millimetres is rejected (DepthProvider.h:110-116)
+    assert oracle_lib.depth_from_disparity(vp(d), vp(out), len(d), 0.5, 700.0, 1.0, 0.5, 40.0) != 0
+
+
+def box_mask(H, W, y0, x0, h, w, seed):
+    rng = np.random.default_rng(seed)
+    m = (rng.random((h, w)) < 0.7).astype(np.uint8)
+    m[0, :] = 2  # values other than 1 are "not copied"
+    return m
+
+
+def numpy_extract(rgba, depth, mask, x0, y0):
+    H, W = depth.shape
+    out_c = np.full_like(rgba, 255)
+    out_d = np.zeros_like(depth)
+    h, w = mask.shape
+    for r in range(h):
+        for c in range(w):
+            y, x = r + y0, c + x0
+            if 0 <= y < H and 0 <= x < W and mask[r, c] == 1:
+                out_c[y, x] = rgba[y, x]
+                out_d[y, x] = depth[y, x]
+    return out_c, out_d
+
+
+def make_engines(factory, W, H):
+    sc = StreetScene(W, H)
+    kw = dict(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+              sdf_local_block_num=20000, hash_bucket_num=0x8000, excess_list_size=0x2000)
+    return sc, factory(kw, (*sc.intrinsics(), W, H)), factory(kw, (*sc.intrinsics(), W, H))
+
+
+def oracle_factory(kw, calib_args):
+    from oracle.oracle import OracleEngine, oracle_settings
+    return OracleEngine(oracle_settings(**kw), make_calib(*calib_args))
+
+
+def hip_factory(kw, calib_args):
+    from dynslam_amd.engine import EngineCore, default_settings
+    return EngineCore(default_settings(**kw), make_calib(*calib_args))
+
+
+@pytest.mark.parametrize("x0,y0,h,w", [(20, 10, 30, 50), (-7, -5, 25, 40), (130, 30, 40, 60)])
+def test_oracle_silhouette_ops(oracle_lib, x0, y0, h, w):
+    W, H = 160, 48
+    sc, main, inst = make_engines(oracle_factory, W, H)
+    rgba, d, T, _ = sc.frame(0)
+    main.update_view(rgba, d)
+    src_c, src_d = main.get_view()
+    mask = box_mask(H, W, y0, x0, h, w, 1)
+    main.extract_silhouette(inst, mask, x0, y0)
+    got_c, got_d = inst.get_view()
+    want_c, want_d = numpy_extract(src_c, src_d, mask, x0, y0)
+    assert np.array_equal(got_c, want_c) and np.array_equal(got_d, want_d)
+    main.remove_silhouette(mask, x0, y0)
+    rem_c, rem_d = main.get_view()
+    sel = np.zeros((H, W), bool)
+    for r in range(h):
+        for c in range(w):
+            if 0 <= r + y0 < H and 0 <= c + x0 < W and mask[r, c] == 1:
+                sel[r + y0, c + x0] = True
+    assert (rem_c[sel] == 0).all() and (rem_d[sel] == 0).all()
+    assert np.array_equal(rem_c[~sel], src_c[~sel]) and np.array_equal(rem_d[~sel], src_d[~sel])
+
+
+# ------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_gpu_depth_from_disparity(hip_api, oracle_lib):
+    import torch
+    d = disparity_case(1242 * 375)
+    g = np.empty(len(d), np.int16); o = np.empty(len(d), np.int16)
+    args = (len(d), KITTI_BASELINE_M, 707.0912, 1.0, 0.5, 20.0)
+    assert hip_api.depth_from_disparity(vp(d), vp(g), *args) == 0
+    assert oracle_lib.depth_from_disparity(vp(d), vp(o), *args) == 0
+    assert np.array_equal(g, o)
+    # HBM-resident variant
+    td = torch.from_numpy(d).cuda(); to = torch.empty(len(d), dtype=torch.int16, device="cuda")
+    st = hip_api.depth_from_disparity_dev(0, C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(td.data_ptr()),
+                                          C.c_void_p(to.data_ptr()), *args)
+    assert st == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(to.cpu().numpy(), o)
+
+
+@pytest.mark.gpu
+def test_gpu_instance_pipeline(hip_api, oracle_lib):
+    """Main view -> GPU split into an instance volume + blanked static map, both fused and
+    raycast: identical to the oracle running the reference's CPU loops."""
+    from dynslam_amd.engine import OutOfBlocksError
+    from tests.common import assert_render_equal, assert_scene_equal
+    W, H = 320, 96
+    sc = StreetScene(W, H, n_instances=2)
+    sc, gm, gi = make_engines(hip_factory, W, H)
+    sc, om, oi = make_engines(oracle_factory, W, H)
+    sc = StreetScene(W, H, n_instances=2)
+    for i in range(4):
+        rgba, d, T, inst_id = sc.frame(i)
+        ys, xs = np.nonzero(inst_id == 0)
+        for main, inst in ((gm, gi), (om, oi)):
+            main.update_view(rgba, d)
+            if len(ys):
+                y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+                mask = (inst_id[y0:y1, x0:x1] == 0).astype(np.uint8)
+                main.extract_silhouette(inst, mask, x0, y0)
+                main.remove_silhouette(mask, x0, y0)
+                # the instance volume lives in the object frame: pose = object^-1 * camera
+                rel = (np.linalg.inv(sc.instance_pose(0, i).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
+                inst.set_pose_inv_m(rel)
+                try:
+                    inst.process_frame()
+                except OutOfBlocksError:
+                    pass
+                inst.prepare()
+            main.set_pose_inv_m(T)
+            main.process_frame()
+            main.prepare()
+        assert np.array_equal(gm.get_view()[0], om.get_view()[0]) and np.array_equal(gm.get_view()[1], om.get_view()[1])
+        assert np.array_equal(gi.get_view()[1], oi.get_view()[1])
+    assert oi.get_stats().no_visible_blocks > 0
+    assert_scene_equal(gm, om); assert_render_equal(gm, om)
+    assert_scene_equal(gi, oi); assert_render_equal(gi, oi)
