@@ -117,6 +117,8 @@ SIGNATURES = {
     "dump_voxel_blocks": (C.c_int, [_H, C.c_int, C.c_int, _P]),
     "dump_allocation_lists": (C.c_int, [_H, _P, _P]),
     "dump_render_state": (C.c_int, [_H, C.c_int, _P, _P, _P, _P, _P]),
+    "dump_swap_state": (C.c_int, [_H, _P, _P]),
+    "dump_stored_block": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int)]),
     "selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "profile_enable": (C.c_int, [_H, C.c_int]),
     "profile_reset": (C.c_int, [_H]),

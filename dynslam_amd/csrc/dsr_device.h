@@ -46,6 +46,7 @@ enum Ctr {
   CTR_DECAY_FREED = 9,        // blocks freed by the running decay call
   CTR_DECAY_NCAND = 10,       // candidates of the running decay call
   CTR_TMP_OLD_NVIS = 11,      // live visible count before the post-decay compaction
+  CTR_SWAP_COUNT = 12,        // blocks in the running swap-in / swap-out transfer
   CTR_COUNT = 16
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)
@@ -83,6 +84,8 @@ struct SceneP {
   int32_t *ctr;           // Ctr
   unsigned long long *work;  // Work
   uint32_t *allocKey;     // per entry: 0 or (pixel*maxSteps + step + 1) of the winning writer
+  uint8_t *swapState;     // ITMHashSwapState::state per entry (null unless use_swapping)
+  uint8_t *swapStored;    // 1 = the host store (ITMGlobalCache) holds a copy of this entry's block
 };
 
 // ------------------------------------------------------------------ conversions

@@ -16,6 +16,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "dsr_device.h"
@@ -25,6 +26,7 @@
 #include "k_edges.h"
 #include "k_integrate.h"
 #include "k_raycast.h"
+#include "k_swap.h"
 
 using namespace dsr;
 
@@ -144,6 +146,11 @@ struct dsr_engine {
   int32_t *fifoCounts = nullptr;     // device, one int per slot
   int fifoCap = 0, fifoHead = 0, fifoLen = 0;
   int32_t *decayCand = nullptr;      // forceAll candidate list
+  // host swapping (use_swapping): ITMGlobalCache = host store of plane-wise 4 KiB blocks
+  uint8_t *swapStagingDev = nullptr, *swapStagingHost = nullptr;  // 16 MiB each (host one pinned)
+  int32_t *swapIdsDev = nullptr;
+  uint8_t *swapFlagsDev = nullptr;
+  std::unordered_map<int, std::vector<uint8_t>> hostStore;
   // silhouette masks (instance view split)
   uint8_t *maskScratch = nullptr;
   size_t maskCap = 0;
@@ -244,6 +251,11 @@ int reset_scene(dsr_engine *e) {
   LAUNCH(e, "reset", k_reset_vba, dim3(4096), dim3(256), reinterpret_cast<uint4 *>(e->scene.vba),
          (size_t)e->noBlocks * (kBlockBytes / 16));
   LAUNCH(e, "reset", k_reset_counters, dim3(1), dim3(64), e->scene.ctr, e->scene.work, e->noBlocks, e->noExcess);
+  if (e->scene.swapState) {
+    HIP_TRY(hipMemsetAsync(e->scene.swapState, 0, (size_t)e->E, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scene.swapStored, 0, (size_t)e->E, e->stream));
+    e->hostStore.clear();
+  }
   HIP_TRY(hipMemsetAsync(e->live.visType, 0, (size_t)e->E, e->stream));
   HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
   e->fifoHead = 0; e->fifoLen = 0;
@@ -262,6 +274,8 @@ void free_all(dsr_engine *e) {
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
+  F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
+  if (e->swapStagingHost) (void)hipHostFree(e->swapStagingHost);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
@@ -310,7 +324,7 @@ int allocate_scene(dsr_engine *e) {
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
          (int)SCAN_VISIBLE_LIVE, e->noBlocks);
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
-         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
+         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -373,6 +387,63 @@ int ensure_fifo(dsr_engine *e, int slotsNeeded) {
   return DSR_OK;
 }
 
+// ITMSwappingEngine::IntegrateGlobalIntoLocal: host store -> staging -> merge into local blocks
+int swap_in(dsr_engine *e) {
+  LAUNCH(e, "swap_list", (k_swap_count<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+         (const uint8_t *)e->live.visType, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_SWAP_IN,
+         (int)kTransferBlocks);
+  LAUNCH(e, "swap_list", (k_swap_write<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+         (const uint8_t *)e->live.visType, (const int2 *)e->tileSums, e->swapIdsDev, e->swapFlagsDev);
+  int32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (n <= 0) return DSR_OK;
+  std::vector<int32_t> ids((size_t)n);
+  std::vector<uint8_t> flags((size_t)n);
+  HIP_TRY(hipMemcpyAsync(ids.data(), e->swapIdsDev, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(flags.data(), e->swapFlagsDev, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  bool any = false;
+  for (int i = 0; i < n; ++i) {
+    if (!flags[i]) continue;
+    auto it = e->hostStore.find(ids[i]);
+    if (it == e->hostStore.end()) return fail(DSR_E_DEVICE, "swap-in: device says the host store holds a block it does not hold");
+    memcpy(e->swapStagingHost + (size_t)i * kBlockBytes, it->second.data(), kBlockBytes);
+    any = true;
+  }
+  if (any) HIP_TRY(hipMemcpyAsync(e->swapStagingDev, e->swapStagingHost, (size_t)n * kBlockBytes, hipMemcpyHostToDevice, e->stream));
+  LAUNCH(e, "swapin_combine", k_swapin_combine, dim3(std::min(1024, div_up(n, 4))), dim3(256), e->scene, (int)e->s.max_w,
+         (const int32_t *)e->swapIdsDev, (const uint8_t *)e->swapFlagsDev, (const uint8_t *)e->swapStagingDev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the pinned buffer is reused by swap_out
+  return DSR_OK;
+}
+
+// ITMSwappingEngine::SaveToGlobalMemory: invisible resident blocks -> staging -> host store
+int swap_out(dsr_engine *e) {
+  LAUNCH(e, "swap_list", (k_swap_count<true>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+         (const uint8_t *)e->live.visType, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_SWAP_OUT,
+         (int)kTransferBlocks);
+  LAUNCH(e, "swap_list", (k_swap_write<true>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+         (const uint8_t *)e->live.visType, (const int2 *)e->tileSums, e->swapIdsDev, e->swapFlagsDev);
+  LAUNCH(e, "swapout_move", k_swapout_move, dim3(1024), dim3(256), e->scene, (const int32_t *)e->swapIdsDev, e->swapStagingDev);
+  int32_t n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (n <= 0) return DSR_OK;
+  std::vector<int32_t> ids((size_t)n);
+  HIP_TRY(hipMemcpyAsync(ids.data(), e->swapIdsDev, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->swapStagingHost, e->swapStagingDev, (size_t)n * kBlockBytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int i = 0; i < n; ++i) {
+    std::vector<uint8_t> &blk = e->hostStore[ids[i]];
+    blk.assign(e->swapStagingHost + (size_t)i * kBlockBytes, e->swapStagingHost + (size_t)(i + 1) * kBlockBytes);
+  }
+  return DSR_OK;
+}
+
 }  // namespace
 
 #define CHECK_E(e)                                          \
@@ -403,7 +474,6 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (s.excess_list_size <= 0 || s.sdf_local_block_num <= 0) return fail(DSR_E_ARG, "bad table sizes");
   if (!(s.voxel_size > 0) || !(s.mu > 0) || s.max_w < 1 || s.max_w > 255) return fail(DSR_E_ARG, "bad scene params");
   if (calib->depth.width <= 0 || calib->depth.height <= 0) return fail(DSR_E_ARG, "bad image size");
-  if (s.use_swapping) return fail(DSR_E_ARG, "swapping not implemented in this build");
   int nDev = 0;
   if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0)
     return fail(DSR_E_DEVICE, "no HIP device: the HIP engine has no CPU fallback");
@@ -461,6 +531,16 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->freeDepth, (size_t)e->P));
   ALLOC(dmalloc(&e->decayFlags, (size_t)e->noBlocks));
   ALLOC(dmalloc(&e->decayCand, (size_t)e->noBlocks));
+  if (s.use_swapping) {
+    ALLOC(dmalloc(&e->scene.swapState, (size_t)e->E));
+    ALLOC(dmalloc(&e->scene.swapStored, (size_t)e->E));
+    ALLOC(dmalloc(&e->swapStagingDev, (size_t)kTransferBlocks * kBlockBytes));
+    ALLOC(dmalloc(&e->swapIdsDev, (size_t)kTransferBlocks));
+    ALLOC(dmalloc(&e->swapFlagsDev, (size_t)kTransferBlocks));
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->swapStagingHost), (size_t)kTransferBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess) {
+      free_all(e); delete e; return fail(DSR_E_NOMEM, "pinned staging buffer allocation failed");
+    }
+  }
   // clear image-sized buffers once so that dumps before the first frame are defined
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     (void)hipMemsetAsync(rs->raycastResult, 0, (size_t)e->P * 16, e->stream);
@@ -604,6 +684,10 @@ int dsr_process_frame(dsr_engine *e) {
   if (st) return st;
   st = integrate_scene(e);
   if (st) return st;
+  if (e->s.use_swapping) {  // ITMDenseMapper::ProcessFrame: CPU -> GPU, then GPU -> CPU
+    if ((st = swap_in(e))) return st;
+    if ((st = swap_out(e))) return st;
+  }
   e->framesProcessed++;
   if (e->s.sync_status) {
     int status = DSR_OK;
@@ -712,7 +796,7 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
              (int)SCAN_VISIBLE_FREE, e->noBlocks);
       LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E,
-             (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
+             (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0);
       int st = expected_depths(e, rs, p);
       if (st) return st;
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
@@ -879,6 +963,39 @@ int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uin
   if (tR) CP(hipMemcpy(target_rgba, tR, P * 4, hipMemcpyDeviceToHost));
 #undef CP
   cleanup();
+  return DSR_OK;
+}
+
+int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored) {
+  CHECK_E(e);
+  if (!e->scene.swapState) return fail(DSR_E_ARG, "swapping is not enabled");
+  if (states) HIP_TRY(hipMemcpyAsync(states, e->scene.swapState, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
+  if (has_stored) HIP_TRY(hipMemcpyAsync(has_stored, e->scene.swapStored, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present) {
+  CHECK_E(e);
+  if (!present || entry < 0 || entry >= e->E) return fail(DSR_E_ARG, "bad entry");
+  *present = 0;
+  if (!e->scene.swapState) return DSR_OK;
+  uint8_t flag = 0;
+  HIP_TRY(hipMemcpy(&flag, e->scene.swapStored + entry, 1, hipMemcpyDeviceToHost));
+  if (!flag) return DSR_OK;
+  auto it = e->hostStore.find(entry);
+  if (it == e->hostStore.end()) return fail(DSR_E_DEVICE, "host store inconsistent");
+  *present = 1;
+  if (out) {
+    const uint8_t *b = it->second.data();
+    for (int v = 0; v < kBlockSize3; ++v) {
+      dsr_voxel o; memset(&o, 0, sizeof o);
+      memcpy(&o.sdf, b + kOffSdf + v * 2, 2);
+      o.w_depth = b[kOffWDepth + v]; o.w_color = b[kOffWColor + v];
+      o.clr[0] = b[kOffClr + v * 4]; o.clr[1] = b[kOffClr + v * 4 + 1]; o.clr[2] = b[kOffClr + v * 4 + 2];
+      out[v] = o;
+    }
+  }
   return DSR_OK;
 }
 

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_count(SceneP s, int noTo
 }
 
 // Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
-enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5 };
+enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7 };
 __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tileSums, int numTiles, SceneP s, int mode,
                                                          int capacity) {
   __shared__ int2 lds[1024 / 64];
@@ -209,6 +209,22 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
       int n = carry.x < capacity ? carry.x : capacity;
       if (mode == SCAN_COMPACT_LIVE) ctr[CTR_TMP_OLD_NVIS] = ctr[CTR_NO_VISIBLE_LIVE];
       ctr[mode == SCAN_VISIBLE_FREE ? CTR_NO_VISIBLE_FREE : CTR_NO_VISIBLE_LIVE] = n;
+      if (mode == SCAN_VISIBLE_LIVE) {
+        // with swapping: visible swapped-out entries (y) take fresh blocks, after the frame's
+        // regular allocations, in ascending entry order
+        const int oldV = ctr[CTR_LAST_FREE_BLOCK];
+        ctr[CTR_ALLOC_OLD_HEAD_VBA] = oldV;
+        const int nv = oldV - carry.y;
+        ctr[CTR_LAST_FREE_BLOCK] = nv < -1 ? -1 : nv;
+        if (carry.y > oldV + 1) ctr[CTR_STATUS] = DSR_E_OUT_OF_BLOCKS;
+      }
+    } else if (mode == SCAN_SWAP_IN || mode == SCAN_SWAP_OUT) {
+      const int n = carry.x < capacity ? carry.x : capacity;
+      ctr[CTR_SWAP_COUNT] = n;
+      if (mode == SCAN_SWAP_OUT) {
+        ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];
+        ctr[CTR_LAST_FREE_BLOCK] += n;
+      }
     } else if (mode == SCAN_NCAND) {
       ctr[CTR_DECAY_NCAND] = carry.x < capacity ? carry.x : capacity;
     } else if (mode == SCAN_DECAY) {
@@ -368,7 +384,13 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP
         }
         visType[t] = v[j];
       }
-      if (v[j] > 0) c.x++;
+      if (v[j] > 0) {
+        c.x++;
+        if (p.useSwapping) {  // ITMSceneReconstructionEngine_CPU: swapStates + "reallocate deleted ones"
+          if (s.swapState[t] != 2) s.swapState[t] = 1;
+          if (s.table[t].ptr == -1) c.y++;
+        }
+      }
     }
   }
   int2 total;
@@ -376,28 +398,42 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP
   if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
 }
 
-// K3b: ordered compaction -> ascending visibleEntryIDs
+// K3b: ordered compaction -> ascending visibleEntryIDs; with swapping also the "reallocate
+// deleted ones from previous swap operation" loop (visible entries with ptr == -1 get a block)
 __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntries, const uint8_t *__restrict__ visType,
                                                                 const int2 *__restrict__ tileOffsets,
-                                                                int32_t *__restrict__ visibleIDs, int capacity) {
+                                                                int32_t *__restrict__ visibleIDs, int capacity,
+                                                                SceneP s, int useSwapping) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
   uint8_t v[kTileItems];
+  bool re[kTileItems];
   int2 c = make_int2(0, 0);
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j) {
     v[j] = (base + j < noTotalEntries) ? visType[base + j] : 0;
-    if (v[j] > 0) c.x++;
+    re[j] = false;
+    if (v[j] > 0) {
+      c.x++;
+      if (useSwapping && s.table[base + j].ptr == -1) { re[j] = true; c.y++; }
+    }
   }
   int2 total;
   int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
   if (total.x == 0) return;
-  int rank = tileOffsets[blockIdx.x].x + ex.x;
+  const int2 off = tileOffsets[blockIdx.x];
+  int rank = off.x + ex.x, rrank = off.y + ex.y;
+  const int oldHead = useSwapping ? s.ctr[CTR_ALLOC_OLD_HEAD_VBA] : 0;
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
     if (v[j] > 0) {
       if (rank < capacity) visibleIDs[rank] = base + j;
       rank++;
+      if (re[j]) {
+        const int vbaIdx = oldHead - rrank;
+        rrank++;
+        if (vbaIdx >= 0) s.table[base + j].ptr = s.voxelAllocList[vbaIdx];
+      }
     }
 }
 

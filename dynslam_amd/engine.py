@@ -262,6 +262,18 @@ class EngineCore:
         self._check(self.api.dump_allocation_lists(self._h, _ptr(v), _ptr(x)))
         return v, x
 
+    def dump_swap_state(self):
+        st = np.empty(self.no_total_entries, np.uint8)
+        hs = np.empty(self.no_total_entries, np.uint8)
+        self._check(self.api.dump_swap_state(self._h, _ptr(st), _ptr(hs)))
+        return st, hs
+
+    def dump_stored_block(self, entry):
+        out = np.empty(BLOCK_SIZE3, VOXEL_DTYPE)
+        present = C.c_int(0)
+        self._check(self.api.dump_stored_block(self._h, int(entry), _ptr(out), C.byref(present)))
+        return out if present.value else None
+
     def dump_render_state(self, freeview=False):
         mw, mh = (self.W + 7) // 8, (self.H + 7) // 8
         out = {

@@ -308,6 +308,17 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result,
                           float *points, float *normals, uint8_t *raycast_image);
 
+/* Host swapping (settings.use_swapping; ITMSwappingEngine + ITMGlobalCache, run inside
+ * dsr_process_frame after integration: IntegrateGlobalIntoLocal then SaveToGlobalMemory, at
+ * most DSR_TRANSFER_BLOCK_NUM blocks each way per frame).  Parity dumps:
+ *   states     : no_total_entries uint8 — ITMHashSwapState::state (0 host only / most recent on
+ *                host, 1 both: needs merge, 2 device most recent)
+ *   has_stored : no_total_entries uint8 — ITMGlobalCache::HasStoredData(entry)
+ * dsr_dump_stored_block copies the host-side copy of one entry's block (AoS); *present = 0 and
+ * `out` untouched when the global cache holds nothing for it. */
+int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored);
+int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present);
+
 /* ---- self-test ------------------------------------------------------------------- */
 
 /* Compares the engine's shared-reciprocal division (dsr_device.h: the IEEE fp32 divide

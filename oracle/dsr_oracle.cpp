@@ -35,6 +35,7 @@
 #include <deque>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #ifdef _OPENMP
@@ -198,6 +199,11 @@ struct Engine {
   int64_t framesProcessed = 0;
   std::deque<std::vector<int32_t>> decayFifo;
 
+  /* ITMGlobalCache (host store) + ITMHashSwapState, only with use_swapping */
+  std::vector<uint8_t> swapStates;
+  std::vector<uint8_t> hasStored;
+  std::unordered_map<int, std::vector<dsr_voxel>> storedBlocks;
+
   int threads = 1;
 };
 
@@ -224,6 +230,9 @@ static void reset_scene(Engine &e) {
   }
   e.decayFifo.clear();
   e.decayedBlockCount = 0;
+  std::fill(e.swapStates.begin(), e.swapStates.end(), 0);
+  std::fill(e.hasStored.begin(), e.hasStored.end(), 0);
+  e.storedBlocks.clear();
   e.stickyStatus = DSR_OK;
 }
 
@@ -464,12 +473,26 @@ static int allocate_scene_from_depth(Engine &e) {
       }
       evt[targetIdx] = hashVisibleType;
     }
+    if (useSwapping) {
+      if (hashVisibleType > 0 && e.swapStates[targetIdx] != 2) e.swapStates[targetIdx] = 1;
+    }
     if (hashVisibleType > 0) {
       if (noVisibleEntries < (int)rs.visibleEntryIDs.size()) rs.visibleEntryIDs[noVisibleEntries] = targetIdx;
       noVisibleEntries++;
     }
   }
   if (noVisibleEntries > (int)rs.visibleEntryIDs.size()) noVisibleEntries = (int)rs.visibleEntryIDs.size();
+
+  /* reallocate deleted ones from previous swap operation */
+  if (useSwapping) {
+    for (int targetIdx = 0; targetIdx < e.noTotalEntries; targetIdx++) {
+      if (evt[targetIdx] > 0 && e.hashTable[targetIdx].ptr == -1) {
+        int vbaIdx = lastFreeVoxelBlockId; lastFreeVoxelBlockId--;
+        if (vbaIdx >= 0) e.hashTable[targetIdx].ptr = e.voxelAllocationList[vbaIdx];
+        else status = DSR_E_OUT_OF_BLOCKS;
+      }
+    }
+  }
 
   /* heads are clamped at -1 (upstream lets them run negative; the fork throws,
    * InstanceReconstructor.cpp:662-671) */
@@ -1049,6 +1072,95 @@ static void render_image(Engine &e, RenderState &rs, const M4 &M, const V4f &pro
   }
 }
 
+/* --------------------------------------------------------------- swapping */
+
+/* ITMSwappingEngine.h combineVoxelDepthInformation / combineVoxelColorInformation
+ * (CombineVoxelInformation<true>) */
+static inline void combineVoxelInformation(const dsr_voxel &src, dsr_voxel &dst, int maxW) {
+  {
+    int newW = dst.w_depth, oldW = src.w_depth;
+    float newF = sdf_to_float((float)dst.sdf), oldF = sdf_to_float((float)src.sdf);
+    if (oldW != 0) {
+      newF = oldW * oldF + newW * newF;
+      newW = oldW + newW;
+      newF /= newW;
+      newW = std::min(newW, maxW);
+      dst.w_depth = (uint8_t)newW;
+      dst.sdf = sdf_from_float(newF);
+    }
+  }
+  {
+    int newW = dst.w_color, oldW = src.w_color;
+    V3f newC = {(float)dst.clr[0] / 255.0f, (float)dst.clr[1] / 255.0f, (float)dst.clr[2] / 255.0f};
+    V3f oldC = {(float)src.clr[0] / 255.0f, (float)src.clr[1] / 255.0f, (float)src.clr[2] / 255.0f};
+    if (oldW != 0) {
+      newC.x = oldC.x * (float)oldW + newC.x * (float)newW;
+      newC.y = oldC.y * (float)oldW + newC.y * (float)newW;
+      newC.z = oldC.z * (float)oldW + newC.z * (float)newW;
+      newW = oldW + newW;
+      newC.x /= (float)newW; newC.y /= (float)newW; newC.z /= (float)newW;
+      newW = std::min(newW, maxW);
+      dst.clr[0] = (uint8_t)f2i(newC.x * 255.0f); dst.clr[1] = (uint8_t)f2i(newC.y * 255.0f); dst.clr[2] = (uint8_t)f2i(newC.z * 255.0f);
+      dst.w_color = (uint8_t)newW;
+    }
+  }
+}
+
+/* ITMSwappingEngine_CPU<TVoxel,ITMVoxelBlockHash>::IntegrateGlobalIntoLocal (+ LoadFromGlobalMemory):
+ * the first <= SDF_TRANSFER_BLOCK_NUM entries (ascending) in state 1 are merged with their copy in
+ * the global cache, if any, and become state 2.  Deviation: an entry whose stored copy could not be
+ * given a block (voxel block array exhausted, ptr < 0) keeps state 1 instead of being merged
+ * through an invalid pointer. */
+static void swap_in(Engine &e) {
+  std::vector<int> needed;
+  for (int t = 0; t < e.noTotalEntries; t++) {
+    if ((int)needed.size() >= DSR_TRANSFER_BLOCK_NUM) break;
+    if (e.swapStates[t] == 1) needed.push_back(t);
+  }
+  const int maxW = e.s.max_w;
+  for (int id : needed) {
+    if (e.hasStored[id]) {
+      const int ptr = e.hashTable[id].ptr;
+      if (ptr < 0) continue;
+      const std::vector<dsr_voxel> &src = e.storedBlocks[id];
+      dsr_voxel *dst = &e.voxels[(size_t)ptr * DSR_BLOCK_SIZE3];
+      for (int v = 0; v < DSR_BLOCK_SIZE3; v++) combineVoxelInformation(src[v], dst[v], maxW);
+    }
+    e.swapStates[id] = 2;
+  }
+}
+
+/* ITMSwappingEngine_CPU<TVoxel,ITMVoxelBlockHash>::SaveToGlobalMemory: the first
+ * <= SDF_TRANSFER_BLOCK_NUM entries (ascending) that are in state 2, resident and NOT visible are
+ * copied to the global cache, their block is reset and pushed back on the free list, ptr = -1.
+ * (Upstream bounds the free-list push with `vbaIdx < SDF_BUCKET_NUM - 1`; the block-array size
+ * is the meaningful bound and the one used here — neither can trigger, since only allocated
+ * blocks are returned.) */
+static void swap_out(Engine &e) {
+  const uint8_t *evt = e.live.entriesVisibleType.data();
+  int count = 0;
+  int noAllocatedVoxelEntries = e.lastFreeBlockId;
+  for (int t = 0; t < e.noTotalEntries; t++) {
+    if (count >= DSR_TRANSFER_BLOCK_NUM) break;
+    const int localPtr = e.hashTable[t].ptr;
+    if (e.swapStates[t] == 2 && localPtr >= 0 && evt[t] == 0) {
+      dsr_voxel *blk = &e.voxels[(size_t)localPtr * DSR_BLOCK_SIZE3];
+      e.storedBlocks[t].assign(blk, blk + DSR_BLOCK_SIZE3);
+      e.hasStored[t] = 1;
+      e.swapStates[t] = 0;
+      int vbaIdx = noAllocatedVoxelEntries;
+      if (vbaIdx < e.noBlocks - 1) {
+        noAllocatedVoxelEntries++;
+        e.voxelAllocationList[vbaIdx + 1] = localPtr;
+        e.hashTable[t].ptr = -1;
+        for (int i = 0; i < DSR_BLOCK_SIZE3; i++) blk[i] = default_voxel();
+      }
+      count++;
+    }
+  }
+  e.lastFreeBlockId = noAllocatedVoxelEntries;
+}
+
 /* ------------------------------------------------------------------ decay */
 
 /* Fork: ITMDenseMapper::Decay (InfiniTamDriver.h:201-235).  No CPU version
@@ -1088,6 +1200,7 @@ static void decay(Engine &e, int maxWeight, int minAge, bool forceAll) {
       e.voxelAllocationList[e.lastFreeBlockId] = he.ptr;
       he.ptr = -2;
       rs.entriesVisibleType[t] = 0;
+      if (!e.swapStates.empty()) { e.swapStates[t] = 0; if (e.hasStored[t]) { e.hasStored[t] = 0; e.storedBlocks.erase(t); } }
       e.decayedBlockCount++;
       anyFreed = true;
     }
@@ -1134,7 +1247,6 @@ int orc_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (s.excess_list_size <= 0 || s.sdf_local_block_num <= 0) return fail(DSR_E_ARG, "bad table sizes");
   if (!(s.voxel_size > 0) || !(s.mu > 0) || s.max_w < 1 || s.max_w > 255) return fail(DSR_E_ARG, "bad scene params");
   if (calib->depth.width <= 0 || calib->depth.height <= 0) return fail(DSR_E_ARG, "bad image size");
-  if (s.use_swapping) return fail(DSR_E_ARG, "swapping not implemented in this build");
   dsr_engine *h = new (std::nothrow) dsr_engine();
   if (!h) return fail(DSR_E_NOMEM, "oom");
   Engine &e = h->e;
@@ -1152,6 +1264,7 @@ int orc_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e.voxels.resize((size_t)e.noBlocks * DSR_BLOCK_SIZE3);
     e.voxelAllocationList.resize(e.noBlocks);
     e.entriesAllocType.resize(e.noTotalEntries);
+    if (s.use_swapping) { e.swapStates.assign(e.noTotalEntries, 0); e.hasStored.assign(e.noTotalEntries, 0); }
     e.blockCoords.resize(4 * (size_t)e.noTotalEntries);
     const int mw = (e.W + 7) / 8, mh = (e.H + 7) / 8;
     for (RenderState *rs : {&e.live, &e.freeview}) {
@@ -1252,6 +1365,7 @@ int orc_process_frame(dsr_engine *h) {
   if (!E.hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   int st = allocate_scene_from_depth(E);
   integrate_into_scene(E);
+  if (E.s.use_swapping) { swap_in(E); swap_out(E); }  /* ITMDenseMapper::ProcessFrame */
   E.framesProcessed++;
   if (st != DSR_OK) return fail(st, "out of voxel blocks / excess list entries");
   return DSR_OK;
@@ -1467,6 +1581,22 @@ int orc_dump_render_state(dsr_engine *h, int which, float *minmax, float *raycas
   if (points) memcpy(points, E.pointsMap.data(), P * sizeof(V4f));
   if (normals) memcpy(normals, E.normalsMap.data(), P * sizeof(V4f));
   if (raycast_image) memcpy(raycast_image, rs.raycastImage.data(), P * 4);
+  return DSR_OK;
+}
+
+int orc_dump_swap_state(dsr_engine *h, uint8_t *states, uint8_t *has_stored) {
+  if (!h) return fail(DSR_E_ARG, "null");
+  if (E.swapStates.empty()) return fail(DSR_E_ARG, "swapping is not enabled");
+  if (states) memcpy(states, E.swapStates.data(), (size_t)E.noTotalEntries);
+  if (has_stored) memcpy(has_stored, E.hasStored.data(), (size_t)E.noTotalEntries);
+  return DSR_OK;
+}
+int orc_dump_stored_block(dsr_engine *h, int entry, dsr_voxel *out, int *present) {
+  if (!h || !present || entry < 0 || entry >= E.noTotalEntries) return fail(DSR_E_ARG, "bad entry");
+  *present = 0;
+  if (E.swapStates.empty() || !E.hasStored[entry]) return DSR_OK;
+  *present = 1;
+  if (out) memcpy(out, E.storedBlocks[entry].data(), DSR_BLOCK_SIZE3 * sizeof(dsr_voxel));
   return DSR_OK;
 }
 
