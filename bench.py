@@ -43,17 +43,45 @@ PRESETS = {
 
 def _gen_frame(args):
     from dynslam_amd.synth import StreetScene
-    w, h, i = args
-    rgba, d, T, _ = StreetScene(w, h).frame(i)
-    return rgba, d, T
+    w, h, i, n_inst = args
+    sc = StreetScene(w, h, n_instances=n_inst)
+    rgba, d, T, inst_id = sc.frame(i)
+    masks = []  # (instance, x0, y0, bbox-local uint8 mask, object->camera pose) like MNC detections
+    for k in range(n_inst):
+        ys, xs = np.nonzero(inst_id == k)
+        if len(ys) < 64:
+            continue
+        y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+        rel = (np.linalg.inv(sc.instance_pose(k, i).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
+        masks.append((k, int(x0), int(y0), (inst_id[y0:y1, x0:x1] == k).astype(np.uint8), rel))
+    return rgba, d, T, masks
 
 
-def make_frames(w, h, n):
+def make_frames(w, h, n, n_inst=0):
     procs = min(n, max(1, (os.cpu_count() or 2) - 1), 16)
     if procs <= 1:
-        return [_gen_frame((w, h, i)) for i in range(n)]
+        return [_gen_frame((w, h, i, n_inst)) for i in range(n)]
     with Pool(procs) as pool:
-        return pool.map(_gen_frame, [(w, h, i) for i in range(n)])
+        return pool.map(_gen_frame, [(w, h, i, n_inst) for i in range(n)])
+
+
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_b_bench5mm_pmc_traffic.json")
+
+
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, separate passes, MI355X_MICROARCH.md corrections; summarised by the round's
+    profiling run into profiles/).  PMC counters cannot be collected from inside this process, so
+    the figure is only reported for the exact command those passes profiled."""
+    same_cmd = (args.preset == "5mm" and args.width == 1242 and args.height == 375 and args.steps == 45
+                and args.warmup == 5 and not args.decay and not args.swap and not args.instances and args.gpus == 1)
+    if not same_cmd or not os.path.exists(PMC_TRAFFIC_FILE):
+        return None
+    try:
+        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"].get(kernel)
+        return round(k["hbm_bytes"], 0) if k else None
+    except Exception:
+        return None
 
 
 def settings_kwargs(preset):
@@ -77,7 +105,7 @@ def cpu_baseline(frames, w, h, preset, budget_s):
     sc = StreetScene(w, h)
     e = OracleEngine(oracle_settings(**kw), make_calib(*sc.intrinsics(), w, h), threads=1)
     done, t_total = 0, 0.0
-    for rgba, d, T in frames:
+    for rgba, d, T, _ in frames:
         e.update_view(rgba, d)
         e.set_pose_inv_m(T)
         t0 = time.perf_counter()
@@ -110,6 +138,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--decay", action="store_true", help="also run voxel GC each frame (min_age 200, max_weight 1)")
+    ap.add_argument("--swap", action="store_true", help="enable host swap-in/out (use_swapping; configs[4])")
+    ap.add_argument("--instances", type=int, default=0,
+                    help="configs[2]: also reconstruct this many moving instances in their own volumes "
+                         "(voxel 0.035, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379), split on the GPU")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +161,7 @@ def main():
 
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     n_frames = Wm + K
-    frames = make_frames(W, H, n_frames)
+    frames = make_frames(W, H, n_frames, args.instances)
     # inputs resident in HBM before the timed region
     rgb_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
     dep_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
@@ -138,10 +170,24 @@ def main():
 
     sc = StreetScene(W, H)
     kw = settings_kwargs(args.preset)
+    if args.swap:
+        kw["use_swapping"] = 1
     eng = EngineCore(default_settings(**kw, device=local_rank, sync_status=0), make_calib(*sc.intrinsics(), W, H))
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                   sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
+    inst_eng = [EngineCore(default_settings(**inst_kw, device=local_rank, sync_status=0), make_calib(*sc.intrinsics(), W, H))
+                for _ in range(args.instances)]
 
     def step(i):
         eng.update_view_dev(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr())
+        for k, x0, y0, mask, rel in frames[i][3]:
+            # ProcessSilhouette + RemoveSilhouette on the GPU, then FuseFrame of the instance
+            # (InstanceReconstructor.cpp:238-263,569-700)
+            eng.extract_silhouette(inst_eng[k], mask, x0, y0)
+            eng.remove_silhouette(mask, x0, y0)
+            inst_eng[k].set_pose_inv_m(rel)
+            inst_eng[k].process_frame()
+            inst_eng[k].prepare()
         eng.set_pose_inv_m(poses[i])
         eng.process_frame()
         eng.prepare()
@@ -149,6 +195,8 @@ def main():
             eng.decay(1, 200, False)
 
     def barrier():
+        for ie in inst_eng:
+            ie.sync()
         eng.sync()
         torch.cuda.synchronize()
         if world > 1:
@@ -189,7 +237,7 @@ def main():
                 achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                            "traffic": None,
+                            "traffic": pmc_traffic(args, "dsr::k_integrate<true>"),
                             "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                             "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}
         cpu = None
@@ -203,15 +251,18 @@ def main():
             "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: static map only, synthetic KITTI-like street {W}x{H}, "
+            "config": {"workload": f"{'configs[2]: static map + ' + str(args.instances) + ' instance volumes' if args.instances else 'configs[1]: static map only'}"
+                                   f"{' + voxel GC' if args.decay else ''}{' + host swapping' if args.swap else ''}, synthetic KITTI-like street {W}x{H}, "
                                    f"preset {args.preset} (voxel {kw['voxel_size']} m, mu {kw['mu']} m), "
                                    f"frames {Wm}..{Wm + K - 1} of a {n_frames}-frame sequence, one volume per GPU",
                        "visible_blocks_last_frame": stats.no_visible_blocks,
                        "allocated_blocks": kw["sdf_local_block_num"] - 1 - stats.last_free_block_id,
-                       "status": stats.sticky_status, "decay": bool(args.decay)},
+                       "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
+    for ie in inst_eng:
+        ie.close()
     eng.close()
     if world > 1:
         dist.barrier()

@@ -150,7 +150,11 @@ struct dsr_engine {
   uint8_t *swapStagingDev = nullptr, *swapStagingHost = nullptr;  // 16 MiB each (host one pinned)
   int32_t *swapIdsDev = nullptr;
   uint8_t *swapFlagsDev = nullptr;
-  std::unordered_map<int, std::vector<uint8_t>> hostStore;
+  std::vector<uint8_t *> hostSlabs;              // pinned, kTransferBlocks blocks each
+  int hostSlabUsed = 0;                          // slots used in the last slab
+  std::unordered_map<int, long long> hostSlot;   // entry -> slot of its most recent copy
+  std::vector<int32_t> swapIdsHost;
+  std::vector<uint8_t> swapFlagsHost;
   // silhouette masks (instance view split)
   uint8_t *maskScratch = nullptr;
   size_t maskCap = 0;
@@ -254,7 +258,10 @@ int reset_scene(dsr_engine *e) {
   if (e->scene.swapState) {
     HIP_TRY(hipMemsetAsync(e->scene.swapState, 0, (size_t)e->E, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.swapStored, 0, (size_t)e->E, e->stream));
-    e->hostStore.clear();
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->hostSlot.clear();
+    for (auto p : e->hostSlabs) (void)hipHostFree(p);
+    e->hostSlabs.clear(); e->hostSlabUsed = 0;
   }
   HIP_TRY(hipMemsetAsync(e->live.visType, 0, (size_t)e->E, e->stream));
   HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
@@ -276,6 +283,7 @@ void free_all(dsr_engine *e) {
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
   F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
   if (e->swapStagingHost) (void)hipHostFree(e->swapStagingHost);
+  for (auto p : e->hostSlabs) (void)hipHostFree(p);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
@@ -346,8 +354,16 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   LAUNCH(e, "minmax_init", k_minmax_init, dim3(div_up(mw * mh, 256)), dim3(256), rs.minmax, mw * mh,
          (const int32_t *)e->scene.ctr, rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? (int)CTR_NO_VISIBLE_LIVE : -1);
-  LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int32_t *)rs.visibleIDs,
-         rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+  const size_t ldsBytes = (size_t)mw * mh * sizeof(int2);
+  if (ldsBytes <= 64 * 1024) {
+    // range image privatised in LDS by a few large workgroups (k_raycast.h)
+    ProfScope _ps(e, "expected_depth");
+    hipLaunchKernelGGL(k_expected_depth_lds, dim3(64), dim3(1024), ldsBytes, e->stream, p, e->scene,
+                       (const int32_t *)rs.visibleIDs, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+  } else {
+    LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int32_t *)rs.visibleIDs,
+           rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+  }
   return DSR_OK;
 }
 
@@ -387,6 +403,14 @@ int ensure_fifo(dsr_engine *e, int slotsNeeded) {
   return DSR_OK;
 }
 
+// Host store (ITMGlobalCache): pinned slabs of kTransferBlocks plane-wise 4 KiB blocks.  A swap-out
+// batch is written straight into a slab by one asynchronous D2H copy (no per-block host work);
+// hostSlot maps a hash entry to its most recent copy (older copies of a re-swapped entry are
+// simply abandoned until the next reset).
+uint8_t *host_slot_ptr(dsr_engine *e, long long slot) {
+  return e->hostSlabs[(size_t)(slot / kTransferBlocks)] + (size_t)(slot % kTransferBlocks) * kBlockBytes;
+}
+
 // ITMSwappingEngine::IntegrateGlobalIntoLocal: host store -> staging -> merge into local blocks
 int swap_in(dsr_engine *e) {
   LAUNCH(e, "swap_list", (k_swap_count<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
@@ -395,29 +419,27 @@ int swap_in(dsr_engine *e) {
          (int)kTransferBlocks);
   LAUNCH(e, "swap_list", (k_swap_write<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
          (const uint8_t *)e->live.visType, (const int2 *)e->tileSums, e->swapIdsDev, e->swapFlagsDev);
+  // one round trip: count, ids and flags together (this also drains the previous frame's
+  // asynchronous swap-out copy, so the slabs read below are complete)
   int32_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->swapIdsHost.data(), e->swapIdsDev, (size_t)kTransferBlocks * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->swapFlagsHost.data(), e->swapFlagsDev, (size_t)kTransferBlocks, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (n <= 0) return DSR_OK;
-  std::vector<int32_t> ids((size_t)n);
-  std::vector<uint8_t> flags((size_t)n);
-  HIP_TRY(hipMemcpyAsync(ids.data(), e->swapIdsDev, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(flags.data(), e->swapFlagsDev, (size_t)n, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
   bool any = false;
   for (int i = 0; i < n; ++i) {
-    if (!flags[i]) continue;
-    auto it = e->hostStore.find(ids[i]);
-    if (it == e->hostStore.end()) return fail(DSR_E_DEVICE, "swap-in: device says the host store holds a block it does not hold");
-    memcpy(e->swapStagingHost + (size_t)i * kBlockBytes, it->second.data(), kBlockBytes);
+    if (!e->swapFlagsHost[i]) continue;
+    auto it = e->hostSlot.find(e->swapIdsHost[i]);
+    if (it == e->hostSlot.end()) return fail(DSR_E_DEVICE, "swap-in: device says the host store holds a block it does not hold");
+    memcpy(e->swapStagingHost + (size_t)i * kBlockBytes, host_slot_ptr(e, it->second), kBlockBytes);
     any = true;
   }
   if (any) HIP_TRY(hipMemcpyAsync(e->swapStagingDev, e->swapStagingHost, (size_t)n * kBlockBytes, hipMemcpyHostToDevice, e->stream));
   LAUNCH(e, "swapin_combine", k_swapin_combine, dim3(std::min(1024, div_up(n, 4))), dim3(256), e->scene, (int)e->s.max_w,
          (const int32_t *)e->swapIdsDev, (const uint8_t *)e->swapFlagsDev, (const uint8_t *)e->swapStagingDev);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(e->stream));  // the pinned buffer is reused by swap_out
-  return DSR_OK;
+  return DSR_OK;  // no sync: the pinned staging buffer is next touched after the next frame's round trip
 }
 
 // ITMSwappingEngine::SaveToGlobalMemory: invisible resident blocks -> staging -> host store
@@ -431,17 +453,22 @@ int swap_out(dsr_engine *e) {
   LAUNCH(e, "swapout_move", k_swapout_move, dim3(1024), dim3(256), e->scene, (const int32_t *)e->swapIdsDev, e->swapStagingDev);
   int32_t n = 0;
   HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->swapIdsHost.data(), e->swapIdsDev, (size_t)kTransferBlocks * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (n <= 0) return DSR_OK;
-  std::vector<int32_t> ids((size_t)n);
-  HIP_TRY(hipMemcpyAsync(ids.data(), e->swapIdsDev, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->swapStagingHost, e->swapStagingDev, (size_t)n * kBlockBytes, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int i = 0; i < n; ++i) {
-    std::vector<uint8_t> &blk = e->hostStore[ids[i]];
-    blk.assign(e->swapStagingHost + (size_t)i * kBlockBytes, e->swapStagingHost + (size_t)(i + 1) * kBlockBytes);
+  // room for n contiguous slots: the tail of the current slab or a fresh one
+  if (e->hostSlabs.empty() || e->hostSlabUsed + n > kTransferBlocks) {
+    uint8_t *slab = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&slab), (size_t)kTransferBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess)
+      return fail(DSR_E_NOMEM, "host store slab allocation failed");
+    e->hostSlabs.push_back(slab);
+    e->hostSlabUsed = 0;
   }
-  return DSR_OK;
+  const long long firstSlot = (long long)(e->hostSlabs.size() - 1) * kTransferBlocks + e->hostSlabUsed;
+  HIP_TRY(hipMemcpyAsync(host_slot_ptr(e, firstSlot), e->swapStagingDev, (size_t)n * kBlockBytes, hipMemcpyDeviceToHost, e->stream));
+  for (int i = 0; i < n; ++i) e->hostSlot[e->swapIdsHost[i]] = firstSlot + i;
+  e->hostSlabUsed += n;
+  return DSR_OK;  // asynchronous: ordered before any later use by the stream
 }
 
 }  // namespace
@@ -537,6 +564,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     ALLOC(dmalloc(&e->swapStagingDev, (size_t)kTransferBlocks * kBlockBytes));
     ALLOC(dmalloc(&e->swapIdsDev, (size_t)kTransferBlocks));
     ALLOC(dmalloc(&e->swapFlagsDev, (size_t)kTransferBlocks));
+    e->swapIdsHost.assign(kTransferBlocks, 0); e->swapFlagsHost.assign(kTransferBlocks, 0);
     if (hipHostMalloc(reinterpret_cast<void **>(&e->swapStagingHost), (size_t)kTransferBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess) {
       free_all(e); delete e; return fail(DSR_E_NOMEM, "pinned staging buffer allocation failed");
     }
@@ -983,11 +1011,12 @@ int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present
   uint8_t flag = 0;
   HIP_TRY(hipMemcpy(&flag, e->scene.swapStored + entry, 1, hipMemcpyDeviceToHost));
   if (!flag) return DSR_OK;
-  auto it = e->hostStore.find(entry);
-  if (it == e->hostStore.end()) return fail(DSR_E_DEVICE, "host store inconsistent");
+  auto it = e->hostSlot.find(entry);
+  if (it == e->hostSlot.end()) return fail(DSR_E_DEVICE, "host store inconsistent");
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the swap-out copy is asynchronous
   *present = 1;
   if (out) {
-    const uint8_t *b = it->second.data();
+    const uint8_t *b = host_slot_ptr(e, it->second);
     for (int v = 0; v < kBlockSize3; ++v) {
       dsr_voxel o; memset(&o, 0, sizeof o);
       memcpy(&o.sdf, b + kOffSdf + v * 2, 2);
