@@ -144,6 +144,9 @@ def main():
                          "(voxel 0.035, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379), split on the GPU")
     args = ap.parse_args()
 
+    # synthetic frames first: the worker pool forks, which must happen before HIP / RCCL start
+    frames = make_frames(args.width, args.height, args.warmup + args.steps, args.instances)
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -161,7 +164,6 @@ def main():
 
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     n_frames = Wm + K
-    frames = make_frames(W, H, n_frames, args.instances)
     # inputs resident in HBM before the timed region
     rgb_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
     dep_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
