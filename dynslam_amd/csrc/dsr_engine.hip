@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -26,6 +27,7 @@
 #include "k_edges.h"
 #include "k_integrate.h"
 #include "k_raycast.h"
+#include "k_raycast_lds.h"
 #include "k_swap.h"
 
 using namespace dsr;
@@ -120,6 +122,10 @@ struct dsr_engine {
   int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
   uint32_t maxSteps = 0;
   int gridPersistent = 2048;
+  // 0 = per-lane raycast (default, 0.66 ms at the 5 mm bench); 2/4/8 = experimental wave-cooperative
+  // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
+  // env DSR_RAYCAST_SLOTS for further work)
+  int raycastSlots = 0;
   Mat4 calibInv, M_d, invM_d;
 
   SceneP scene{};
@@ -367,6 +373,19 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
   return DSR_OK;
 }
 
+int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderStateDev &rs) {
+  dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+  if (e->raycastSlots == 8)
+    LAUNCH(e, name, (k_raycast_lds<8>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  else if (e->raycastSlots == 4)
+    LAUNCH(e, name, (k_raycast_lds<4>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  else if (e->raycastSlots == 2)
+    LAUNCH(e, name, (k_raycast_lds<2>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  else
+    LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  return DSR_OK;
+}
+
 int sticky_status(dsr_engine *e, int *status) {
   HIP_TRY(hipMemcpyAsync(status, e->scene.ctr + CTR_STATUS, 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -523,6 +542,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (S * (double)e->P >= 4294967295.0) { delete e; return fail(DSR_E_ARG, "mu/voxel_size ratio too large for the 32-bit allocation key"); }
     e->maxSteps = (uint32_t)S;
   }
+  if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();
@@ -739,7 +759,7 @@ int dsr_prepare(dsr_engine *e) {
   int st = expected_depths(e, rs, p);
   if (st) return st;
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  LAUNCH(e, "raycast", k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  launch_raycast(e, "raycast", p, rs);
   LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
          e->normalsMap, rs.raycastImage);
   HIP_TRY(hipGetLastError());
@@ -828,8 +848,7 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       int st = expected_depths(e, rs, p);
       if (st) return st;
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-      LAUNCH(e, "raycast_freeview", k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax,
-             rs.raycastResult);
+      launch_raycast(e, "raycast_freeview", p, rs);
       LAUNCH(e, "render", k_render, g, dim3(256), p, e->scene, type, (const float4 *)rs.raycastResult, rs.raycastImage,
              depth_out ? e->freeDepth : (float *)nullptr);
       HIP_TRY(hipGetLastError());

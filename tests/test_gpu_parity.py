@@ -175,3 +175,17 @@ def test_division_selftest(hip_api):
     bad = C.c_uint64(123)
     assert hip_api.selftest_division(0, 200_000_000, 12345, C.byref(bad)) == 0
     assert bad.value == 0
+
+
+def test_lds_raycast_variant(hip_api, monkeypatch):
+    """The experimental wave-cooperative LDS raycast (k_raycast_lds.h, off by default) must give
+    the same bits as the oracle too."""
+    monkeypatch.setenv("DSR_RAYCAST_SLOTS", "4")
+    sc, g, o = make_pair()
+    for i in range(4):
+        feed((g, o), sc, i)
+    assert_render_equal(g, o)
+    pose = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
+    ig, dg = g.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
+    io, do = o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
+    assert np.array_equal(ig, io) and np.array_equal(dg, do)
