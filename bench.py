@@ -170,6 +170,24 @@ def main():
     poses = [f[2] for f in frames]
     torch.cuda.synchronize()
 
+    # measured device-to-device copy bandwidth of this GPU (1 GiB, read + write), reported next to
+    # the nominal 8 TB/s peak the roofline fraction is quoted against
+    copy_gbs = None
+    if rank == 0:
+        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(5):
+            b.copy_(a)
+        ev1.record()
+        torch.cuda.synchronize()
+        copy_gbs = round(5 * 2 * a.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
+        del a, b
+        torch.cuda.empty_cache()
+
     sc = StreetScene(W, H)
     kw = settings_kwargs(args.preset)
     if args.swap:
@@ -240,6 +258,7 @@ def main():
                 roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                             "traffic": pmc_traffic(args, "dsr::k_integrate<true>"),
+                            "measured_copy_GBps": copy_gbs,
                             "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                             "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}
         cpu = None

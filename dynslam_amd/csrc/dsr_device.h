@@ -124,16 +124,7 @@ __device__ __forceinline__ float fdiv_tame(float a, float b) { return div_with_r
 __device__ __forceinline__ float sdf_to_float(float v) { return v / 32767.0f; }
 __device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f * 32767.0f); }
 
-// ORUtils Matrix4 * Vector4 (w explicit)
-__device__ __forceinline__ float4 mat_mul(const Mat4 &a, float x, float y, float z, float w) {
-  float4 r;
-  r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;
-  r.y = a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w;
-  r.z = a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w;
-  r.w = a.m[3] * x + a.m[7] * y + a.m[11] * z + a.m[15] * w;
-  return r;
-}
-// same without the (unused) w row
+// ORUtils Matrix4 * Vector4, the three rows the kernels use (w explicit)
 __device__ __forceinline__ float3 mat_mul3(const Mat4 &a, float x, float y, float z, float w) {
   float3 r;
   r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;

@@ -91,3 +91,41 @@ def test_preview_exchange_single_gpu(hip_api, oracle_lib):
     ids = np.array([3, 7], np.int32)
     assert oracle_lib.composite_instances(vp(t_c), vp(t_d), vp(lc), vp(ld), vp(ids), 2, P, 1.0, 1) == 0
     assert np.array_equal(bg_d.cpu().numpy(), t_d) and np.array_equal(bg_c.cpu().numpy(), t_c)
+
+
+def test_preview_exchange_over_rccl(hip_api, oracle_lib):
+    """The all-gather of PreviewExchange on a real RCCL process group (backend "nccl"; one rank:
+    the box has one GPU) followed by the HIP composite — the 8-GPU layout's code path."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from dynslam_amd.multigpu import PreviewExchange
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        P, n_vol = 4096, 4
+        ex = PreviewExchange(P, n_vol, 1, 0, dev, group=None)
+        rng = np.random.default_rng(0)
+        layers_c = rng.integers(0, 256, (3, P, 4)).astype(np.uint8)
+        layers_d = rng.uniform(1, 9, (3, P)).astype(np.float32); layers_d[rng.random((3, P)) < 0.5] = 0
+        ex.local_rgba.copy_(torch.from_numpy(layers_c)); ex.local_depth.copy_(torch.from_numpy(layers_d))
+        # force the collective path even for one rank
+        ex.world = 1
+        dist.all_gather_into_tensor(ex.all_depth, ex.local_depth)
+        dist.all_gather_into_tensor(ex.all_rgba.view(ex.slots, P * 4), ex.local_rgba.view(ex.slots, P * 4))
+        bg_c = rng.integers(0, 256, (P, 4)).astype(np.uint8); bg_d = rng.uniform(1, 9, P).astype(np.float32)
+        t_c, t_d = torch.from_numpy(bg_c).to(dev), torch.from_numpy(bg_d).to(dev)
+        ids = {0: 12, 1: 5, 2: 31}
+        ex.composite(t_c, t_d, ids)
+        torch.cuda.synchronize()
+        order = [1, 0, 2]
+        o_c, o_d = bg_c.copy(), bg_d.copy()
+        lc = np.ascontiguousarray(layers_c[order]); ld = np.ascontiguousarray(layers_d[order])
+        tid = np.array([5, 12, 31], np.int32)
+        assert oracle_lib.composite_instances(vp(o_c), vp(o_d), vp(lc), vp(ld), vp(tid), 3, P, 1.0, 1) == 0
+        assert np.array_equal(t_d.cpu().numpy(), o_d) and np.array_equal(t_c.cpu().numpy(), o_c)
+    finally:
+        dist.destroy_process_group()
