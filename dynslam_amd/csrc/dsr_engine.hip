@@ -122,6 +122,10 @@ struct dsr_engine {
   int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
   uint32_t maxSteps = 0;
   int gridPersistent = 2048;
+  // k_integrate grid: more, finer strided shares balance the tail (5 mm bench: 1280 workgroups
+  // (= resident) 918 us, 4096 872 us, 8192 840 us, 16384 835 us); scaled down for small volumes.
+  // env DSR_GRID_INTEGRATE overrides.
+  int gridIntegrate = 8192;
   // 0 = per-lane raycast (default, 0.66 ms at the 5 mm bench); 2/4/8 = experimental wave-cooperative
   // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
   // env DSR_RAYCAST_SLOTS for further work)
@@ -347,10 +351,10 @@ int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   if (p.rgbSame)
-    LAUNCH(e, "integrate", (k_integrate<true>), dim3(e->gridPersistent), dim3(256), p, e->scene, (const float *)e->depth,
+    LAUNCH(e, "integrate", (k_integrate<true>), dim3(e->gridIntegrate), dim3(256), p, e->scene, (const float *)e->depth,
            (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
   else
-    LAUNCH(e, "integrate", (k_integrate<false>), dim3(e->gridPersistent), dim3(256), p, e->scene,
+    LAUNCH(e, "integrate", (k_integrate<false>), dim3(e->gridIntegrate), dim3(256), p, e->scene,
            (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
@@ -543,6 +547,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e->maxSteps = (uint32_t)S;
   }
   if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
+  e->gridIntegrate = std::min(8192, std::max(256, s.sdf_local_block_num / 8));
+  if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();
