@@ -100,7 +100,7 @@ __device__ __forceinline__ float wave_read_sdf(const SceneP &s, const FrameP &p,
 // per-lane global path of k_raycast.h.
 template <int K>
 __device__ __forceinline__ float wave_read_sdf_interpolated(const SceneP &s, const FrameP &p, WaveSdfCache<K> &c, bool want,
-                                                            float x, float y, float z, VoxCache &gcache) {
+                                                            float x, float y, float z, VoxCache &gcache, VoxCache &gcache2) {
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const bool single = ((ix & 7) != 7) && ((iy & 7) != 7) && ((iz & 7) != 7);
   bool f;
@@ -143,7 +143,7 @@ __device__ __forceinline__ float wave_read_sdf_interpolated(const SceneP &s, con
       res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
       result = sdf_to_float((1.0f - cz) * res1 + cz * res2);
     } else {
-      result = read_sdf_interpolated(s, p, x, y, z, gcache);
+      result = read_sdf_interpolated(s, p, x, y, z, gcache, gcache2);
     }
   }
   return result;
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void k_raycast_lds(FrameP p, SceneP s, int ctr
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   VoxCache gcache; cache_init(gcache);
+  VoxCache gcache2; cache_init(gcache2);
 
   // ---- castRay set-up (ITMVisualisationEngine.h), identical to cast_ray() in k_raycast.h
   const float2 mm = inImage ? minmax[(x >> 3) + (y >> 3) * mw] : make_float2(kFarAway, kVeryClose);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void k_raycast_lds(FrameP p, SceneP s, int ctr
     const float raw = wave_read_sdf<K>(s, p, c, active, f2i(roundf_itm(rx)), f2i(roundf_itm(ry)), f2i(roundf_itm(rz)), hash_found);
     float sv = sdf_to_float(raw);
     const bool needTri = active && hash_found && (sv <= 0.1f) && (sv >= -0.5f);
-    const float tri = wave_read_sdf_interpolated<K>(s, p, c, needTri, rx, ry, rz, gcache);
+    const float tri = wave_read_sdf_interpolated<K>(s, p, c, needTri, rx, ry, rz, gcache, gcache2);
     if (active) {
       if (needTri) sv = tri;
       sdfValue = sv;
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void k_raycast_lds(FrameP p, SceneP s, int ctr
     stepLength = sdfValue * stepScale;
     rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
   }
-  const float refined = wave_read_sdf_interpolated<K>(s, p, c, hit, rx, ry, rz, gcache);
+  const float refined = wave_read_sdf_interpolated<K>(s, p, c, hit, rx, ry, rz, gcache, gcache2);
   if (inImage) {
     float4 out;
     if (hit) {
