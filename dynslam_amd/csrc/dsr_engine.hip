@@ -123,9 +123,13 @@ struct dsr_engine {
   uint32_t maxSteps = 0;
   int gridPersistent = 2048;
   // k_integrate grid: more, finer strided shares balance the tail (5 mm bench: 1280 workgroups
-  // (= resident) 918 us, 4096 872 us, 8192 840 us, 16384 835 us); scaled down for small volumes.
+  // (= resident) 918 us, 4096 872 us, 8192 840 us, 16384 835 us, whole-block variant); scaled down
+  // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
+  // k_integrate variant = voxels per lane x waves per SIMD.  48 (half block per wave, 62 VGPRs,
+  // 8 waves/SIMD): 757 us at the 5 mm bench; 85 (whole block per wave, 94 VGPRs, 5 waves): 797 us.
+  int integrateVariant = 48;
   // 0 = per-lane raycast (default, 0.66 ms at the 5 mm bench); 2/4/8 = experimental wave-cooperative
   // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
   // env DSR_RAYCAST_SLOTS for further work)
@@ -350,12 +354,22 @@ int allocate_scene(dsr_engine *e) {
 int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
-  if (p.rgbSame)
-    LAUNCH(e, "integrate", (k_integrate<true>), dim3(e->gridIntegrate), dim3(256), p, e->scene, (const float *)e->depth,
-           (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
-  else
-    LAUNCH(e, "integrate", (k_integrate<false>), dim3(e->gridIntegrate), dim3(256), p, e->scene,
-           (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs);
+  const bool plain = !p.depthWeighting && !p.stopAtMaxW;
+#define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
+  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
+         (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs)
+#define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
+  do {                                                                                                       \
+    if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
+    else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC); else LAUNCH_INTEGRATE(false, false, VOX, OCC); }         \
+  } while (0)
+  switch (e->integrateVariant) {  // voxels per lane x waves per SIMD (env DSR_INTEGRATE_VARIANT)
+    case 48: LAUNCH_INTEGRATE_V(4, 8); break;
+    case 46: LAUNCH_INTEGRATE_V(4, 6); break;
+    default: LAUNCH_INTEGRATE_V(8, 5); break;
+  }
+#undef LAUNCH_INTEGRATE_V
+#undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -547,8 +561,9 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e->maxSteps = (uint32_t)S;
   }
   if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
-  e->gridIntegrate = std::min(8192, std::max(256, s.sdf_local_block_num / 8));
+  e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
+  if (const char *iv = getenv("DSR_INTEGRATE_VARIANT")) e->integrateVariant = atoi(iv);
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();

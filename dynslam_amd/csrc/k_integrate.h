@@ -2,21 +2,23 @@
 //
 // Replaces integrateIntoScene_device (upstream: one 512-thread CUDA block per voxel block,
 // 8 B array-of-structs voxels).  CDNA4 formulation:
-//   * ONE WAVE64 PER VOXEL BLOCK, lane = (y,z) row of the 8^3 block, 8 voxels along x per
-//     lane.  With the plane-wise block layout (dsr_device.h) a lane moves 16 B of sdf and 8 B
-//     of w_depth with fully coalesced dwordx4/dwordx2 accesses (1 KiB per wave instruction).
-//   * PHASE A1 (project): branch-free; all 8 depth-image gathers of a lane are issued before
-//     any is consumed; image positions go to a per-wave LDS table.
-//   * PHASE A2 (depth): branch-free SDF running mean on all 512 voxels.  Voxels that also pass
-//     the colour gate (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended
-//     to a per-wave LDS list (wave64 ballot + prefix popcount).
+//   * A WAVE64 PER HALF BLOCK (VOX = 4 voxels along x per lane; 4 z-slices = 256 voxels per wave)
+//     or per whole block (VOX = 8).  With the plane-wise block layout (dsr_device.h) a lane moves
+//     2*VOX B of sdf and VOX B of w_depth in fully coalesced accesses (lane l owns voxels
+//     [VOX*l, VOX*l+VOX) of its half).  VOX = 4 halves the per-lane register arrays, which is what
+//     lets the kernel run at more waves per SIMD (VOX = 8: 96 VGPRs, 5 waves).
+//   * PHASE A1 (project): branch-free; all depth-image gathers of a lane are issued before any is
+//     consumed; image positions go to a per-wave LDS table.
+//   * PHASE A2 (depth): branch-free SDF running mean.  Voxels that also pass the colour gate
+//     (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended to a per-wave LDS
+//     list (wave64 ballot + prefix popcount).
 //   * PHASE B (colour): the wave walks that list DENSELY, 64 voxels per pass: gathers the 4 B
 //     colour + 1 B weight of each listed voxel, bilinear RGB sample, running mean, scatter back.
 //     The divergent colour branch of the per-voxel formulation (every lane paying for the few
 //     that need it) is gone and the colour planes of untouched voxels are never read.
-//   * A fixed persistent grid strides over the visible list whose length is read from device
-//     memory (the host never synchronises to learn noVisibleBlocks); hash entries are fetched
-//     two blocks ahead and voxel planes one block ahead of the arithmetic.
+//   * A persistent grid strides over the visible list whose length is read from device memory
+//     (the host never synchronises to learn noVisibleBlocks); hash entries are fetched two tasks
+//     ahead and voxel planes one task ahead of the arithmetic.
 //   * Divisions use the shared-reciprocal form of the IEEE sequence (dsr_device.h
 //     "correctly rounded division for tame operands"): same rounding, ~half the instructions.
 //   * The scalar unit is shared by the 4 SIMDs of a CU: per-voxel branching (exec-mask
@@ -53,27 +55,61 @@ __device__ __forceinline__ int depth_weight(float depth_measure) {
   return w < 1 ? 1 : w;
 }
 
-constexpr int kIntegrateWaves = 4;  // waves (= voxel blocks in flight) per workgroup
+constexpr int kIntegrateWaves = 4;  // waves (= tasks in flight) per workgroup
 
-// LDS slot of voxel v (= lane*8 + x) in the per-wave image-position table: x-major so that the
-// 64 lanes of one ds_write_b64 hit consecutive 8-byte slots (conflict-free).
-__device__ __forceinline__ int uv_slot(int vox) { return ((vox & 7) << 6) | (vox >> 3); }
+// the sdf / w_depth words a lane owns: VOX voxels = VOX/2 sdf words + VOX/4 weight words
+template <int VOX>
+struct LanePlanes {
+  uint32_t sdf[VOX / 2];
+  uint32_t wd[VOX / 4];
+};
+template <int VOX>
+__device__ __forceinline__ LanePlanes<VOX> load_planes(const uint8_t *blk, int vox0) {
+  LanePlanes<VOX> r;
+  if (VOX == 8) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(blk + kOffSdf + vox0 * 2);
+    const uint2 b = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + vox0);
+    r.sdf[0] = a.x; r.sdf[1] = a.y; r.sdf[VOX / 2 - 2] = a.z; r.sdf[VOX / 2 - 1] = a.w;
+    r.wd[0] = b.x; r.wd[VOX / 4 - 1] = b.y;
+  } else {
+    const uint2 a = *reinterpret_cast<const uint2 *>(blk + kOffSdf + vox0 * 2);
+    r.sdf[0] = a.x; r.sdf[VOX / 2 - 1] = a.y;
+    r.wd[0] = *reinterpret_cast<const uint32_t *>(blk + kOffWDepth + vox0);
+  }
+  return r;
+}
+template <int VOX>
+__device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LanePlanes<VOX> &r) {
+  if (VOX == 8) {
+    *reinterpret_cast<uint4 *>(blk + kOffSdf + vox0 * 2) = make_uint4(r.sdf[0], r.sdf[1], r.sdf[VOX / 2 - 2], r.sdf[VOX / 2 - 1]);
+    *reinterpret_cast<uint2 *>(blk + kOffWDepth + vox0) = make_uint2(r.wd[0], r.wd[VOX / 4 - 1]);
+  } else {
+    *reinterpret_cast<uint2 *>(blk + kOffSdf + vox0 * 2) = make_uint2(r.sdf[0], r.sdf[VOX / 2 - 1]);
+    *reinterpret_cast<uint32_t *>(blk + kOffWDepth + vox0) = r.wd[0];
+  }
+}
 
-template <bool RGB_SAME>
-// 5 waves per SIMD: measured optimum (98 -> 96 VGPRs; 4 waves: 987 us, 5: 918 us, 6: 1101 us with spills)
-__global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                                    const uchar4 *__restrict__ rgb,
-                                                                    const int32_t *__restrict__ visibleIDs) {
-  // per wave: image position of every voxel of the block + the list of voxels needing colour
-  __shared__ float2 s_uv[kIntegrateWaves][kBlockSize3];
-  __shared__ unsigned short s_idx[kIntegrateWaves][kBlockSize3];
+// PLAIN: depth weighting and stopIntegratingAtMaxW are both off (the defaults): the flags become
+// compile-time constants and their selects / the extra division disappear from the voxel loop.
+// OCC: waves per SIMD the register allocator must allow.
+template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
+__global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                                         const uchar4 *__restrict__ rgb,
+                                                                         const int32_t *__restrict__ visibleIDs) {
+  constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
+  constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
+  // per wave: image position of every voxel of the task + the list of voxels needing colour
+  __shared__ float2 s_uv[kIntegrateWaves][kVoxPerTask];
+  __shared__ unsigned short s_idx[kIntegrateWaves][kVoxPerTask];
 
   const int noVisible = s.ctr[CTR_NO_VISIBLE_LIVE];
+  const int noTasks = noVisible * kTasksPerBlock;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_INTEGRATED], (unsigned long long)noVisible);
+  const bool stopAtMaxW = PLAIN ? false : (p.stopAtMaxW != 0);
+  const bool depthWeighting = PLAIN ? false : (p.depthWeighting != 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int stride = gridDim.x * kIntegrateWaves;
-  const int ly = lane & 7, lz = lane >> 3;
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
@@ -92,45 +128,47 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
   const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
 
-  // software pipeline over this wave's blocks: entries two ahead, voxel planes one ahead
-  const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
-  int b = blockIdx.x * kIntegrateWaves + wave;
-  dsr_hash_entry heCur = (b < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b])) : kNone;
-  dsr_hash_entry heNext =
-      (b + stride < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b + stride])) : kNone;
-  uint4 sdfRaw = make_uint4(0, 0, 0, 0);
-  uint2 wdRaw = make_uint2(0, 0);
-  if (heCur.ptr >= 0) {
-    const uint8_t *blk0 = s.vba + (size_t)heCur.ptr * kBlockBytes;
-    sdfRaw = *reinterpret_cast<const uint4 *>(blk0 + kOffSdf + lane * 16);
-    wdRaw = *reinterpret_cast<const uint2 *>(blk0 + kOffWDepth + lane * 8);
-  }
+  // task t = (visible block t / kTasksPerBlock, half t % kTasksPerBlock); a lane owns the VOX
+  // consecutive voxels starting at vox0 (linear index x + 8y + 64z inside the block)
+  auto task_entry = [&](int tt) -> dsr_hash_entry {
+    return load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[tt / kTasksPerBlock]));
+  };
+  auto task_vox0 = [&](int tt) -> int { return VOX * lane + kVoxPerTask * (tt % kTasksPerBlock); };
 
-  for (; b < noVisible; b += stride) {
+  // software pipeline over this wave's tasks: entries two ahead, voxel planes one ahead
+  const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
+  int t = blockIdx.x * kIntegrateWaves + wave;
+  dsr_hash_entry heCur = (t < noTasks) ? task_entry(t) : kNone;
+  dsr_hash_entry heNext = (t + stride < noTasks) ? task_entry(t + stride) : kNone;
+  LanePlanes<VOX> planesNext;
+#pragma unroll
+  for (int k = 0; k < VOX / 2; ++k) planesNext.sdf[k] = 0;
+#pragma unroll
+  for (int k = 0; k < VOX / 4; ++k) planesNext.wd[k] = 0;
+  if (heCur.ptr >= 0) planesNext = load_planes<VOX>(s.vba + (size_t)heCur.ptr * kBlockBytes, task_vox0(t));
+
+  for (; t < noTasks; t += stride) {
     const dsr_hash_entry he = heCur;
-    const dsr_hash_entry heAfter =
-        (b + 2 * stride < noVisible) ? load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[b + 2 * stride])) : kNone;
-    uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
-    uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
-    if (heNext.ptr >= 0) {  // prefetch the next block's depth planes
-      const uint8_t *blkN = s.vba + (size_t)heNext.ptr * kBlockBytes;
-      sdfRaw = *reinterpret_cast<const uint4 *>(blkN + kOffSdf + lane * 16);
-      wdRaw = *reinterpret_cast<const uint2 *>(blkN + kOffWDepth + lane * 8);
-    }
+    const dsr_hash_entry heAfter = (t + 2 * stride < noTasks) ? task_entry(t + 2 * stride) : kNone;
+    LanePlanes<VOX> pl = planesNext;
+    if (heNext.ptr >= 0)  // prefetch the next task's depth planes
+      planesNext = load_planes<VOX>(s.vba + (size_t)heNext.ptr * kBlockBytes, task_vox0(t + stride));
     heCur = heNext;
     heNext = heAfter;
     if (he.ptr < 0) continue;
     uint8_t *blk = s.vba + (size_t)he.ptr * kBlockBytes;
 
-    const int gx = he.pos[0] * kBlockSize, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
+    const int vox0 = task_vox0(t);
+    const int lx0 = vox0 & 7, ly = (vox0 >> 3) & 7, lz = vox0 >> 6;
+    const int gx = he.pos[0] * kBlockSize + lx0, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
     const float my = (float)(gy + ly) * p.voxelSize;
     const float mz = (float)(gz + lz) * p.voxelSize;
 
-    // ---------------------------------------------- phase A1: project, issue the 8 depth gathers
-    float pz[8], dm[8];
+    // ---------------------------------------------- phase A1: project, issue the depth gathers
+    float pz[VOX], dm[VOX];
     uint32_t inbMask = 0, posMask = 0, grazeMask = 0;  // per-lane bit x: inside image / z > 0 / 0 < z < 1e-4
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
+    for (int x = 0; x < VOX; ++x) {
       const float mx = (float)(gx + x) * p.voxelSize;
       const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
       const bool pos = pc.z > 0;
@@ -151,7 +189,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
     if (__builtin_expect(__any(grazeMask != 0), 0)) {
       // voxels grazing the camera plane (0 < z < 1e-4): the divisor is not tame, redo them
       // with the plain IEEE divide
-      for (int x = 0; x < 8; ++x) {
+      for (int x = 0; x < VOX; ++x) {
         if (!((grazeMask >> x) & 1u)) continue;
         const float mx = (float)(gx + x) * p.voxelSize;
         const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
         uvTab[(x << 6) | lane] = make_float2(u, v);
         inbMask |= inb ? (1u << x) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (k == x) dm[k] = d;
+        for (int k = 0; k < VOX; ++k) if (k == x) dm[k] = d;
       }
     }
 
@@ -170,10 +208,10 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
     bool dirtyDepth = false;
     int nColor = 0;  // wave-uniform length of the colour list
 #pragma unroll
-    for (int x = 0; x < 8; ++x) {
-      const short sdf = (short)((sdfW[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
-      const int wDepth = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
-      const bool skip = p.stopAtMaxW && wDepth == p.maxW;
+    for (int x = 0; x < VOX; ++x) {
+      const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
+      const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
+      const bool skip = stopAtMaxW && wDepth == p.maxW;
       const float depth_measure = dm[x];
       // ---- computeUpdatedVoxelDepthInfo
       const bool ok = !skip && ((inbMask >> x) & 1u) && !(depth_measure <= 0.0f);
@@ -182,16 +220,16 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
       const bool upd = ok && !(eta < -p.mu);
       const float oldF = div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
       float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
-      int newW = p.depthWeighting ? depth_weight(ok ? depth_measure : 1.0f) : 1;
+      int newW = depthWeighting ? depth_weight(ok ? depth_measure : 1.0f) : 1;
       newF = (float)wDepth * oldF + (float)newW * newF;
       newW = wDepth + newW;
       newF = fdiv_tame(newF, (float)newW);
       newW = newW < p.maxW ? newW : p.maxW;
       const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
-      const uint32_t sw = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
-      const uint32_t ww = (wdW[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
-      sdfW[x >> 1] = upd ? sw : sdfW[x >> 1];
-      wdW[x >> 2] = upd ? ww : wdW[x >> 2];
+      const uint32_t sw = (pl.sdf[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
+      const uint32_t ww = (pl.wd[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
+      pl.sdf[x >> 1] = upd ? sw : pl.sdf[x >> 1];
+      pl.wd[x >> 2] = upd ? ww : pl.wd[x >> 2];
       dirtyDepth |= upd;
       // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
       //      voxels the depth step rejected carry eta = -1
@@ -200,26 +238,24 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
       bool wantColor = gate;
       if (!colourFollowsDepth) {  // uniform branch
         const bool reuse = RGB_SAME && ((posMask >> x) & 1u);
-        float2 t = uvTab[(x << 6) | lane];
+        float2 tuv = uvTab[(x << 6) | lane];
         if (gate && !reuse) {
           const float mx = (float)(gx + x) * p.voxelSize;
           const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
-          t.x = projr.x * pr.x / pr.z + projr.z;
-          t.y = projr.y * pr.y / pr.z + projr.w;
-          uvTab[(x << 6) | lane] = t;
+          tuv.x = projr.x * pr.x / pr.z + projr.z;
+          tuv.y = projr.y * pr.y / pr.z + projr.w;
+          uvTab[(x << 6) | lane] = tuv;
         }
-        wantColor = gate && !((t.x < 1) || (t.x > wcLim) || (t.y < 1) || (t.y > hcLim));
+        wantColor = gate && !((tuv.x < 1) || (tuv.x > wcLim) || (tuv.y < 1) || (tuv.y > hcLim));
       }
-      // append to the wave's colour list (ordered compaction across the 64 lanes)
+      // append to the wave's colour list (ordered compaction across the 64 lanes): the entry is the
+      // voxel's slot in uvTab, (x << 6) | lane; its voxel index is vox0(lane) + x
       const unsigned long long m = __ballot(wantColor);
-      if (wantColor) idxList[nColor + __popcll(m & laneMaskLt)] = (unsigned short)(lane * 8 + x);
+      if (wantColor) idxList[nColor + __popcll(m & laneMaskLt)] = (unsigned short)((x << 6) | lane);
       nColor += __popcll(m);
     }
 
-    if (dirtyDepth) {
-      *reinterpret_cast<uint4 *>(blk + kOffSdf + lane * 16) = make_uint4(sdfW[0], sdfW[1], sdfW[2], sdfW[3]);
-      *reinterpret_cast<uint2 *>(blk + kOffWDepth + lane * 8) = make_uint2(wdW[0], wdW[1]);
-    }
+    if (dirtyDepth) store_planes<VOX>(blk, vox0, pl);
 
     // ------------------------------------------------------------ phase B: colour
     // the tables were written and are read by this wave only; LDS operations of one wave
@@ -227,9 +263,11 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, 5) void k_integrate(FrameP p,
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int taskVoxBase = kVoxPerTask * (t % kTasksPerBlock);
     for (int i = lane; i < nColor; i += 64) {
-      const int vox = idxList[i];
-      const float2 uv = uvTab[uv_slot(vox)];
+      const int slot = idxList[i];
+      const float2 uv = uvTab[slot];
+      const int vox = taskVoxBase + VOX * (slot & 63) + (slot >> 6);  // owner lane's vox0 + x
       uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
       uint8_t *wcPtr = blk + kOffWColor + vox;
       const uint32_t cw = *clrPtr;
