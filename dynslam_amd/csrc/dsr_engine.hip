@@ -333,8 +333,8 @@ int allocate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
-  LAUNCH(e, "mark_prev_visible", k_mark_previous_visible, dim3(512), dim3(256), (const int32_t *)rs.visibleIDs,
-         (const int32_t *)e->scene.ctr, (int)CTR_NO_VISIBLE_LIVE, rs.visType);
+  LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
+         (const int32_t *)rs.visibleIDs, rs.visType);
   LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
          (const float *)e->depth, rs.visType);
   LAUNCH(e, "alloc_count", k_alloc_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
