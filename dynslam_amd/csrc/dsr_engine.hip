@@ -139,6 +139,7 @@ struct dsr_engine {
   SceneP scene{};
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
+  int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
 
   // view
   bool hasView = false;
@@ -291,7 +292,7 @@ void free_all(dsr_engine *e) {
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
-  F(e->tileSums); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
+  F(e->tileSums); F(e->allocWork); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
@@ -339,8 +340,10 @@ int allocate_scene(dsr_engine *e) {
          (const float *)e->depth, rs.visType);
   LAUNCH(e, "alloc_count", k_alloc_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
-  LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, (const float *)e->depth,
-         (const int2 *)e->tileSums, rs.visType);
+  LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
+         (const int2 *)e->tileSums, e->allocWork);
+  LAUNCH(e, "alloc_apply", k_alloc_apply, dim3(256), dim3(256), p, e->scene, (const float *)e->depth,
+         (const int4 *)e->allocWork, rs.visType);
   LAUNCH(e, "visible_count", (k_visible_count<false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
          e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
@@ -579,6 +582,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->scene.ctr, (size_t)CTR_COUNT));
   ALLOC(dmalloc(&e->scene.work, (size_t)WORK_COUNT));
   ALLOC(dmalloc(&e->scene.allocKey, (size_t)e->E));
+  ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     ALLOC(dmalloc(&rs->visibleIDs, (size_t)e->noBlocks));

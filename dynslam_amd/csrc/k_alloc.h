@@ -228,10 +228,12 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
   }
 }
 
-// K2b: commit in ascending entry order (the serial loop of AllocateSceneFromDepth).
-__global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                               const int2 *__restrict__ tileOffsets,
-                                                               uint8_t *__restrict__ visType) {
+// K2b: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two
+// steps. The sweep over the table only ranks the ~1 % marked entries and compacts them into
+// an ordered work list {entry, key, vbaIdx, exlIdx}; the dense kernel below replays the
+// winner's ray and writes the table, with every lane busy.
+__global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP s, const int2 *__restrict__ tileOffsets,
+                                                               int4 *__restrict__ workList) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
   uint32_t k[kTileItems];
@@ -256,34 +258,36 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP 
     const int t = base + j;
     s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
     const int vbaIdx = oldV - rank12;
+    int exlIdx = 0;
+    if (isExc[j]) { exlIdx = oldE - rank2; rank2++; }
+    // out of voxel blocks: nothing is written past the list end; out of excess entries: a hole
+    if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k[j], vbaIdx, isExc[j] ? exlIdx : -1);
     rank12++;
-    if (!isExc[j]) {  // type 1: in place (free head or tombstone); the chain link is kept
-      if (vbaIdx >= 0) {
-        short bx, by, bz;
-        alloc_winner_pos(p, depth, k[j], bx, by, bz);
-        dsr_hash_entry *he = s.table + t;
-        int2 w;
-        w.x = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
-        w.y = (int)(uint32_t)(uint16_t)bz;
-        *reinterpret_cast<int2 *>(he) = w;
-        he->ptr = s.voxelAllocList[vbaIdx];
-      }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_alloc_apply(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                     const int4 *__restrict__ workList, uint8_t *__restrict__ visType) {
+  const int total = s.ctr[CTR_ALLOC_TOTAL12], avail = s.ctr[CTR_ALLOC_OLD_HEAD_VBA] + 1;
+  const int n = total < avail ? total : avail;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int4 w = workList[i];
+    const int t = w.x;
+    if (t < 0) continue;
+    short bx, by, bz;
+    alloc_winner_pos(p, depth, (uint32_t)w.y, bx, by, bz);
+    const int px = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
+    const int pz = (int)(uint32_t)(uint16_t)bz;
+    const int ptr = s.voxelAllocList[w.z];
+    if (w.w < 0) {  // type 1: in place (free head or tombstone); the chain link is kept
+      dsr_hash_entry *he = s.table + t;
+      *reinterpret_cast<int2 *>(he) = make_int2(px, pz);
+      he->ptr = ptr;
     } else {  // type 2: append a child from the excess list to this chain tail
-      const int exlIdx = oldE - rank2;
-      rank2++;
-      if (vbaIdx >= 0 && exlIdx >= 0) {
-        short bx, by, bz;
-        alloc_winner_pos(p, depth, k[j], bx, by, bz);
-        const int exlOffset = s.excessAllocList[exlIdx];
-        s.table[t].offset = exlOffset + 1;
-        int4 w;
-        w.x = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
-        w.y = (int)(uint32_t)(uint16_t)bz;
-        w.z = 0;
-        w.w = s.voxelAllocList[vbaIdx];
-        *reinterpret_cast<int4 *>(s.table + p.noBuckets + exlOffset) = w;
-        visType[p.noBuckets + exlOffset] = 1;
-      }
+      const int exlOffset = s.excessAllocList[w.w];
+      s.table[t].offset = exlOffset + 1;
+      *reinterpret_cast<int4 *>(s.table + p.noBuckets + exlOffset) = make_int4(px, pz, 0, ptr);
+      visType[p.noBuckets + exlOffset] = 1;
     }
   }
 }
