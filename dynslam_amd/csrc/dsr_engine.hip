@@ -154,6 +154,7 @@ struct dsr_engine {
   int aosScratchBlocks = 0;
 
   int depthWeighting = 0;
+  bool shortDivMuExact = false;  // div_short(x, mu) == x / mu for every x (checked at creation)
   long long framesProcessed = 0;
 
   // voxel GC FIFO of visible lists
@@ -177,7 +178,7 @@ struct dsr_engine {
   uint8_t *decayFlags = nullptr;
 
   // profiling
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every kernel, 2 the two dominant kernels only
   std::vector<ProfRec> profRecs;
   std::map<std::string, int> profIndex;
   struct Pending { int rec; hipEvent_t a, b; };
@@ -214,6 +215,7 @@ struct ProfScope {
   dsr_engine *e; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(dsr_engine *e_, const char *name) : e(e_) {
     if (!e->profiling) return;
+    if (e->profiling == 2 && strcmp(name, "integrate") != 0 && strcmp(name, "raycast") != 0) return;
     auto it = e->profIndex.find(name);
     if (it == e->profIndex.end()) {
       rec = (int)e->profRecs.size();
@@ -305,6 +307,32 @@ void free_all(dsr_engine *e) {
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
+// div_short(a, b, RN(1/b)) against a / b for every numerator mantissa (a in [1, 2): division is
+// scale invariant while nothing under- or overflows, and symmetric in the signs)
+__global__ __launch_bounds__(256) void k_check_short_division(float b, unsigned long long *mismatches) {
+  const float y = 1.0f / b;
+  unsigned long long bad = 0;
+  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < (1u << 23); m += gridDim.x * blockDim.x) {
+    const float a = __uint_as_float(0x3f800000u | m);
+    if (__float_as_uint(div_short(a, b, y)) != __float_as_uint(a / b)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+// true when the one-correction division is exact for this divisor (k_integrate.h div_short)
+int short_division_exact(hipStream_t stream, float b, bool *exact) {
+  unsigned long long *d = nullptr, h = 1;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8));
+  (void)hipMemsetAsync(d, 0, 8, stream);
+  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, stream, b, d);
+  hipError_t err = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(stream);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, "short-division check failed to run");
+  *exact = (h == 0);
+  return DSR_OK;
+}
+
 template <class T>
 int dmalloc(T **p, size_t n) {
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
@@ -357,7 +385,7 @@ int allocate_scene(dsr_engine *e) {
 int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
-  const bool plain = !p.depthWeighting && !p.stopAtMaxW;
+  const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
   LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
          (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs)
@@ -614,6 +642,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
       free_all(e); delete e; return fail(DSR_E_NOMEM, "pinned staging buffer allocation failed");
     }
   }
+  ALLOC(short_division_exact(e->stream, s.mu, &e->shortDivMuExact));
   // clear image-sized buffers once so that dumps before the first frame are defined
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     (void)hipMemsetAsync(rs->raycastResult, 0, (size_t)e->P * 16, e->stream);
@@ -1121,6 +1150,13 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
   HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8));
   HIP_TRY(hipMemset(d, 0, 8));
   hipLaunchKernelGGL(k_selftest_division, dim3(4096), dim3(256), 0, 0, (unsigned long long)n, (unsigned long long)seed, d);
+  // the divisors the one-correction form is used with: the constants, every integer weight, and
+  // the truncation bands of the presets (an engine checks its own mu at creation)
+  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, 32767.0f, d);
+  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, 255.0f, d);
+  for (int w = 1; w <= 256; ++w) hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, (float)w, d);
+  for (float mu : {0.02f, 0.016f, 0.2f, 0.14f, 0.1f, 0.3f, 0.05f, 0.04f, 0.08f, 0.5f, 1.0f, 4.0f})
+    hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, mu, d);
   unsigned long long h = 0;
   hipError_t err = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
   (void)hipFree(d);
@@ -1235,7 +1271,7 @@ int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycas
 int dsr_profile_enable(dsr_engine *e, int enable) {
   CHECK_E(e);
   if (!enable) prof_resolve(e);
-  e->profiling = enable != 0;
+  e->profiling = enable == 2 ? 2 : (enable != 0);
   return DSR_OK;
 }
 

@@ -8,19 +8,23 @@
 //     [VOX*l, VOX*l+VOX) of its half).  VOX = 4 halves the per-lane register arrays, which is what
 //     lets the kernel run at more waves per SIMD (VOX = 8: 96 VGPRs, 5 waves).
 //   * PHASE A1 (project): branch-free; all depth-image gathers of a lane are issued before any is
-//     consumed; image positions go to a per-wave LDS table.
+//     consumed.  A task none of whose voxels passes the depth tests ends right after it.
 //   * PHASE A2 (depth): branch-free SDF running mean.  Voxels that also pass the colour gate
-//     (|eta/mu| <= 0.25: a thin sheet, ~1/4 of a surface block) are appended to a per-wave LDS
-//     list (wave64 ballot + prefix popcount).
-//   * PHASE B (colour): the wave walks that list DENSELY, 64 voxels per pass: gathers the 4 B
-//     colour + 1 B weight of each listed voxel, bilinear RGB sample, running mean, scatter back.
-//     The divergent colour branch of the per-voxel formulation (every lane paying for the few
-//     that need it) is gone and the colour planes of untouched voxels are never read.
+//     (|eta/mu| <= 0.25: a thin sheet, ~2 % of the visible voxels) are appended to a per-wave LDS
+//     list {block, voxel} (wave64 ballot + prefix popcount) that PERSISTS ACROSS TASKS.
+//   * PHASE B (colour): whenever the list holds 64 voxels the wave updates them DENSELY, one per
+//     lane: re-projects the voxel, gathers its 4 B colour + 1 B weight, bilinear RGB sample,
+//     running mean, scatter back.  The divergent colour branch of the per-voxel formulation (every
+//     lane paying ~150 instructions for the few that need it, once per task) is paid once per 64
+//     colour voxels instead, and the colour planes of untouched voxels are never read.
 //   * A persistent grid strides over the visible list whose length is read from device memory
 //     (the host never synchronises to learn noVisibleBlocks); hash entries are fetched two tasks
 //     ahead and voxel planes one task ahead of the arithmetic.
-//   * Divisions use the shared-reciprocal form of the IEEE sequence (dsr_device.h
-//     "correctly rounded division for tame operands"): same rounding, ~half the instructions.
+//   * The kernel is VALU-issue bound (~95 instructions per voxel quartet and lane before this
+//     formulation), not HBM bound, so instruction count is what is optimised: divisions use the
+//     shared-reciprocal form of the IEEE sequence (dsr_device.h "correctly rounded division for
+//     tame operands"), and for divisors with a correctly rounded reciprocal at hand (mu, 32767,
+//     255, the integer weights) the one-correction form div_short below.
 //   * The scalar unit is shared by the 4 SIMDs of a CU: per-voxel branching (exec-mask
 //     bookkeeping) made it a bottleneck, hence selects instead of nested ifs.
 //
@@ -57,6 +61,19 @@ __device__ __forceinline__ int depth_weight(float depth_measure) {
 
 constexpr int kIntegrateWaves = 4;  // waves (= tasks in flight) per workgroup
 
+// Division by a divisor whose CORRECTLY ROUNDED reciprocal y = RN(1/b) is at hand (constants
+// 32767 and 255, mu, the integer weights 1..256): one residual correction gives the correctly
+// rounded quotient.  Unlike the two-correction sequence this is not the compiler's own lowering
+// of `/`, so it is used only for divisors for which the equivalence with `/` has been checked
+// over all 2^23 numerator mantissas (division is scale invariant): the constants and the
+// weight table in dsr_selftest_division, mu at engine creation (dsr_engine.hip
+// short_division_exact; a failing mu selects the PLAIN = false kernels).
+__device__ __forceinline__ float div_short(float a, float b, float yRN) {
+  const float q = a * yRN;
+  const float r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, yRN, q);
+}
+
 // the sdf / w_depth words a lane owns: VOX voxels = VOX/2 sdf words + VOX/4 weight words
 template <int VOX>
 struct LanePlanes {
@@ -90,7 +107,8 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 }
 
 // PLAIN: depth weighting and stopIntegratingAtMaxW are both off (the defaults): the flags become
-// compile-time constants and their selects / the extra division disappear from the voxel loop.
+// compile-time constants, their selects / the extra division disappear from the voxel loop and
+// the divisions by mu, 32767 and the new weight take the one-correction form.
 // OCC: waves per SIMD the register allocator must allow.
 template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
@@ -98,9 +116,12 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
                                                                          const int32_t *__restrict__ visibleIDs) {
   constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
   constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
-  // per wave: image position of every voxel of the task + the list of voxels needing colour
-  __shared__ float2 s_uv[kIntegrateWaves][kVoxPerTask];
-  __shared__ unsigned short s_idx[kIntegrateWaves][kVoxPerTask];
+  // per wave: the voxels waiting for their colour update {block ptr, block pos x|y, pos z | voxel}
+  constexpr int kPendCap = 64 + kVoxPerTask;
+  __shared__ uint32_t s_pend[kIntegrateWaves][3][kPendCap];
+  __shared__ float s_rcpW[257];  // RN(1/w), w = 1..256 (`/` is the correctly rounded division)
+  for (int i = threadIdx.x; i < 257; i += 64 * kIntegrateWaves) s_rcpW[i] = 1.0f / (float)(i > 0 ? i : 1);
+  __syncthreads();
 
   const int noVisible = s.ctr[CTR_NO_VISIBLE_LIVE];
   const int noTasks = noVisible * kTasksPerBlock;
@@ -113,20 +134,71 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
-  float2 *uvTab = s_uv[wave];
-  unsigned short *idxList = s_idx[wave];
+  uint32_t *pendPtr = s_pend[wave][0], *pendXY = s_pend[wave][1], *pendZV = s_pend[wave][2];
 
-  // reciprocals of the constant divisors (uniform)
-  const float yMu = rcp_refined(p.mu), y32767 = rcp_refined(32767.0f), y255 = rcp_refined(255.0f);
+  // reciprocals of the constant divisors (uniform): correctly rounded for div_short, the refined
+  // hardware reciprocal for the two-correction form
+  const float yMu = PLAIN ? 1.0f / p.mu : rcp_refined(p.mu);
+  const float y32767 = PLAIN ? 1.0f / 32767.0f : rcp_refined(32767.0f);
+  const float y255 = 1.0f / 255.0f;
   // gate of ComputeUpdatedVoxelInfo<true> for voxels the depth step rejected with eta = -1
   // (true only for mu >= 4 m)
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
-  // common case: the colour projection is the depth projection and only depth-accepted voxels
-  // can pass the gate => the colour bounds test is implied by the depth one
-  const bool colourFollowsDepth = RGB_SAME && !rejectedPassGate;
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
   const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
+
+  // ------------------------------------------------------------ colour pass
+  // computeUpdatedVoxelColorInfo for `cnt` (<= 64) pending voxels starting at list position `base`,
+  // one per lane: every lane busy, which the per-voxel formulation (a divergent branch taken by
+  // ~2 % of the voxels) never was.  The voxel's colour projection is recomputed from its
+  // coordinates with the plain IEEE divide (for the shared-camera case it is the depth
+  // projection again: same operands, same correctly rounded quotient).
+  auto colour_pass = [&](int base, int cnt) {
+    // the list is written and read by this wave only; LDS operations of one wave execute in
+    // order, the fences keep the compiler from reordering across the boundary
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < cnt) {
+      const int i = base + lane;
+      const uint32_t bptr = pendPtr[i], pxy = pendXY[i], pzv = pendZV[i];
+      const int vox = (int)(pzv >> 16);
+      const int bx = (short)(pxy & 0xffffu), by = (short)(pxy >> 16), bz = (short)(pzv & 0xffffu);
+      const float mx = (float)(bx * kBlockSize + (vox & 7)) * p.voxelSize;
+      const float my = (float)(by * kBlockSize + ((vox >> 3) & 7)) * p.voxelSize;
+      const float mz = (float)(bz * kBlockSize + (vox >> 6)) * p.voxelSize;
+      const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
+      const float u = projr.x * pr.x / pr.z + projr.z;
+      const float v = projr.y * pr.y / pr.z + projr.w;
+      if (!((u < 1) || (u > wcLim) || (v < 1) || (v > hcLim))) {
+        uint8_t *blk = s.vba + (size_t)bptr * kBlockBytes;
+        uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
+        uint8_t *wcPtr = blk + kOffWColor + vox;
+        const uint32_t cw = *clrPtr;
+        const int oldWcI = (int)*wcPtr;
+        const float3 mm = bilinear_rgb(rgb, u, v, Wc);
+        const float oldWc = (float)oldWcI;
+        const float ocx = div_short((float)(cw & 0xffu), 255.0f, y255);
+        const float ocy = div_short((float)((cw >> 8) & 0xffu), 255.0f, y255);
+        const float ocz = div_short((float)((cw >> 16) & 0xffu), 255.0f, y255);
+        const float rx = div_short(mm.x, 255.0f, y255), ry = div_short(mm.y, 255.0f, y255),
+                    rz = div_short(mm.z, 255.0f, y255);
+        float newWc = 1.0f;
+        float ncx = ocx * oldWc + rx * newWc, ncy = ocy * oldWc + ry * newWc, ncz = ocz * oldWc + rz * newWc;
+        newWc = oldWc + newWc;
+        const float yW = s_rcpW[oldWcI + 1];
+        ncx = div_short(ncx, newWc, yW); ncy = div_short(ncy, newWc, yW); ncz = div_short(ncz, newWc, yW);
+        newWc = (newWc < (float)p.maxW) ? newWc : (float)p.maxW;  // MIN(newW, maxW)
+        const uint32_t r8 = (uint32_t)f2i(ncx * 255.0f) & 0xffu, g8 = (uint32_t)f2i(ncy * 255.0f) & 0xffu,
+                       b8 = (uint32_t)f2i(ncz * 255.0f) & 0xffu;
+        *clrPtr = r8 | (g8 << 8) | (b8 << 16);
+        *wcPtr = (uint8_t)f2i(newWc);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
 
   // task t = (visible block t / kTasksPerBlock, half t % kTasksPerBlock); a lane owns the VOX
   // consecutive voxels starting at vox0 (linear index x + 8y + 64z inside the block)
@@ -137,6 +209,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
   // software pipeline over this wave's tasks: entries two ahead, voxel planes one ahead
   const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
+  int nPend = 0;  // wave-uniform length of the pending colour list (< 64 between tasks)
   int t = blockIdx.x * kIntegrateWaves + wave;
   dsr_hash_entry heCur = (t < noTasks) ? task_entry(t) : kNone;
   dsr_hash_entry heNext = (t + stride < noTasks) ? task_entry(t + stride) : kNone;
@@ -166,7 +239,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
     // ---------------------------------------------- phase A1: project, issue the depth gathers
     float pz[VOX], dm[VOX];
-    uint32_t inbMask = 0, posMask = 0, grazeMask = 0;  // per-lane bit x: inside image / z > 0 / 0 < z < 1e-4
+    bool inb[VOX];
+    bool graze = false;
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
       const float mx = (float)(gx + x) * p.voxelSize;
@@ -177,53 +251,59 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       const float yz = rcp_refined(zs);
       const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
       const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
-      const bool inb = pos && tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
-      const int pix = inb ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0;
+      inb[x] = tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+      const int pix = inb[x] ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0;
       dm[x] = depth[pix];
       pz[x] = pc.z;
-      uvTab[(x << 6) | lane] = make_float2(u, v);
-      inbMask |= inb ? (1u << x) : 0u;
-      posMask |= pos ? (1u << x) : 0u;
-      grazeMask |= (pos && !tame) ? (1u << x) : 0u;
+      graze |= pos && !tame;
     }
-    if (__builtin_expect(__any(grazeMask != 0), 0)) {
+    if (__builtin_expect(__any(graze), 0)) {
       // voxels grazing the camera plane (0 < z < 1e-4): the divisor is not tame, redo them
       // with the plain IEEE divide
+#pragma unroll
       for (int x = 0; x < VOX; ++x) {
-        if (!((grazeMask >> x) & 1u)) continue;
+        if (!(pz[x] > 0) || pz[x] >= 1e-4f) continue;
         const float mx = (float)(gx + x) * p.voxelSize;
         const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
         const float u = p.proj.x * pc.x / pc.z + p.proj.z;
         const float v = p.proj.y * pc.y / pc.z + p.proj.w;
-        const bool inb = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
-        const float d = depth[inb ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0];
-        uvTab[(x << 6) | lane] = make_float2(u, v);
-        inbMask |= inb ? (1u << x) : 0u;
-#pragma unroll
-        for (int k = 0; k < VOX; ++k) if (k == x) dm[k] = d;
+        inb[x] = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+        dm[x] = depth[inb[x] ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0];
       }
     }
 
+    // computeUpdatedVoxelDepthInfo's rejection tests; a task none of whose voxels is updated
+    // (behind the surface / outside the image: ~15 % of the visible half blocks) ends here
+    float eta[VOX];
+    bool ok[VOX];
+    bool anyUpd = false;
+#pragma unroll
+    for (int x = 0; x < VOX; ++x) {
+      ok[x] = inb[x] && !(dm[x] <= 0.0f);
+      eta[x] = dm[x] - pz[x];
+      anyUpd |= ok[x] && !(eta[x] < -p.mu);
+    }
+    if (!rejectedPassGate && !__any(anyUpd)) continue;
+
     // ---------------------------------------------- phase A2: SDF running mean, colour gate
     bool dirtyDepth = false;
-    int nColor = 0;  // wave-uniform length of the colour list
+    const uint32_t posXY = (uint32_t)(uint16_t)he.pos[0] | ((uint32_t)(uint16_t)he.pos[1] << 16);
+    const uint32_t posZ = (uint32_t)(uint16_t)he.pos[2];
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
       const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
       const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
       const bool skip = stopAtMaxW && wDepth == p.maxW;
-      const float depth_measure = dm[x];
-      // ---- computeUpdatedVoxelDepthInfo
-      const bool ok = !skip && ((inbMask >> x) & 1u) && !(depth_measure <= 0.0f);
-      const float eta = depth_measure - pz[x];
-      const float q = div_with_rcp(eta, p.mu, yMu);  // eta / mu
-      const bool upd = ok && !(eta < -p.mu);
-      const float oldF = div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
+      const bool okx = !skip && ok[x];
+      const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
+      const bool upd = okx && !(eta[x] < -p.mu);
+      const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
+                               : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
       float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
-      int newW = depthWeighting ? depth_weight(ok ? depth_measure : 1.0f) : 1;
+      int newW = depthWeighting ? depth_weight(okx ? dm[x] : 1.0f) : 1;
       newF = (float)wDepth * oldF + (float)newW * newF;
       newW = wDepth + newW;
-      newF = fdiv_tame(newF, (float)newW);
+      newF = PLAIN ? div_short(newF, (float)newW, s_rcpW[newW]) : fdiv_tame(newF, (float)newW);
       newW = newW < p.maxW ? newW : p.maxW;
       const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
       const uint32_t sw = (pl.sdf[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
@@ -233,65 +313,28 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       dirtyDepth |= upd;
       // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
       //      voxels the depth step rejected carry eta = -1
-      const bool gate = !skip && (ok ? !((eta > p.mu) || (fabsf(q) > 0.25f)) : rejectedPassGate);
-      // ---- computeUpdatedVoxelColorInfo: projection + bounds
-      bool wantColor = gate;
-      if (!colourFollowsDepth) {  // uniform branch
-        const bool reuse = RGB_SAME && ((posMask >> x) & 1u);
-        float2 tuv = uvTab[(x << 6) | lane];
-        if (gate && !reuse) {
-          const float mx = (float)(gx + x) * p.voxelSize;
-          const float3 pr = mat_mul3(Mr, mx, my, mz, 1.0f);
-          tuv.x = projr.x * pr.x / pr.z + projr.z;
-          tuv.y = projr.y * pr.y / pr.z + projr.w;
-          uvTab[(x << 6) | lane] = tuv;
-        }
-        wantColor = gate && !((tuv.x < 1) || (tuv.x > wcLim) || (tuv.y < 1) || (tuv.y > hcLim));
+      const bool gateOk = !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
+      const bool gate = !skip && ((ok[x] && gateOk) || (!ok[x] && rejectedPassGate));
+      // append to the wave's pending colour list (ordered compaction across the 64 lanes)
+      const unsigned long long m = __ballot(gate);
+      if (gate) {
+        const int slot = nPend + __popcll(m & laneMaskLt);
+        pendPtr[slot] = (uint32_t)he.ptr;
+        pendXY[slot] = posXY;
+        pendZV[slot] = posZ | ((uint32_t)(vox0 + x) << 16);
       }
-      // append to the wave's colour list (ordered compaction across the 64 lanes): the entry is the
-      // voxel's slot in uvTab, (x << 6) | lane; its voxel index is vox0(lane) + x
-      const unsigned long long m = __ballot(wantColor);
-      if (wantColor) idxList[nColor + __popcll(m & laneMaskLt)] = (unsigned short)((x << 6) | lane);
-      nColor += __popcll(m);
+      nPend += __popcll(m);
     }
 
     if (dirtyDepth) store_planes<VOX>(blk, vox0, pl);
 
-    // ------------------------------------------------------------ phase B: colour
-    // the tables were written and are read by this wave only; LDS operations of one wave
-    // execute in order, the fences keep the compiler from reordering across the boundary.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int taskVoxBase = kVoxPerTask * (t % kTasksPerBlock);
-    for (int i = lane; i < nColor; i += 64) {
-      const int slot = idxList[i];
-      const float2 uv = uvTab[slot];
-      const int vox = taskVoxBase + VOX * (slot & 63) + (slot >> 6);  // owner lane's vox0 + x
-      uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
-      uint8_t *wcPtr = blk + kOffWColor + vox;
-      const uint32_t cw = *clrPtr;
-      const float oldWc = (float)*wcPtr;
-      const float ocx = div_with_rcp((float)(cw & 0xffu), 255.0f, y255);
-      const float ocy = div_with_rcp((float)((cw >> 8) & 0xffu), 255.0f, y255);
-      const float ocz = div_with_rcp((float)((cw >> 16) & 0xffu), 255.0f, y255);
-      const float3 mm = bilinear_rgb(rgb, uv.x, uv.y, Wc);
-      const float rx = div_with_rcp(mm.x, 255.0f, y255), ry = div_with_rcp(mm.y, 255.0f, y255),
-                  rz = div_with_rcp(mm.z, 255.0f, y255);
-      float newWc = 1.0f;
-      float ncx = ocx * oldWc + rx * newWc, ncy = ocy * oldWc + ry * newWc, ncz = ocz * oldWc + rz * newWc;
-      newWc = oldWc + newWc;
-      const float yW = rcp_refined(newWc);
-      ncx = div_with_rcp(ncx, newWc, yW); ncy = div_with_rcp(ncy, newWc, yW); ncz = div_with_rcp(ncz, newWc, yW);
-      newWc = (newWc < (float)p.maxW) ? newWc : (float)p.maxW;  // MIN(newW, maxW)
-      const uint32_t r8 = (uint32_t)f2i(ncx * 255.0f) & 0xffu, g8 = (uint32_t)f2i(ncy * 255.0f) & 0xffu,
-                     b8 = (uint32_t)f2i(ncz * 255.0f) & 0xffu;
-      *clrPtr = r8 | (g8 << 8) | (b8 << 16);
-      *wcPtr = (uint8_t)f2i(newWc);
+    // ------------------------------------------------------------ phase B: colour, 64 at a time
+    while (nPend >= 64) {
+      nPend -= 64;
+      colour_pass(nPend, 64);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
+  if (nPend > 0) colour_pass(0, nPend);
 }
 
 }  // namespace dsr

@@ -290,7 +290,8 @@ class EngineCore:
 
     # -- profiling ------------------------------------------------------------
     def profile_enable(self, enable=True):
-        self._check(self.api.profile_enable(self._h, int(bool(enable))))
+        """True / 1: HIP events around every kernel; 2: around integrate and raycast only."""
+        self._check(self.api.profile_enable(self._h, 2 if enable == 2 and enable is not True else int(bool(enable))))
 
     def profile_reset(self):
         self._check(self.api.profile_reset(self._h))

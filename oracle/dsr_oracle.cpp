@@ -579,6 +579,11 @@ static inline void computeUpdatedVoxelColorInfo(dsr_voxel &voxel, const V4f &pt_
   voxel.w_color = (uint8_t)f2i(newW);
 }
 
+/* oracle-only diagnostics of the integration (orc_debug_integrate_stats): blocks, voxels whose
+ * depth was updated, voxels whose colour was updated, half blocks / z-slices / blocks with any update */
+static long long g_int_stats[8];
+static bool g_int_stats_on = false;
+
 /* ITMSceneReconstructionEngine_CPU<TVoxel,ITMVoxelBlockHash>::IntegrateIntoScene */
 static void integrate_into_scene(Engine &e) {
   const RenderState &rs = e.live;
@@ -596,6 +601,7 @@ static void integrate_into_scene(Engine &e) {
     if (he.ptr < 0) continue;
     V3i globalPos = {he.pos[0] * DSR_BLOCK_SIZE, he.pos[1] * DSR_BLOCK_SIZE, he.pos[2] * DSR_BLOCK_SIZE};
     dsr_voxel *localVoxelBlock = &e.voxels[(size_t)he.ptr * DSR_BLOCK_SIZE3];
+    long long nUpd = 0, nClr = 0; unsigned sliceMask = 0;
     for (int z = 0; z < DSR_BLOCK_SIZE; z++)
       for (int y = 0; y < DSR_BLOCK_SIZE; y++)
         for (int x = 0; x < DSR_BLOCK_SIZE; x++) {
@@ -608,11 +614,24 @@ static void integrate_into_scene(Engine &e) {
           pt_model.z = (float)(globalPos.z + z) * voxelSize;
           pt_model.w = 1.0f;
           /* ComputeUpdatedVoxelInfo<true,TVoxel>::compute */
+          const dsr_voxel before = voxel;
           float eta = computeUpdatedVoxelDepthInfo(voxel, pt_model, M_d, projParams_d, mu, maxW, e.depth.data(),
                                                    e.W, e.H, e.depthWeighting);
+          if (g_int_stats_on && (eta != -1 && !(eta < -mu))) { nUpd++; sliceMask |= 1u << z; }
+          (void)before;
           if ((eta > mu) || (fabsf(eta / mu) > 0.25f)) continue;
           computeUpdatedVoxelColorInfo(voxel, pt_model, M_rgb, projParams_rgb, maxW, e.rgb.data(), e.Wr, e.Hr);
+          nClr++;
         }
+    if (g_int_stats_on) {
+#pragma omp critical
+      {
+        g_int_stats[0]++; g_int_stats[1] += nUpd; g_int_stats[2] += nClr;
+        g_int_stats[3] += ((sliceMask & 0x0f) != 0) + ((sliceMask & 0xf0) != 0);
+        g_int_stats[4] += __builtin_popcount(sliceMask);
+        g_int_stats[5] += sliceMask != 0;
+      }
+    }
   }
 }
 
@@ -1613,6 +1632,15 @@ int orc_debug_raycast_stats(int enable, int reset, long long out[8]) {
   g_rc_stats_on = enable != 0;
   if (out) memcpy(out, g_rc_stats, sizeof g_rc_stats);
   if (reset) memset(g_rc_stats, 0, sizeof g_rc_stats);
+  return DSR_OK;
+}
+
+/* oracle-only: integration statistics since the last reset: blocks, depth-updated voxels,
+ * colour-updated voxels, half blocks / z-slices / blocks with at least one depth update */
+int orc_debug_integrate_stats(int enable, int reset, long long out[8]) {
+  g_int_stats_on = enable != 0;
+  if (out) memcpy(out, g_int_stats, sizeof g_int_stats);
+  if (reset) memset(g_int_stats, 0, sizeof g_int_stats);
   return DSR_OK;
 }
 
