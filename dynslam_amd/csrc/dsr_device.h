@@ -121,7 +121,25 @@ __device__ __forceinline__ float div_with_rcp(float a, float b, float y1) {
 }
 __device__ __forceinline__ float fdiv_tame(float a, float b) { return div_with_rcp(a, b, rcp_refined(b)); }
 
+// Division by a divisor whose CORRECTLY ROUNDED reciprocal y = RN(1/b) is at hand (constants
+// 32767 and 255, mu, the integer weights 1..256): one residual correction gives the correctly
+// rounded quotient.  Unlike the two-correction sequence this is not the compiler's own lowering
+// of `/`, so it is used only for divisors for which the equivalence with `/` has been checked
+// over all 2^23 numerator mantissas (division is scale invariant): the constants and the
+// weight table in dsr_selftest_division, mu at engine creation (dsr_engine.hip
+// short_division_exact; a failing mu selects the PLAIN = false integrate kernels).
+// Precondition beyond "tame": a is not -0 (the sequence returns +0 for it; `/` returns -0).
+// Every call site divides a converted integer, a difference of finite positive floats, a running
+// mean of such or a trilinear combination of converted shorts, none of which can be -0.
+__device__ __forceinline__ float div_short(float a, float b, float yRN) {
+  const float q = a * yRN;
+  const float r = __builtin_fmaf(-b, q, a);
+  return __builtin_fmaf(r, yRN, q);
+}
+
 __device__ __forceinline__ float sdf_to_float(float v) { return v / 32767.0f; }
+// same value for every v that is not -0 (div_short)
+__device__ __forceinline__ float sdf_to_float_short(float v) { return div_short(v, 32767.0f, 1.0f / 32767.0f); }
 __device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f * 32767.0f); }
 
 // ORUtils Matrix4 * Vector4, the three rows the kernels use (w explicit)

@@ -61,19 +61,6 @@ __device__ __forceinline__ int depth_weight(float depth_measure) {
 
 constexpr int kIntegrateWaves = 4;  // waves (= tasks in flight) per workgroup
 
-// Division by a divisor whose CORRECTLY ROUNDED reciprocal y = RN(1/b) is at hand (constants
-// 32767 and 255, mu, the integer weights 1..256): one residual correction gives the correctly
-// rounded quotient.  Unlike the two-correction sequence this is not the compiler's own lowering
-// of `/`, so it is used only for divisors for which the equivalence with `/` has been checked
-// over all 2^23 numerator mantissas (division is scale invariant): the constants and the
-// weight table in dsr_selftest_division, mu at engine creation (dsr_engine.hip
-// short_division_exact; a failing mu selects the PLAIN = false kernels).
-__device__ __forceinline__ float div_short(float a, float b, float yRN) {
-  const float q = a * yRN;
-  const float r = __builtin_fmaf(-b, q, a);
-  return __builtin_fmaf(r, yRN, q);
-}
-
 // the sdf / w_depth words a lane owns: VOX voxels = VOX/2 sdf words + VOX/4 weight words
 template <int VOX>
 struct LanePlanes {

@@ -59,8 +59,9 @@ __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const 
   return sdf_to_float(v);
 }
 
-__device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                       VoxCache &cache, VoxCache &cache2) {
+// returns the trilinear combination BEFORE SDF_valueToFloat (the division by 32767)
+__device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                           VoxCache &cache, VoxCache &cache2) {
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   bool f;
@@ -85,7 +86,7 @@ __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const Fr
     res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
     res2 = (1.0f - cx) * v[4] + cx * v[5];
     res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
-    return sdf_to_float((1.0f - cz) * res1 + cz * res2);
+    return (1.0f - cz) * res1 + cz * res2;
   }
   {
     const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
@@ -111,7 +112,7 @@ __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const Fr
       res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
       res2 = (1.0f - cx) * v[4] + cx * v[5];
       res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
-      return sdf_to_float((1.0f - cz) * res1 + cz * res2);
+      return (1.0f - cz) * res1 + cz * res2;
     }
   }
   v1 = read_sdf_raw(s, p, ix, iy, iz, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy, iz, f, cache);
@@ -122,7 +123,11 @@ __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const Fr
   res2 = (1.0f - cx) * v1 + cx * v2;
   v1 = read_sdf_raw(s, p, ix, iy + 1, iz + 1, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy + 1, iz + 1, f, cache);
   res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
-  return sdf_to_float((1.0f - cz) * res1 + cz * res2);
+  return (1.0f - cz) * res1 + cz * res2;
+}
+__device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                       VoxCache &cache, VoxCache &cache2) {
+  return sdf_to_float(read_sdf_interpolated_raw(s, p, x, y, z, cache, cache2));
 }
 
 // One ray-march sample: castRay's
@@ -394,15 +399,19 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
           pfIdx = hash_index(nx, ny, nz, p.hashMask);
           pfRaw = *reinterpret_cast<const int4 *>(s.table + pfIdx);
         }
-        // (a second slot for the sample after next during runs of misses was measured: 580 us vs
-        //  515 us with this single look-ahead)
+        // (measured and rejected: a second look-ahead slot during runs of misses, 580 us vs 515 us;
+        //  four bucket heads at once after 8 misses in a row, 631 us; a fire-and-forget prefetch
+        //  of the head 3..10 miss steps ahead into an LDS sink, 560 us; parking lanes that need a
+        //  trilinear sample until 1..48 of them can take it together, 607..896 us.  Every variant
+        //  that adds requests or iterations loses: the march is bound by gather-request
+        //  throughput and by the per-wave chain of dependent round trips.)
       }
       float raw16 = 32767.0f;
       if (hash_found) {
         const int lin = (vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6);
         raw16 = (float)*reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf + lin * 2);
       }
-      sdfValue = sdf_to_float(raw16);
+      sdfValue = sdf_to_float_short(raw16);
     }
 #else
     sdfValue = read_sdf_uninterpolated(s, p, rx, ry, rz, hash_found, cache);
@@ -410,7 +419,7 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
     if (!hash_found) {
       stepLength = (float)kBlockSize;
     } else {
-      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = read_sdf_interpolated(s, p, rx, ry, rz, cache, cache2);
+      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = sdf_to_float_short(read_sdf_interpolated_raw(s, p, rx, ry, rz, cache, cache2));
       if (sdfValue <= 0.0f) break;
       float ss = sdfValue * stepScale;
       stepLength = (ss > 1.0f) ? ss : 1.0f;  // MAX(sdfValue * stepScale, 1.0f)
@@ -422,7 +431,7 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
   if (sdfValue <= 0.0f) {
     stepLength = sdfValue * stepScale;
     rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
-    sdfValue = read_sdf_interpolated(s, p, rx, ry, rz, cache, cache2);
+    sdfValue = sdf_to_float_short(read_sdf_interpolated_raw(s, p, rx, ry, rz, cache, cache2));
     stepLength = sdfValue * stepScale;
     rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
     out.w = 1.0f;

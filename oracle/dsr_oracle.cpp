@@ -705,6 +705,8 @@ static inline float readFromSDF_float_interpolated(const Engine &e, const V3f &p
 /* oracle-only diagnostics of the ray march (orc_debug_raycast_stats) */
 static long long g_rc_stats[8];
 static bool g_rc_stats_on = false;
+static int *g_rc_steps = nullptr;  /* per-pixel step counts of the last raycast (orc_debug_raycast_steps) */
+static int g_rc_steps_w = 0;
 
 /* ITMVisualisationEngine.h castRay */
 static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 &invM, const V4f &invProj,
@@ -740,7 +742,7 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
   pt_result = pt_block_s;
   IndexCache cache;
 
-  long long nMiss = 0, nFar = 0, nTri = 0;
+  long long nMiss = 0, nFar = 0, nTri = 0, nSat = 0;
   while (totalLength < totalLengthMax) {
     sdfValue = readFromSDF_float_uninterpolated(e, pt_result, hash_found, cache);
     if (!hash_found) {
@@ -748,6 +750,7 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
       nMiss++;
     } else {
       nFar++;
+      if (sdfValue >= 1.0f) nSat++;
       if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) { nTri++; sdfValue = readFromSDF_float_interpolated(e, pt_result, hash_found, cache); }
       if (sdfValue <= 0.0f) break;
       stepLength = std::max(sdfValue * stepScale, 1.0f);
@@ -775,6 +778,7 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
       if (nMiss + nFar > 50) g_rc_stats[7]++;
     }
   }
+  if (g_rc_steps) g_rc_steps[x + y * g_rc_steps_w] = (int)(nMiss | (nSat << 10) | ((nFar - nSat) << 20));  /* packed 10-bit fields */
   pt_out.x = pt_result.x; pt_out.y = pt_result.y; pt_out.z = pt_result.z;
   pt_out.w = pt_found ? 1.0f : 0.0f;
   return pt_found;
@@ -1632,6 +1636,13 @@ int orc_debug_raycast_stats(int enable, int reset, long long out[8]) {
   g_rc_stats_on = enable != 0;
   if (out) memcpy(out, g_rc_stats, sizeof g_rc_stats);
   if (reset) memset(g_rc_stats, 0, sizeof g_rc_stats);
+  return DSR_OK;
+}
+
+/* oracle-only: record the number of march steps of every ray of the following raycasts into
+ * out[W*H] (NULL stops recording) */
+int orc_debug_raycast_steps(int *out, int width) {
+  g_rc_steps = out; g_rc_steps_w = width;
   return DSR_OK;
 }
 

@@ -3,6 +3,7 @@
 
   profile_summary.py stats <dir>            -> per-kernel count / total / average duration
   profile_summary.py pmc <dir> [<dir> ...]  -> per-kernel mean of every collected counter
+  profile_summary.py traffic <fetch_dir> <write_dir> <n>  -> HBM bytes per launch (last n launches)
 
 Counters are reported raw; the FETCH_SIZE / WRITE_SIZE -> bytes conversion (KB units, FETCH_SIZE
 x2 for wide reads on gfx950, see tools/pmc_calibrate.py and MI355X_MICROARCH.md) is applied by the
@@ -40,8 +41,42 @@ def pmc(dirs):
     return {k: {c: {"mean": v[0] / v[1], "launches": v[1]} for c, v in cs.items()} for k, cs in acc.items()}
 
 
+def traffic(fetch_dir, write_dir, last_n):
+    """HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes, averaged over the LAST
+    last_n launches of every kernel (the timed steps of bench.py; earlier launches are warm-up).
+    Units per MI355X_MICROARCH.md / tools/pmc_calibrate.py: both counters are in KB; FETCH_SIZE
+    reports half of the bytes actually read (a 1 GiB device copy reads 524300 "KB")."""
+    def per_kernel(d, counter):
+        rows = defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == counter:
+                    rows[short(r["Kernel_Name"])].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+        out = {}
+        for k, v in rows.items():
+            v.sort()
+            tail = [x[1] for x in v[-last_n:]]
+            out[k] = (sum(tail) / len(tail), len(tail))
+        return out
+    fe, wr = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        f = fe.get(k, (0.0, 0))[0] * 1024.0 * 2.0
+        w = wr.get(k, (0.0, 0))[0] * 1024.0
+        kernels[k] = {"launches": max(fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1]),
+                      "fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w}
+    return {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 45 "
+                    "--warmup 5 --no-cpu-baseline --no-profile`; KB per launch averaged over the last %d launches "
+                    "of each kernel (the timed steps); FETCH_SIZE x2 per MI355X_MICROARCH.md (calibrated with "
+                    "tools/pmc_calibrate.py: a 1 GiB device copy reads 524300 KB, writes 1048576 KB)" % last_n,
+            "kernels": kernels}
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
-    res = stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2:])
+    if mode == "traffic":
+        res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    else:
+        res = stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2:])
     json.dump(res, sys.stdout, indent=1)
     print()
