@@ -84,6 +84,8 @@ struct SceneP {
   int32_t *ctr;           // Ctr
   unsigned long long *work;  // Work
   uint32_t *allocKey;     // per entry: 0 or (pixel*maxSteps + step + 1) of the winning writer
+  uint32_t *allocGrp;     // per 8 entries one byte: marked entries (low nibble), of those excess-list ones (high)
+  unsigned long long *allocTile;  // per sweep tile: marked entries (low 32 bits) | excess-list ones (high)
   uint8_t *swapState;     // ITMHashSwapState::state per entry (null unless use_swapping)
   uint8_t *swapStored;    // 1 = the host store (ITMGlobalCache) holds a copy of this entry's block
 };

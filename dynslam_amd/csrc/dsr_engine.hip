@@ -282,6 +282,8 @@ int reset_scene(dsr_engine *e) {
   }
   HIP_TRY(hipMemsetAsync(e->live.visType, 0, (size_t)e->E, e->stream));
   HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
+  HIP_TRY(hipMemsetAsync(e->scene.allocGrp, 0, (size_t)e->numTilesE * (kTile / 32) * 4, e->stream));
+  HIP_TRY(hipMemsetAsync(e->scene.allocTile, 0, ((size_t)e->numTilesE + 1) * 8, e->stream));
   e->fifoHead = 0; e->fifoLen = 0;
   HIP_TRY(hipGetLastError());
   return DSR_OK;
@@ -290,7 +292,7 @@ int reset_scene(dsr_engine *e) {
 void free_all(dsr_engine *e) {
   auto F = [](void *p) { if (p) (void)hipFree(p); };
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
-  F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey);
+  F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
@@ -366,10 +368,9 @@ int allocate_scene(dsr_engine *e) {
          (const int32_t *)rs.visibleIDs, rs.visType);
   LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
          (const float *)e->depth, rs.visType);
-  LAUNCH(e, "alloc_count", k_alloc_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
-  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
-  LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
-         (const int2 *)e->tileSums, e->allocWork);
+  int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
+  LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, allocTile, e->allocWork);
   LAUNCH(e, "alloc_apply", k_alloc_apply, dim3(256), dim3(256), p, e->scene, (const float *)e->depth,
          (const int4 *)e->allocWork, rs.visType);
   LAUNCH(e, "visible_count", (k_visible_count<false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
@@ -610,6 +611,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->scene.ctr, (size_t)CTR_COUNT));
   ALLOC(dmalloc(&e->scene.work, (size_t)WORK_COUNT));
   ALLOC(dmalloc(&e->scene.allocKey, (size_t)e->E));
+  ALLOC(dmalloc(&e->scene.allocGrp, (size_t)e->numTilesE * (kTile / 32)));
+  ALLOC(dmalloc(&e->scene.allocTile, (size_t)e->numTilesE + 1));
   ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
@@ -1309,8 +1312,7 @@ int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
     else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;
     else if (r.name == "expected_depth") k.bytes = (double)work[WORK_V_EXPECTED] * 16.0 + L * 8.0 * std::ceil(e->W / 8.0) * std::ceil(e->H / 8.0);
     else if (r.name == "icp_maps") k.bytes = L * P * (16.0 + 16.0 + 16.0 + 4.0);
-    else if (r.name == "alloc_count") k.bytes = L * E * 4.0;
-    else if (r.name == "alloc_commit") k.bytes = L * E * 4.0;
+    else if (r.name == "alloc_commit") k.bytes = L * E / 8.0;
     else if (r.name == "visible_count") k.bytes = L * E * 1.0;
     else if (r.name == "visible_write") k.bytes = L * E * 1.0;
     else if (r.name == "decay_blocks") k.bytes = (double)work[WORK_V_DECAY] * (16.0 + 2.0 * B);

@@ -130,7 +130,14 @@ __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const fl
         const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
         if (!isExcess) visType[target] = 1;
         uint32_t step = (uint32_t)i < p.maxSteps ? (uint32_t)i : p.maxSteps - 1u;
-        atomicMax(&s.allocKey[target], keyBase + step);
+        // the first writer of an entry in this frame (its key is still 0) also counts it: per group
+        // of 8 entries and per sweep tile, so that the commit finds the ~1 % marked entries
+        // without reading all the keys
+        if (atomicMax(&s.allocKey[target], keyBase + step) == 0u) {
+          const uint32_t one = isExcess ? 0x11u : 0x01u;
+          atomicAdd(&s.allocGrp[target >> 5], one << (((target >> 3) & 3u) * 8u));
+          atomicAdd(&s.allocTile[target / (uint32_t)kTile], isExcess ? 0x100000001ull : 1ull);
+        }
       }
     }
     px += r.dx; py += r.dy; pz += r.dz;
@@ -148,29 +155,6 @@ __device__ __forceinline__ void alloc_winner_pos(const FrameP &p, const float *_
   float px = r.px, py = r.py, pz = r.pz;
   for (uint32_t i = 0; i < step; ++i) { px += r.dx; py += r.dy; pz += r.dz; }
   bx = f2s(floorf(px)); by = f2s(floorf(py)); bz = f2s(floorf(pz));
-}
-
-// K2a: per tile, number of entries to allocate (x) and of those the excess-list ones (y)
-__global__ __launch_bounds__(kTileThreads) void k_alloc_count(SceneP s, int noTotalEntries, int2 *__restrict__ tileSums) {
-  __shared__ int2 lds[kTileThreads / 64];
-  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
-  int2 c = make_int2(0, 0);
-  if (base + kTileItems <= noTotalEntries) {
-    uint4 k0 = *reinterpret_cast<const uint4 *>(s.allocKey + base);
-    uint4 k1 = *reinterpret_cast<const uint4 *>(s.allocKey + base + 4);
-    uint32_t k[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-#pragma unroll
-    for (int j = 0; j < kTileItems; ++j)
-      if (k[j]) { c.x++; if (s.table[base + j].ptr >= -1) c.y++; }
-  } else {
-    for (int j = 0; j < kTileItems; ++j) {
-      int t = base + j;
-      if (t < noTotalEntries && s.allocKey[t]) { c.x++; if (s.table[t].ptr >= -1) c.y++; }
-    }
-  }
-  int2 total;
-  wg_exclusive_scan2<kTileThreads>(c, total, lds);
-  if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
 }
 
 // Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
@@ -228,40 +212,41 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
   }
 }
 
-// K2b: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two
-// steps. The sweep over the table only ranks the ~1 % marked entries and compacts them into
-// an ordered work list {entry, key, vbaIdx, exlIdx}; the dense kernel below replays the
-// winner's ray and writes the table, with every lane busy.
-__global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP s, const int2 *__restrict__ tileOffsets,
+// K2: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two
+// steps.  The sweep reads one BYTE per 8 entries (the counts k_alloc_mark kept), ranks the ~1 %
+// marked entries and compacts them into an ordered work list {entry, key, vbaIdx, exlIdx}; the
+// dense kernel below replays the winner's ray and writes the table, with every lane busy.  The
+// per-tile totals the ranks start from were accumulated by k_alloc_mark too and scanned by
+// k_scan_tile_sums: no pass over the 4-byte keys of all entries is left in the frame.
+__global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP s, int2 *__restrict__ tileOffsets,
                                                                int4 *__restrict__ workList) {
   __shared__ int2 lds[kTileThreads / 64];
-  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
-  uint32_t k[kTileItems];
-  uint8_t isExc[kTileItems];
-  int2 c = make_int2(0, 0);
-#pragma unroll
-  for (int j = 0; j < kTileItems; ++j) {
-    int t = base + j;
-    k[j] = (t < p.noTotalEntries) ? s.allocKey[t] : 0u;
-    isExc[j] = 0;
-    if (k[j]) { c.x++; if (s.table[t].ptr >= -1) { isExc[j] = 1; c.y++; } }
-  }
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;  // this thread's group of 8 entries
+  // counts of the group from the byte k_alloc_mark maintained (4 groups = 4 adjacent lanes per word)
+  uint32_t *grpWord = s.allocGrp + (base >> 5);
+  const uint32_t word = (base < p.noTotalEntries) ? *grpWord : 0u;
+  const uint32_t byte = (word >> (((base >> 3) & 3) * 8)) & 0xffu;
+  const int2 c = make_int2((int)(byte & 15u), (int)(byte >> 4));
+  if (word != 0u && (threadIdx.x & 3) == 0) *grpWord = 0u;  // ready for the next frame
   int2 total;
   int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
-  if (total.x == 0) return;
   const int2 tileOff = tileOffsets[blockIdx.x];
+  if (threadIdx.x == 0) tileOffsets[blockIdx.x] = make_int2(0, 0);  // k_alloc_mark accumulates into it again
+  if (c.x == 0) return;
   int rank12 = tileOff.x + ex.x, rank2 = tileOff.y + ex.y;
   const int oldV = s.ctr[CTR_ALLOC_OLD_HEAD_VBA], oldE = s.ctr[CTR_ALLOC_OLD_HEAD_EXC];
-#pragma unroll
   for (int j = 0; j < kTileItems; ++j) {
-    if (!k[j]) continue;
     const int t = base + j;
+    if (t >= p.noTotalEntries) break;
+    const uint32_t k = s.allocKey[t];
+    if (!k) continue;
+    const bool isExc = s.table[t].ptr >= -1;
     s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
     const int vbaIdx = oldV - rank12;
     int exlIdx = 0;
-    if (isExc[j]) { exlIdx = oldE - rank2; rank2++; }
+    if (isExc) { exlIdx = oldE - rank2; rank2++; }
     // out of voxel blocks: nothing is written past the list end; out of excess entries: a hole
-    if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k[j], vbaIdx, isExc[j] ? exlIdx : -1);
+    if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k, vbaIdx, isExc ? exlIdx : -1);
     rank12++;
   }
 }
