@@ -65,7 +65,7 @@ def make_frames(w, h, n, n_inst=0):
         return pool.map(_gen_frame, [(w, h, i, n_inst) for i in range(n)])
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_b_bench5mm_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_bench5mm_pmc_traffic.json")
 
 
 def pmc_traffic(args, kernel):
@@ -260,7 +260,10 @@ def main():
                 achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                            "traffic": pmc_traffic(args, "dsr::k_integrate<true>"),
+                            "traffic": pmc_traffic(args, "k_integrate"),
+                            "note": "algorithmic bytes = SURVEY 8d: V*(16+2*4096)+8P (every voxel of every visible "
+                                    "block read and written as 8 B structs); the plane-wise layout moves less "
+                                    "(traffic) and the kernel is VALU-issue bound (DESIGN.md 4)",
                             "measured_copy_GBps": copy_gbs,
                             "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                             "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}

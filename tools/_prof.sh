@@ -1,18 +1,23 @@
-set -x
+# Round profile: kernel-trace stats of the default bench command + separate PMC passes.
+# Run on the GPU box from the repo root: bash tools/_prof.sh <tag>   (writes gpurun_out/prof_<tag>/)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=$GRAFT_REPO_ROOT/gpurun_out/prof_r01d
+TAG=${1:-r01d}
+O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-rocprofv3 -L > $O/avail.txt 2>&1 || true
-B="python bench.py --no-cpu-baseline --no-profile"
+B="python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-profile"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py > $O/kt.log 2>&1
+grep '^{"metric"' $O/kt.log > $O/bench_line_under_rocprof.json
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $B > $O/fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $B > $O/write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/inst -o p --output-format csv -- $B > $O/inst.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INST_CYCLES_SALU -d $O/cyc -o p --output-format csv -- $B > $O/cyc.log 2>&1
-python tools/profile_summary.py stats $O/kt > $O/stats.json
-python tools/profile_summary.py pmc $O/fetch $O/write $O/inst $O/cyc > $O/pmc.json
-tail -3 $O/*.log
-# keep the merged output small
-find $O -name "*.csv" -size +2M -delete
-du -sh $O
+timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $O/cyc -o p --output-format csv -- $B > $O/cyc.log 2>&1
+python tools/profile_summary.py stats $O/kt > $O/kernel_stats.json
+python tools/profile_summary.py traffic $O/fetch $O/write 45 > $O/pmc_traffic.json
+python tools/profile_summary.py pmc $O/inst $O/cyc > $O/pmc_sq.json
+cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
+python bench.py > $O/bench_line.json 2> $O/bench.err
+python bench.py --profile-all --no-cpu-baseline > $O/bench_line_profile_all.json 2>> $O/bench.err
+find $O -name "*.csv" -size +1M -delete
+rm -rf $O/kt $O/fetch $O/write $O/inst $O/cyc
+ls -la $O
