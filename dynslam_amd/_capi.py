@@ -123,6 +123,11 @@ SIGNATURES = {
     "profile_enable": (C.c_int, [_H, C.c_int]),
     "profile_reset": (C.c_int, [_H]),
     "profile_get": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),
+    "mesh_scene": (C.c_int, [_H, C.POINTER(C.c_uint64)]),
+    "mesh_get": (C.c_int, [_H, C.c_void_p, C.c_uint64, C.c_uint64]),
+    "mesh_write_obj": (C.c_int, [_H, C.c_char_p]),
+    "mesh_free": (C.c_int, [_H]),
+    "save_scene_to_mesh": (C.c_int, [_H, C.c_char_p]),
 }
 
 

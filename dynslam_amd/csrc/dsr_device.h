@@ -47,6 +47,7 @@ enum Ctr {
   CTR_DECAY_NCAND = 10,       // candidates of the running decay call
   CTR_TMP_OLD_NVIS = 11,      // live visible count before the post-decay compaction
   CTR_SWAP_COUNT = 12,        // blocks in the running swap-in / swap-out transfer
+  CTR_MESH_TOTAL = 13,        // triangles of the running MeshScene
   CTR_COUNT = 16
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)

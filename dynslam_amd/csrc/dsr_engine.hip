@@ -29,6 +29,7 @@
 #include "k_raycast.h"
 #include "k_raycast_lds.h"
 #include "k_swap.h"
+#include "k_mesh.h"
 
 using namespace dsr;
 
@@ -140,6 +141,8 @@ struct dsr_engine {
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
   int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
+  dsr_triangle *meshTris = nullptr;  // current mesh (dsr_mesh_scene), device
+  uint64_t meshCount = 0;
 
   // view
   bool hasView = false;
@@ -296,7 +299,7 @@ void free_all(dsr_engine *e) {
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
-  F(e->tileSums); F(e->allocWork); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
+  F(e->tileSums); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
@@ -1102,6 +1105,115 @@ int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present
     }
   }
   return DSR_OK;
+}
+
+// ---- meshing
+
+int dsr_mesh_free(dsr_engine *e) {
+  CHECK_E(e);
+  if (e->meshTris) { HIP_TRY(hipStreamSynchronize(e->stream)); (void)hipFree(e->meshTris); e->meshTris = nullptr; }
+  e->meshCount = 0;
+  return DSR_OK;
+}
+
+// ITMMeshingEngine::MeshScene (an offline dump: host synchronisation is fine here)
+int dsr_mesh_scene(dsr_engine *e, uint64_t *n_triangles) {
+  CHECK_E(e);
+  int st = dsr_mesh_free(e);
+  if (st) return st;
+  // ascending list of the allocated entries (shared with Decay(forceAllVoxels))
+  LAUNCH(e, "mesh_candidates", k_allocated_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_NCAND, e->noBlocks);
+  LAUNCH(e, "mesh_candidates", k_allocated_write, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+         (const int2 *)e->tileSums, e->decayCand, e->noBlocks);
+  const int32_t *nPtr = e->scene.ctr + CTR_DECAY_NCAND;
+  int n = 0;
+  HIP_TRY(hipMemcpyAsync(&n, nPtr, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (n_triangles) *n_triangles = 0;
+  if (n <= 0) return DSR_OK;
+  uint32_t *blockCount = nullptr, *blockOffset = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&blockCount), (size_t)n * 4));
+  if (hipMalloc(reinterpret_cast<void **>(&blockOffset), (size_t)n * 4) != hipSuccess) { (void)hipFree(blockCount); return fail(DSR_E_NOMEM, "mesh scratch allocation failed"); }
+  MeshP mp; mp.voxelSize = e->s.voxel_size; mp.hashMask = (uint32_t)(e->noBuckets - 1); mp.noBuckets = e->noBuckets;
+  const int grid = std::min(8192, div_up(n, kMeshWaves));
+  const int tiles = div_up(n, kTile);
+  LAUNCH(e, "mesh_count", (k_mesh_blocks<false>), dim3(grid), dim3(64 * kMeshWaves), e->scene, mp, (const int32_t *)e->decayCand, nPtr,
+         blockCount, (const uint32_t *)nullptr, (dsr_triangle *)nullptr, 0ull);
+  LAUNCH(e, "mesh_scan", k_u32_tile_sums, dim3(tiles), dim3(kTileThreads), (const uint32_t *)blockCount, nPtr, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, tiles, e->scene, (int)SCAN_MESH, 0);
+  LAUNCH(e, "mesh_scan", k_u32_tile_offsets, dim3(tiles), dim3(kTileThreads), (const uint32_t *)blockCount, nPtr,
+         (const int2 *)e->tileSums, blockOffset);
+  int total = 0;
+  hipError_t err = hipMemcpyAsync(&total, e->scene.ctr + CTR_MESH_TOTAL, 4, hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  st = DSR_OK;
+  if (err != hipSuccess) st = fail(DSR_E_DEVICE, hipGetErrorString(err));
+  else if (total < 0) st = fail(DSR_E_ARG, "mesh has more than 2^31 triangles");
+  // ITMMesh: noMaxTriangles = maxBlocks * 32; the append keeps the first noMaxTriangles - 1
+  const unsigned long long cap = (unsigned long long)e->noBlocks * 32ull - 1ull;
+  const unsigned long long keep = std::min((unsigned long long)std::max(total, 0), cap);
+  if (st == DSR_OK && keep > 0) {
+    if (hipMalloc(reinterpret_cast<void **>(&e->meshTris), (size_t)keep * sizeof(dsr_triangle)) != hipSuccess) {
+      e->meshTris = nullptr;
+      st = fail(DSR_E_NOMEM, "mesh triangle buffer allocation failed");
+    } else {
+      LAUNCH(e, "mesh_write", (k_mesh_blocks<true>), dim3(grid), dim3(64 * kMeshWaves), e->scene, mp, (const int32_t *)e->decayCand,
+             nPtr, blockCount, (const uint32_t *)blockOffset, e->meshTris, keep);
+      err = hipStreamSynchronize(e->stream);
+      if (err != hipSuccess) st = fail(DSR_E_DEVICE, hipGetErrorString(err));
+      else e->meshCount = keep;
+    }
+  }
+  (void)hipStreamSynchronize(e->stream);
+  (void)hipFree(blockCount); (void)hipFree(blockOffset);
+  if (st == DSR_OK && n_triangles) *n_triangles = e->meshCount;
+  return st;
+}
+
+int dsr_mesh_get(dsr_engine *e, dsr_triangle *out, uint64_t first, uint64_t count) {
+  CHECK_E(e);
+  if (!out && count) return fail(DSR_E_ARG, "null");
+  if (first + count > e->meshCount) return fail(DSR_E_ARG, "triangle range outside the mesh");
+  if (count) {
+    HIP_TRY(hipMemcpyAsync(out, e->meshTris + first, (size_t)count * sizeof(dsr_triangle), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return DSR_OK;
+}
+
+// ITMMesh::WriteOBJ
+int dsr_mesh_write_obj(dsr_engine *e, const char *path) {
+  CHECK_E(e);
+  if (!path) return fail(DSR_E_ARG, "null path");
+  FILE *f = fopen(path, "w+");
+  if (!f) return fail(DSR_E_ARG, "cannot open the OBJ file for writing");
+  const uint64_t chunk = 1u << 20;
+  std::vector<dsr_triangle> buf((size_t)std::min<uint64_t>(chunk, e->meshCount));
+  int st = DSR_OK;
+  for (uint64_t first = 0; first < e->meshCount && st == DSR_OK; first += chunk) {
+    const uint64_t cnt = std::min<uint64_t>(chunk, e->meshCount - first);
+    st = dsr_mesh_get(e, buf.data(), first, cnt);
+    for (uint64_t i = 0; i < cnt && st == DSR_OK; ++i) {
+      const dsr_triangle &t = buf[(size_t)i];
+      fprintf(f, "v %f %f %f\n", t.p0[0], t.p0[1], t.p0[2]);
+      fprintf(f, "v %f %f %f\n", t.p1[0], t.p1[1], t.p1[2]);
+      fprintf(f, "v %f %f %f\n", t.p2[0], t.p2[1], t.p2[2]);
+    }
+  }
+  for (uint64_t i = 0; i < e->meshCount && st == DSR_OK; i++)
+    fprintf(f, "f %llu %llu %llu\n", (unsigned long long)(i * 3 + 2 + 1), (unsigned long long)(i * 3 + 1 + 1),
+            (unsigned long long)(i * 3 + 0 + 1));
+  fclose(f);
+  return st;
+}
+
+// ITMMainEngine::SaveSceneToMesh
+int dsr_save_scene_to_mesh(dsr_engine *e, const char *path) {
+  int st = dsr_mesh_scene(e, nullptr);
+  if (st == DSR_OK) st = dsr_mesh_write_obj(e, path);
+  if (e) (void)dsr_mesh_free(e);
+  return st;
 }
 
 // ---- self-test

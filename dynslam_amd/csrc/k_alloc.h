@@ -158,7 +158,7 @@ __device__ __forceinline__ void alloc_winner_pos(const FrameP &p, const float *_
 }
 
 // Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
-enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7 };
+enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7, SCAN_MESH = 8 };
 __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tileSums, int numTiles, SceneP s, int mode,
                                                          int capacity) {
   __shared__ int2 lds[1024 / 64];
@@ -201,6 +201,8 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
         ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];
         ctr[CTR_LAST_FREE_BLOCK] += n;
       }
+    } else if (mode == SCAN_MESH) {
+      ctr[CTR_MESH_TOTAL] = carry.x;
     } else if (mode == SCAN_NCAND) {
       ctr[CTR_DECAY_NCAND] = carry.x < capacity ? carry.x : capacity;
     } else if (mode == SCAN_DECAY) {

@@ -293,6 +293,25 @@ class EngineCore:
         """True / 1: HIP events around every kernel; 2: around integrate and raycast only."""
         self._check(self.api.profile_enable(self._h, 2 if enable == 2 and enable is not True else int(bool(enable))))
 
+    # ---- meshing (ITMMeshingEngine::MeshScene / ITMMesh::WriteOBJ / ITMMainEngine::SaveSceneToMesh)
+    def mesh_scene(self):
+        """Marching cubes over the allocated blocks; returns the triangles as float32 [n, 3, 3] (metres)."""
+        n = C.c_uint64(0)
+        self._check(self.api.mesh_scene(self._h, C.byref(n)))
+        out = np.empty((n.value, 3, 3), np.float32)
+        if n.value:
+            self._check(self.api.mesh_get(self._h, out.ctypes.data_as(C.c_void_p), 0, n.value))
+        return out
+
+    def mesh_write_obj(self, path):
+        self._check(self.api.mesh_write_obj(self._h, str(path).encode()))
+
+    def mesh_free(self):
+        self._check(self.api.mesh_free(self._h))
+
+    def save_scene_to_mesh(self, path):
+        self._check(self.api.save_scene_to_mesh(self._h, str(path).encode()))
+
     def profile_reset(self):
         self._check(self.api.profile_reset(self._h))
 
@@ -339,6 +358,7 @@ class InfiniTamDriver:
       GetImage/GetFloatImage      .cpp:165-209   (silent no-op before the first frame)
       GetUsedMemoryBytes/GetSavedDecayMemoryBytes  .h:241-250
       Reset()                     .h:282-284
+      SaveSceneToMesh(path)       ITMMainEngine (DynSlam.cpp:188-196); WaitForMeshDump() .h:252-255
     """
 
     def __init__(self, settings, calib, voxel_decay_params=None, use_depth_weighting=False, api=None):
@@ -428,3 +448,13 @@ class InfiniTamDriver:
 
     def Reset(self):
         self.core.reset_scene()
+
+    def SaveSceneToMesh(self, path):
+        """ITMMainEngine::SaveSceneToMesh as called by DynSlam::SaveStaticMap (DynSlam.cpp:188-196)
+        and, per instance, InstanceReconstructor::SaveObjectToMesh (InstanceReconstructor.cpp:736-763)."""
+        self.core.save_scene_to_mesh(path)
+
+    def WaitForMeshDump(self):
+        """InfiniTamDriver.h:252-255 joins the fork's asynchronous dump thread; the dump here is
+        synchronous, so there is nothing to wait for."""
+        return None

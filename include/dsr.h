@@ -344,6 +344,29 @@ int dsr_profile_reset(dsr_engine *e);
 /* Returns the number of records written (<= cap). */
 int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap);
 
+/* ---- meshing ---------------------------------------------------
+ * Replaces ITMMeshingEngine<TVoxel,TIndex>::MeshScene(mesh, scene) + ITMMesh::WriteOBJ as used by
+ * ITMMainEngine::SaveSceneToMesh (DynSlam.cpp:188-196 SaveStaticMap) and
+ * InstanceReconstructor::SaveObjectToMesh (InstanceReconstructor.cpp:736-763).
+ * Marching cubes over every allocated block in ascending entry order, voxels z/y/x, triangles in
+ * table order (the serial order of the _CPU engine; upstream's CUDA engine appends with atomics,
+ * i.e. in arbitrary order).  A cell is meshed when all 8 corners exist and none is at the
+ * initial sdf (+1.0).  Vertices are in metres.  The triangle table is generated
+ * (tools/gen_mc_tables.py): same edge table and surface as the classic tables, consistent on
+ * ambiguous faces; the order of the triangles inside a cell may differ from upstream's. */
+typedef struct dsr_triangle { float p0[3], p1[3], p2[3]; } dsr_triangle; /* ITMMesh::Triangle */
+/* ITMMesh(memoryType, maxBlocks): noMaxTriangles = sdf_local_block_num * 32; MeshScene keeps the
+ * first noMaxTriangles - 1 triangles.  The mesh stays on the device until dsr_mesh_free or the
+ * next dsr_mesh_scene.  n_triangles may be NULL. */
+int dsr_mesh_scene(dsr_engine *e, uint64_t *n_triangles);
+/* copies triangles [first, first+count) of the current mesh to host memory */
+int dsr_mesh_get(dsr_engine *e, dsr_triangle *out, uint64_t first, uint64_t count);
+/* ITMMesh::WriteOBJ: "v x y z" x3 per triangle ("%f"), then "f 3i+3 3i+2 3i+1" (1-based) */
+int dsr_mesh_write_obj(dsr_engine *e, const char *path);
+int dsr_mesh_free(dsr_engine *e);
+/* ITMMainEngine::SaveSceneToMesh(path) = MeshScene + WriteOBJ + release */
+int dsr_save_scene_to_mesh(dsr_engine *e, const char *path);
+
 #ifdef __cplusplus
 }
 #endif

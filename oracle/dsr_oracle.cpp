@@ -161,6 +161,7 @@ struct RenderState { /* ITMRenderState_VH */
 };
 
 struct Engine {
+  std::vector<dsr_triangle> mesh; /* current mesh (orc_mesh_scene) */
   dsr_settings s;
   dsr_calib calib;
   int W, H;          /* depth image size */
@@ -1629,6 +1630,121 @@ int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (m
 int orc_profile_enable(dsr_engine *h, int) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_reset(dsr_engine *h) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_get(dsr_engine *, dsr_kernel_time *, int) { return 0; }
+
+/* ------------------------------------------------------------- meshing (8f row 4) */
+
+#include "mc_tables.h"
+
+/* ITMMeshingEngine.h findPointNeighbors: the 8 corners of the cell at blockLocation, in the cube
+ * numbering of the tables; false when a corner is missing or still at the initial sdf (1.0). */
+static inline bool findPointNeighbors(const Engine &e, V3f *p, float *sdf, const V3i &blockLocation) {
+  static const int off[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+  for (int k = 0; k < 8; ++k) {
+    V3i q = {blockLocation.x + off[k][0], blockLocation.y + off[k][1], blockLocation.z + off[k][2]};
+    bool found;
+    dsr_voxel v = readVoxel(e, q, found, nullptr);
+    sdf[k] = sdf_to_float((float)v.sdf);
+    if (!found || sdf[k] == 1.0f) return false;
+    p[k] = {(float)q.x, (float)q.y, (float)q.z};
+  }
+  return true;
+}
+
+/* ITMMeshingEngine.h sdfInterp */
+static inline V3f sdfInterp(const V3f &p1, const V3f &p2, float valp1, float valp2) {
+  if (fabsf(0.0f - valp1) < 0.00001f) return p1;
+  if (fabsf(0.0f - valp2) < 0.00001f) return p2;
+  if (fabsf(valp1 - valp2) < 0.00001f) return p1;
+  const float t = (0.0f - valp1) / (valp2 - valp1);
+  return {p1.x + t * (p2.x - p1.x), p1.y + t * (p2.y - p1.y), p1.z + t * (p2.z - p1.z)};
+}
+
+/* ITMMeshingEngine.h buildVertList */
+static inline int buildVertList(const Engine &e, V3f *vertList, const V3i &globalPos, const V3i &localPos) {
+  V3f points[8];
+  float sdfVals[8];
+  V3i loc = {globalPos.x + localPos.x, globalPos.y + localPos.y, globalPos.z + localPos.z};
+  if (!findPointNeighbors(e, points, sdfVals, loc)) return -1;
+  int cubeIndex = 0;
+  for (int k = 0; k < 8; ++k) if (sdfVals[k] < 0) cubeIndex |= 1 << k;
+  if (kMcEdgeTable[cubeIndex] == 0) return -1;
+  static const int ends[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+  for (int k = 0; k < 12; ++k)
+    if (kMcEdgeTable[cubeIndex] & (1 << k))
+      vertList[k] = sdfInterp(points[ends[k][0]], points[ends[k][1]], sdfVals[ends[k][0]], sdfVals[ends[k][1]]);
+  return cubeIndex;
+}
+
+/* ITMMeshingEngine_CPU<TVoxel,ITMVoxelBlockHash>::MeshScene */
+int orc_mesh_scene(dsr_engine *h, uint64_t *n_triangles) {
+  if (!h) return fail(DSR_E_ARG, "null engine");
+  Engine &e = E;
+  e.mesh.clear();
+  const uint64_t noMaxTriangles = (uint64_t)e.s.sdf_local_block_num * 32u;
+  const float factor = e.s.voxel_size;
+  uint64_t noTriangles = 0;
+  for (int entryId = 0; entryId < e.noTotalEntries; entryId++) {
+    const dsr_hash_entry &he = e.hashTable[entryId];
+    if (he.ptr < 0) continue;
+    V3i globalPos = {he.pos[0] * DSR_BLOCK_SIZE, he.pos[1] * DSR_BLOCK_SIZE, he.pos[2] * DSR_BLOCK_SIZE};
+    for (int z = 0; z < DSR_BLOCK_SIZE; z++)
+      for (int y = 0; y < DSR_BLOCK_SIZE; y++)
+        for (int x = 0; x < DSR_BLOCK_SIZE; x++) {
+          V3f vertList[12];
+          int cubeIndex = buildVertList(e, vertList, globalPos, V3i{x, y, z});
+          if (cubeIndex < 0) continue;
+          for (int i = 0; kMcTriTable[cubeIndex][i] != -1; i += 3) {
+            const V3f &a = vertList[kMcTriTable[cubeIndex][i]], &b = vertList[kMcTriTable[cubeIndex][i + 1]],
+                      &c = vertList[kMcTriTable[cubeIndex][i + 2]];
+            dsr_triangle t = {{a.x * factor, a.y * factor, a.z * factor},
+                              {b.x * factor, b.y * factor, b.z * factor},
+                              {c.x * factor, c.y * factor, c.z * factor}};
+            /* triangles[noTriangles] = t; if (noTriangles < noMaxTriangles - 1) noTriangles++;
+             * => the first noMaxTriangles - 1 triangles survive */
+            if (noTriangles < noMaxTriangles - 1) { e.mesh.push_back(t); noTriangles++; }
+          }
+        }
+  }
+  if (n_triangles) *n_triangles = noTriangles;
+  return DSR_OK;
+}
+
+int orc_mesh_get(dsr_engine *h, dsr_triangle *out, uint64_t first, uint64_t count) {
+  if (!h || (!out && count)) return fail(DSR_E_ARG, "null");
+  if (first + count > E.mesh.size()) return fail(DSR_E_ARG, "triangle range outside the mesh");
+  if (count) memcpy(out, E.mesh.data() + first, (size_t)count * sizeof(dsr_triangle));
+  return DSR_OK;
+}
+
+/* ITMMesh::WriteOBJ */
+int orc_mesh_write_obj(dsr_engine *h, const char *path) {
+  if (!h || !path) return fail(DSR_E_ARG, "null");
+  FILE *f = fopen(path, "w+");
+  if (!f) return fail(DSR_E_ARG, "cannot open the OBJ file for writing");
+  for (const dsr_triangle &t : E.mesh) {
+    fprintf(f, "v %f %f %f\n", t.p0[0], t.p0[1], t.p0[2]);
+    fprintf(f, "v %f %f %f\n", t.p1[0], t.p1[1], t.p1[2]);
+    fprintf(f, "v %f %f %f\n", t.p2[0], t.p2[1], t.p2[2]);
+  }
+  for (uint64_t i = 0; i < E.mesh.size(); i++)
+    fprintf(f, "f %llu %llu %llu\n", (unsigned long long)(i * 3 + 2 + 1), (unsigned long long)(i * 3 + 1 + 1),
+            (unsigned long long)(i * 3 + 0 + 1));
+  fclose(f);
+  return DSR_OK;
+}
+
+int orc_mesh_free(dsr_engine *h) {
+  if (!h) return fail(DSR_E_ARG, "null engine");
+  E.mesh.clear(); E.mesh.shrink_to_fit();
+  return DSR_OK;
+}
+
+int orc_save_scene_to_mesh(dsr_engine *h, const char *path) {
+  int st = orc_mesh_scene(h, nullptr);
+  if (st == DSR_OK) st = orc_mesh_write_obj(h, path);
+  if (h) orc_mesh_free(h);
+  return st;
+}
 
 /* oracle-only: ray-march statistics since the last call with reset != 0:
  * rays, miss steps, found steps, trilinear samples, max steps of a ray, hits, rays > 200 steps, rays > 50 steps */

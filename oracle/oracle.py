@@ -19,7 +19,8 @@ def build(force=False):
     src = os.path.join(_HERE, "dsr_oracle.cpp")
     hdr = os.path.join(_HERE, "..", "include", "dsr.h")
     stale = (not os.path.exists(LIB_PATH)
-             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr),
+                                                  os.path.getmtime(os.path.join(_HERE, "mc_tables.h"))))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
 

@@ -253,6 +253,49 @@ template <class TVoxel, class TIndex> struct ITMScene {
 
 class ITMMainEngine;
 
+// ITMMesh / ITMMeshingEngine facades (InstanceReconstructor.cpp:749-757).  The triangles stay on the
+// device inside the dsr engine that meshed them; ITMMesh is the handle the host writes out.
+class ITMMesh {
+ public:
+  struct Triangle { Vector3f p0, p1, p2; };
+  MemoryDeviceType memoryType;
+  uint noTotalTriangles = 0;
+  uint noMaxTriangles;
+  ITMMesh(MemoryDeviceType type, long maxBlocks) : memoryType(type), noMaxTriangles((uint)(maxBlocks * 32)) {}
+  ~ITMMesh() { if (e_) dsr_mesh_free(e_); }
+  void WriteOBJ(const char *fileName) {
+    if (!e_) throw std::runtime_error("ITMMesh::WriteOBJ: MeshScene has not been run");
+    ITMLib::Engine::dsr_throw(dsr_mesh_write_obj(e_, fileName));
+  }
+  // copies triangles [first, first + count) to host memory (upstream: triangles->GetData(MEMORYDEVICE_CPU))
+  void GetTriangles(Triangle *out, uint first, uint count) {
+    if (!e_) throw std::runtime_error("ITMMesh: MeshScene has not been run");
+    ITMLib::Engine::dsr_throw(dsr_mesh_get(e_, reinterpret_cast<dsr_triangle *>(out), first, count));
+  }
+  void bind(dsr_engine *e, uint64_t n) { e_ = e; noTotalTriangles = (uint)n; }
+
+ private:
+  dsr_engine *e_ = nullptr;
+};
+
+template <class TVoxel, class TIndex> class ITMMeshingEngine {
+ public:
+  virtual ~ITMMeshingEngine() {}
+  virtual void MeshScene(ITMMesh *mesh, const ITMScene<TVoxel, TIndex> *scene) {
+    uint64_t n = 0;
+    ITMLib::Engine::dsr_throw(dsr_mesh_scene(scene->e, &n));
+    mesh->bind(scene->e, n);
+  }
+};
+template <class TVoxel, class TIndex> class ITMMeshingEngine_CUDA : public ITMMeshingEngine<TVoxel, TIndex> {
+ public:
+  explicit ITMMeshingEngine_CUDA(long /*maxBlocks*/ = 0) {}
+};
+template <class TVoxel, class TIndex> class ITMMeshingEngine_CPU : public ITMMeshingEngine<TVoxel, TIndex> {
+ public:
+  explicit ITMMeshingEngine_CPU(long /*maxBlocks*/ = 0) {}
+};
+
 // ITMDenseMapper facade (InfiniTamDriver.h:138-145,203,248,283)
 template <class TVoxel, class TIndex> class ITMDenseMapper {
  public:
@@ -377,7 +420,8 @@ class ITMMainEngine {
                                             out ? reinterpret_cast<uint8_t *>(out->GetData(MEMORYDEVICE_CPU)) : nullptr,
                                             outFloat ? outFloat->GetData(MEMORYDEVICE_CPU) : nullptr));
   }
-  void SaveSceneToMesh(const char *) { throw std::runtime_error("meshing is not part of the dsr hot path yet (SURVEY.md 8f rank 4)"); }
+  // ITMMainEngine::SaveSceneToMesh (DynSlam.cpp:188-196)
+  void SaveSceneToMesh(const char *objFileName) { ITMLib::Engine::dsr_throw(dsr_save_scene_to_mesh(engine_, objFileName)); }
 
  protected:
   const ITMLibSettings *settings;

@@ -5,7 +5,8 @@
 // It is the compile/run check of the drop-in boundary (OpenCV/Pangolin/Eigen are not installed,
 // so the cv::Mat conversions of InfiniTamDriver.cpp:81-163 are replaced by raw buffers).
 //
-// usage: example_host W H frames   -> prints counters and an FNV-1a hash of the outputs
+// usage: example_host W H frames [out.obj]   -> prints counters and an FNV-1a hash of the outputs;
+//        with out.obj also meshes the scene the way InstanceReconstructor::SaveObjectToMesh does
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -95,8 +96,18 @@ int main(int argc, char **argv) {
     uint64_t h = fnv(out.GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4);
     h = fnv(outf.GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4, h);
     h = fnv(drv.GetView()->depth->GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4, h);
-    printf("visible=%d used_bytes=%zu saved_bytes=%zu hash=%016llx\n", drv.NoVisibleBlocks(), drv.GetUsedMemoryBytes(),
-           drv.GetSavedDecayMemoryBytes(), (unsigned long long)h);
+    unsigned triangles = 0;
+    if (argc > 4) {  // InstanceReconstructor.cpp:749-757
+      auto *meshing_engine = new ITMMeshingEngine_CUDA<ITMVoxel, ITMVoxelIndex>(settings.sdfLocalBlockNum);
+      ITMMesh *mesh = new ITMMesh(MEMORYDEVICE_CUDA, settings.sdfLocalBlockNum);
+      meshing_engine->MeshScene(mesh, drv.GetScene());
+      mesh->WriteOBJ(argv[4]);
+      triangles = mesh->noTotalTriangles;
+      delete mesh;
+      delete meshing_engine;
+    }
+    printf("visible=%d used_bytes=%zu saved_bytes=%zu hash=%016llx triangles=%u\n", drv.NoVisibleBlocks(), drv.GetUsedMemoryBytes(),
+           drv.GetSavedDecayMemoryBytes(), (unsigned long long)h, triangles);
   } catch (const std::exception &ex) {
     fprintf(stderr, "error: %s\n", ex.what());
     return 1;

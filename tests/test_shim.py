@@ -27,6 +27,7 @@ def test_shim_host_compiles_and_links():
     out = subprocess.check_output(["nm", "-u", exe]).decode()
     used = sorted({l.split()[-1] for l in out.splitlines() if " dsr_" in l or l.strip().startswith("U dsr_")})
     assert "dsr_process_frame" in used and "dsr_get_image" in used and "dsr_decay" in used
+    assert "dsr_mesh_scene" in used and "dsr_mesh_write_obj" in used
 
 
 def fnv(data, h=1469598103934665603):
@@ -36,12 +37,13 @@ def fnv(data, h=1469598103934665603):
 
 
 @pytest.mark.gpu
-def test_shim_host_matches_python_mirror(hip_api):
+def test_shim_host_matches_python_mirror(hip_api, tmp_path):
     from dynslam_amd import _capi
     from dynslam_amd.engine import EngineCore, default_settings, make_calib
     W, H, frames = 96, 64, 3
     exe = build_example()
-    out = subprocess.check_output([exe, str(W), str(H), str(frames)]).decode().strip()
+    obj = tmp_path / "shim.obj"
+    out = subprocess.check_output([exe, str(W), str(H), str(frames), str(obj)]).decode().strip()
     got = dict(kv.split("=") for kv in out.split())
     e = EngineCore(default_settings(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
                                     sdf_local_block_num=20000, hash_bucket_num=0x8000, excess_list_size=0x2000),
@@ -68,3 +70,9 @@ def test_shim_host_matches_python_mirror(hip_api):
     assert int(got["used_bytes"]) == 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id)
     assert int(got["saved_bytes"]) == st.decayed_block_count * 4096
     assert got["hash"] == f"{h:016x}"
+    # ITMMeshingEngine::MeshScene + ITMMesh::WriteOBJ through the shim == the same through the mirror
+    ref = tmp_path / "mirror.obj"
+    tris = e.mesh_scene()
+    e.mesh_write_obj(ref)
+    assert int(got["triangles"]) == len(tris) > 0
+    assert obj.read_bytes() == ref.read_bytes()
