@@ -135,6 +135,7 @@ struct dsr_engine {
   // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
   // env DSR_RAYCAST_SLOTS for further work)
   int raycastSlots = 0;
+  int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
   SceneP scene{};
@@ -344,10 +345,22 @@ int dmalloc(T **p, size_t n) {
   return DSR_OK;
 }
 
-int convert_view(dsr_engine *e) {
+// rgbDev/depthDev != null: device-resident inputs, ingested by one fused kernel
+int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthDev = nullptr) {
   const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
-  LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, e->depth,
-         e->P, a, b);
+  const size_t rgbBytes = (size_t)e->Wr * e->Hr * 4;
+  if (rgbDev && depthDev && ((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0 && (rgbBytes & 15) == 0) {
+    const int nRgbVec = (int)(rgbBytes / 16), nQuads = div_up(e->P, 4);
+    LAUNCH(e, "view_ingest", k_view_ingest, dim3(div_up(std::max(nRgbVec, nQuads), 256)), dim3(256), (const uint4 *)rgbDev,
+           reinterpret_cast<uint4 *>(e->rgb), nRgbVec, (const short *)depthDev, e->depth, e->P, a, b);
+  } else {
+    if (rgbDev) {
+      HIP_TRY(hipMemcpyAsync(e->rgb, rgbDev, rgbBytes, hipMemcpyDeviceToDevice, e->stream));
+      HIP_TRY(hipMemcpyAsync(e->rawDepth, depthDev, (size_t)e->P * 2, hipMemcpyDeviceToDevice, e->stream));
+    }
+    LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, e->depth,
+           e->P, a, b);
+  }
   if (e->s.use_bilateral_filter) {
     // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
     HIP_TRY(hipMemcpyAsync(e->depthTmp, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -417,7 +430,7 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
   if (ldsBytes <= 64 * 1024) {
     // range image privatised in LDS by a few large workgroups (k_raycast.h)
     ProfScope _ps(e, "expected_depth");
-    hipLaunchKernelGGL(k_expected_depth_lds, dim3(64), dim3(1024), ldsBytes, e->stream, p, e->scene,
+    hipLaunchKernelGGL(k_expected_depth_lds, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
                        (const int32_t *)rs.visibleIDs, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
   } else {
     LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int32_t *)rs.visibleIDs,
@@ -596,6 +609,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e->maxSteps = (uint32_t)S;
   }
   if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
+  if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
   if (const char *iv = getenv("DSR_INTEGRATE_VARIANT")) e->integrateVariant = atoi(iv);
@@ -698,9 +712,7 @@ int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm)
 int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev) {
   CHECK_E(e);
   if (!rgba_dev || !depth_mm_dev) return fail(DSR_E_ARG, "null image");
-  HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->rawDepth, depth_mm_dev, (size_t)e->P * 2, hipMemcpyDeviceToDevice, e->stream));
-  return convert_view(e);
+  return convert_view(e, rgba_dev, depth_mm_dev);
 }
 
 int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m) {

@@ -37,6 +37,31 @@ __global__ __launch_bounds__(256) void k_depth_to_float(const short *__restrict_
   }
 }
 
+// UpdateView from device-resident inputs in ONE launch: copy the RGBA frame (16 B per thread) and
+// convert the depth (4 pixels per thread) — two hipMemcpyAsync D2D + a kernel cost ~60 us of
+// launch latency per frame, this one ~5 us.  Both inputs must be 16-byte aligned.
+__global__ __launch_bounds__(256) void k_view_ingest(const uint4 *__restrict__ rgbIn, uint4 *__restrict__ rgbOut, int nRgbVec,
+                                                     const short *__restrict__ depthIn, float *__restrict__ depthOut, int n,
+                                                     float a, float b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nRgbVec) rgbOut[i] = rgbIn[i];
+  const int i4 = i * 4;
+  if (i4 + 3 < n) {
+    short4 d = *reinterpret_cast<const short4 *>(depthIn + i4);
+    float4 o;
+    o.x = (d.x <= 0 || d.x > 32000) ? -1.0f : (float)d.x * a + b;
+    o.y = (d.y <= 0 || d.y > 32000) ? -1.0f : (float)d.y * a + b;
+    o.z = (d.z <= 0 || d.z > 32000) ? -1.0f : (float)d.z * a + b;
+    o.w = (d.w <= 0 || d.w > 32000) ? -1.0f : (float)d.w * a + b;
+    *reinterpret_cast<float4 *>(depthOut + i4) = o;
+  } else {
+    for (int k = i4; k < n; ++k) {
+      short d = depthIn[k];
+      depthOut[k] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
+  }
+}
+
 // ITMViewBuilder.h filterDepth (one bilateral pass); borders keep their old value.
 __global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
   const float MEAN_SIGMA_L = 1.2232f;

@@ -196,8 +196,10 @@ __device__ __forceinline__ bool project_single_block(const short pos[3], const F
     float3 q = mat_mul3(p.M, (float)tx * (float)kBlockSize * p.voxelSize, (float)ty * (float)kBlockSize * p.voxelSize,
                         (float)tz * (float)kBlockSize * p.voxelSize, 1.0f);
     if (q.z < 1e-6f) continue;
-    float px = (p.proj.x * q.x / q.z + p.proj.z) / (float)kMinmaxSubsample;
-    float py = (p.proj.y * q.y / q.z + p.proj.w) / (float)kMinmaxSubsample;
+    // q.z >= 1e-6: tame divisor, the two divisions share the refined reciprocal (dsr_device.h)
+    const float yz = rcp_refined(q.z);
+    float px = (div_with_rcp(p.proj.x * q.x, q.z, yz) + p.proj.z) / (float)kMinmaxSubsample;
+    float py = (div_with_rcp(p.proj.y * q.y, q.z, yz) + p.proj.w) / (float)kMinmaxSubsample;
     if ((float)ul.x > floorf(px)) ul.x = f2i(floorf(px));
     if ((float)lr.x < ceilf(px)) lr.x = f2i(ceilf(px));
     if ((float)ul.y > floorf(py)) ul.y = f2i(floorf(py));

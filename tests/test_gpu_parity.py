@@ -189,3 +189,52 @@ def test_lds_raycast_variant(hip_api, monkeypatch):
     ig, dg = g.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
     io, do = o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
     assert np.array_equal(ig, io) and np.array_equal(dg, do)
+
+
+def test_device_resident_view_equals_host_view(hip_api):
+    """dsr_update_view_dev / dsr_set_view_float_dev (the entry bench.py and the multi-GPU path use: inputs
+    already in HBM) give the same view and the same scene as the host-buffer entry points — through
+    the fused ingest kernel (16-byte aligned inputs) and through the copy fallback (misaligned)."""
+    import torch
+    sc, g, o = make_pair()
+    sc2, g2, _o2 = make_pair()
+    _o2.close()
+    dev = torch.device("cuda", 0)
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        for e in (g, o):
+            e.update_view(rgba, d)
+        if i == 1:  # misaligned device pointers: the copy fallback
+            rb = torch.empty(rgba.size + 16, dtype=torch.uint8, device=dev)
+            db = torch.empty(d.size + 8, dtype=torch.int16, device=dev)
+            r_dev = rb[4:4 + rgba.size]; r_dev.copy_(torch.from_numpy(rgba.reshape(-1)))
+            d_dev = db[1:1 + d.size]; d_dev.copy_(torch.from_numpy(d.reshape(-1)))
+            assert r_dev.data_ptr() % 16 != 0 and d_dev.data_ptr() % 16 != 0
+        else:
+            r_dev, d_dev = torch.from_numpy(rgba).to(dev), torch.from_numpy(d).to(dev)
+        torch.cuda.synchronize()
+        g2.update_view_dev(r_dev.data_ptr(), d_dev.data_ptr())
+        for e in (g, o, g2):
+            e.set_pose_inv_m(T)
+            e.process_frame()
+            e.prepare()
+        vr, vd = g.get_view()
+        vr2, vd2 = g2.get_view()
+        assert np.array_equal(vr, vr2) and np.array_equal(vd.view(np.uint32), vd2.view(np.uint32))
+        assert np.array_equal(vr, rgba)
+    assert_scene_equal(g, o)
+    assert_scene_equal(g2, o)
+    # float view from device memory (instance views: InstanceReconstructor.cpp:580)
+    rgba, d, T, _ = sc.frame(3)
+    depth_m = np.where(d > 0, d.astype(np.float32) * np.float32(0.001), np.float32(-1.0)).astype(np.float32)
+    r_dev, f_dev = torch.from_numpy(rgba).to(dev), torch.from_numpy(depth_m).to(dev)
+    torch.cuda.synchronize()
+    g2.set_view_float_dev(r_dev.data_ptr(), f_dev.data_ptr())
+    for e in (g, o):
+        e.set_view_float(rgba, depth_m)
+    for e in (g, o, g2):
+        e.set_pose_inv_m(T)
+        e.process_frame()
+    assert_scene_equal(g2, o)
+    for e in (g, o, g2):
+        e.close()
