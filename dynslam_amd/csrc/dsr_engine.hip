@@ -349,10 +349,10 @@ int dmalloc(T **p, size_t n) {
 int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthDev = nullptr) {
   const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
   const size_t rgbBytes = (size_t)e->Wr * e->Hr * 4;
-  if (rgbDev && depthDev && ((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0 && (rgbBytes & 15) == 0) {
+  if (rgbDev && depthDev && ((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0) {
     const int nRgbVec = (int)(rgbBytes / 16), nQuads = div_up(e->P, 4);
     LAUNCH(e, "view_ingest", k_view_ingest, dim3(div_up(std::max(nRgbVec, nQuads), 256)), dim3(256), (const uint4 *)rgbDev,
-           reinterpret_cast<uint4 *>(e->rgb), nRgbVec, (const short *)depthDev, e->depth, e->P, a, b);
+           reinterpret_cast<uint4 *>(e->rgb), nRgbVec, e->Wr * e->Hr, (const short *)depthDev, e->depth, e->P, a, b);
   } else {
     if (rgbDev) {
       HIP_TRY(hipMemcpyAsync(e->rgb, rgbDev, rgbBytes, hipMemcpyDeviceToDevice, e->stream));

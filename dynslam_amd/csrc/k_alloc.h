@@ -39,12 +39,14 @@ __global__ __launch_bounds__(256) void k_depth_to_float(const short *__restrict_
 
 // UpdateView from device-resident inputs in ONE launch: copy the RGBA frame (16 B per thread) and
 // convert the depth (4 pixels per thread) — two hipMemcpyAsync D2D + a kernel cost ~60 us of
-// launch latency per frame, this one ~5 us.  Both inputs must be 16-byte aligned.
+// launch latency per frame, this one ~5 us.  Both input pointers must be 16-byte aligned.
 __global__ __launch_bounds__(256) void k_view_ingest(const uint4 *__restrict__ rgbIn, uint4 *__restrict__ rgbOut, int nRgbVec,
-                                                     const short *__restrict__ depthIn, float *__restrict__ depthOut, int n,
-                                                     float a, float b) {
+                                                     int nRgbPixels, const short *__restrict__ depthIn,
+                                                     float *__restrict__ depthOut, int n, float a, float b) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nRgbVec) rgbOut[i] = rgbIn[i];
+  if (i < nRgbPixels - nRgbVec * 4)  // the 0..3 pixels after the last whole 16-byte vector
+    reinterpret_cast<uint32_t *>(rgbOut)[nRgbVec * 4 + i] = reinterpret_cast<const uint32_t *>(rgbIn)[nRgbVec * 4 + i];
   const int i4 = i * 4;
   if (i4 + 3 < n) {
     short4 d = *reinterpret_cast<const short4 *>(depthIn + i4);
