@@ -12,7 +12,7 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $B > $O/write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d $O/inst -o p --output-format csv -- $B > $O/inst.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY -d $O/cyc -o p --output-format csv -- $B > $O/cyc.log 2>&1
-python tools/profile_summary.py stats $O/kt > $O/kernel_stats.json
+python tools/profile_summary.py stats $O/kt 45 > $O/kernel_stats.json
 python tools/profile_summary.py traffic $O/fetch $O/write 45 > $O/pmc_traffic.json
 python tools/profile_summary.py pmc $O/inst $O/cyc > $O/pmc_sq.json
 cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 CSV output into small JSON files for profiles/.
 
-  profile_summary.py stats <dir>            -> per-kernel count / total / average duration
+  profile_summary.py stats <dir> [n]        -> per-kernel count / total / average duration (+ avg of the last n launches)
   profile_summary.py pmc <dir> [<dir> ...]  -> per-kernel mean of every collected counter
   profile_summary.py traffic <fetch_dir> <write_dir> <n>  -> HBM bytes per launch (last n launches)
 
@@ -19,7 +19,10 @@ def short(name):
     return name.split("<")[0].strip()
 
 
-def stats(d):
+def stats(d, last_n=0):
+    """per-kernel calls / total / average from *kernel_stats.csv; with last_n > 0 and a
+    *kernel_trace.csv next to it, also the average over the LAST last_n launches of every kernel
+    (the timed steps of bench.py), which is what bench.py's HIP events measure."""
     out = {}
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -28,6 +31,16 @@ def stats(d):
             o["calls"] += int(r["Calls"]); o["total_ns"] += int(float(r["TotalDurationNs"]))
     for o in out.values():
         o["avg_us"] = round(o["total_ns"] / max(1, o["calls"]) / 1e3, 2)
+    if last_n > 0:
+        rows = defaultdict(list)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                rows[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in rows.items():
+            v.sort()
+            tail = [x[1] for x in v[-last_n:]]
+            if k in out and len(v) >= last_n:
+                out[k]["avg_us_last_%d" % last_n] = round(sum(tail) / len(tail) / 1e3, 2)
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ns"]))
 
 
@@ -77,6 +90,6 @@ if __name__ == "__main__":
     if mode == "traffic":
         res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
     else:
-        res = stats(sys.argv[2]) if mode == "stats" else pmc(sys.argv[2:])
+        res = stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0) if mode == "stats" else pmc(sys.argv[2:])
     json.dump(res, sys.stdout, indent=1)
     print()
