@@ -65,7 +65,7 @@ def make_frames(w, h, n, n_inst=0):
         return pool.map(_gen_frame, [(w, h, i, n_inst) for i in range(n)])
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_d_bench5mm_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_f_bench5mm_pmc_traffic.json")
 
 
 def pmc_traffic(args, kernel):
