@@ -130,7 +130,7 @@ struct dsr_engine {
   int gridIntegrate = 8192;
   // k_integrate variant = voxels per lane x waves per SIMD.  48 (half block per wave, 62 VGPRs,
   // 8 waves/SIMD): 757 us at the 5 mm bench; 85 (whole block per wave, 94 VGPRs, 5 waves): 797 us.
-  int integrateVariant = 48;
+  int integrateVariant = 87;
   // 0 = per-lane raycast (default, 0.66 ms at the 5 mm bench); 2/4/8 = experimental wave-cooperative
   // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
   // env DSR_RAYCAST_SLOTS for further work)
@@ -414,7 +414,9 @@ int integrate_scene(dsr_engine *e) {
   switch (e->integrateVariant) {  // voxels per lane x waves per SIMD (env DSR_INTEGRATE_VARIANT)
     case 48: LAUNCH_INTEGRATE_V(4, 8); break;
     case 46: LAUNCH_INTEGRATE_V(4, 6); break;
-    default: LAUNCH_INTEGRATE_V(8, 5); break;
+    case 86: LAUNCH_INTEGRATE_V(8, 6); break;
+    case 85: LAUNCH_INTEGRATE_V(8, 5); break;
+    default: LAUNCH_INTEGRATE_V(8, 7); break;
   }
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE

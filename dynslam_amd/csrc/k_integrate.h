@@ -11,9 +11,10 @@
 //     consumed.  A task none of whose voxels passes the depth tests ends right after it.
 //   * PHASE A2 (depth): branch-free SDF running mean.  Voxels that also pass the colour gate
 //     (|eta/mu| <= 0.25: a thin sheet, ~2 % of the visible voxels) are appended to a per-wave LDS
-//     list {block, voxel} (wave64 ballot + prefix popcount) that PERSISTS ACROSS TASKS.
+//     list {task, voxel} — one word per voxel — (wave64 ballot + prefix popcount) that PERSISTS
+//     ACROSS TASKS.
 //   * PHASE B (colour): whenever the list holds 64 voxels the wave updates them DENSELY, one per
-//     lane: re-projects the voxel, gathers its 4 B colour + 1 B weight, bilinear RGB sample,
+//     lane: re-reads the voxel's hash entry, re-projects it, gathers its 4 B colour + 1 B weight, bilinear RGB sample,
 //     running mean, scatter back.  The divergent colour branch of the per-voxel formulation (every
 //     lane paying ~150 instructions for the few that need it, once per task) is paid once per 64
 //     colour voxels instead, and the colour planes of untouched voxels are never read.
@@ -31,6 +32,8 @@
 // Arithmetic follows ITMSceneReconstructionEngine.h computeUpdatedVoxelDepthInfo /
 // computeUpdatedVoxelColorInfo / ComputeUpdatedVoxelInfo<true> expression by expression.
 #pragma once
+#include <type_traits>
+
 #include "dsr_device.h"
 
 namespace dsr {
@@ -103,9 +106,10 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
                                                                          const int32_t *__restrict__ visibleIDs) {
   constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
   constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
-  // per wave: the voxels waiting for their colour update {block ptr, block pos x|y, pos z | voxel}
+  // per wave: the voxels waiting for their colour update, one word each:
+  // (number of the task among this wave's tasks) << 9 | voxel index in the block
   constexpr int kPendCap = 64 + kVoxPerTask;
-  __shared__ uint32_t s_pend[kIntegrateWaves][3][kPendCap];
+  __shared__ uint32_t s_pend[kIntegrateWaves][kPendCap];
   __shared__ float s_rcpW[257];  // RN(1/w), w = 1..256 (`/` is the correctly rounded division)
   for (int i = threadIdx.x; i < 257; i += 64 * kIntegrateWaves) s_rcpW[i] = 1.0f / (float)(i > 0 ? i : 1);
   __syncthreads();
@@ -121,7 +125,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
-  uint32_t *pendPtr = s_pend[wave][0], *pendXY = s_pend[wave][1], *pendZV = s_pend[wave][2];
+  uint32_t *pend = s_pend[wave];
+  const int t0 = blockIdx.x * kIntegrateWaves + wave;  // this wave's first task; its k-th is t0 + k * stride
 
   // reciprocals of the constant divisors (uniform): correctly rounded for div_short, the refined
   // hardware reciprocal for the two-correction form
@@ -133,7 +138,6 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
-  const unsigned long long laneMaskLt = (1ull << lane) - 1ull;
 
   // ------------------------------------------------------------ colour pass
   // computeUpdatedVoxelColorInfo for `cnt` (<= 64) pending voxels starting at list position `base`,
@@ -148,10 +152,12 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < cnt) {
-      const int i = base + lane;
-      const uint32_t bptr = pendPtr[i], pxy = pendXY[i], pzv = pendZV[i];
-      const int vox = (int)(pzv >> 16);
-      const int bx = (short)(pxy & 0xffffu), by = (short)(pxy >> 16), bz = (short)(pzv & 0xffffu);
+      const uint32_t w = pend[base + lane];
+      const int vox = (int)(w & 511u);
+      const int tt = t0 + (int)(w >> 9) * stride;
+      const dsr_hash_entry hc = load_entry(s.table, (uint32_t)visibleIDs[tt / kTasksPerBlock]);
+      const uint32_t bptr = (uint32_t)hc.ptr;
+      const int bx = hc.pos[0], by = hc.pos[1], bz = hc.pos[2];
       const float mx = (float)(bx * kBlockSize + (vox & 7)) * p.voxelSize;
       const float my = (float)(by * kBlockSize + ((vox >> 3) & 7)) * p.voxelSize;
       const float mz = (float)(bz * kBlockSize + (vox >> 6)) * p.voxelSize;
@@ -197,7 +203,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   // software pipeline over this wave's tasks: entries two ahead, voxel planes one ahead
   const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
   int nPend = 0;  // wave-uniform length of the pending colour list (< 64 between tasks)
-  int t = blockIdx.x * kIntegrateWaves + wave;
+  int t = t0;
+  int taskNo = 0;  // t == t0 + taskNo * stride
   dsr_hash_entry heCur = (t < noTasks) ? task_entry(t) : kNone;
   dsr_hash_entry heNext = (t + stride < noTasks) ? task_entry(t + stride) : kNone;
   LanePlanes<VOX> planesNext;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   for (int k = 0; k < VOX / 4; ++k) planesNext.wd[k] = 0;
   if (heCur.ptr >= 0) planesNext = load_planes<VOX>(s.vba + (size_t)heCur.ptr * kBlockBytes, task_vox0(t));
 
-  for (; t < noTasks; t += stride) {
+  for (; t < noTasks; t += stride, ++taskNo) {
     const dsr_hash_entry he = heCur;
     const dsr_hash_entry heAfter = (t + 2 * stride < noTasks) ? task_entry(t + 2 * stride) : kNone;
     LanePlanes<VOX> pl = planesNext;
@@ -274,44 +281,46 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
     // ---------------------------------------------- phase A2: SDF running mean, colour gate
     bool dirtyDepth = false;
-    const uint32_t posXY = (uint32_t)(uint16_t)he.pos[0] | ((uint32_t)(uint16_t)he.pos[1] << 16);
-    const uint32_t posZ = (uint32_t)(uint16_t)he.pos[2];
+    const uint32_t pendWord0 = ((uint32_t)taskNo << 9) | (uint32_t)vox0;
+    // REJ: voxels the depth step rejected pass the colour gate too (only for mu >= 4 m); a
+    // compile-time flag of the loop so that the usual case carries no trace of it
+    auto phaseA2 = [&](auto rejTag) {
+      constexpr bool REJ = decltype(rejTag)::value;
 #pragma unroll
-    for (int x = 0; x < VOX; ++x) {
-      const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
-      const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
-      const bool skip = stopAtMaxW && wDepth == p.maxW;
-      const bool okx = !skip && ok[x];
-      const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
-      const bool upd = okx && !(eta[x] < -p.mu);
-      const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
-                               : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
-      float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
-      int newW = depthWeighting ? depth_weight(okx ? dm[x] : 1.0f) : 1;
-      newF = (float)wDepth * oldF + (float)newW * newF;
-      newW = wDepth + newW;
-      newF = PLAIN ? div_short(newF, (float)newW, s_rcpW[newW]) : fdiv_tame(newF, (float)newW);
-      newW = newW < p.maxW ? newW : p.maxW;
-      const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
-      const uint32_t sw = (pl.sdf[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
-      const uint32_t ww = (pl.wd[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
-      pl.sdf[x >> 1] = upd ? sw : pl.sdf[x >> 1];
-      pl.wd[x >> 2] = upd ? ww : pl.wd[x >> 2];
-      dirtyDepth |= upd;
-      // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
-      //      voxels the depth step rejected carry eta = -1
-      const bool gateOk = !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
-      const bool gate = !skip && ((ok[x] && gateOk) || (!ok[x] && rejectedPassGate));
-      // append to the wave's pending colour list (ordered compaction across the 64 lanes)
-      const unsigned long long m = __ballot(gate);
-      if (gate) {
-        const int slot = nPend + __popcll(m & laneMaskLt);
-        pendPtr[slot] = (uint32_t)he.ptr;
-        pendXY[slot] = posXY;
-        pendZV[slot] = posZ | ((uint32_t)(vox0 + x) << 16);
+      for (int x = 0; x < VOX; ++x) {
+        const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
+        const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
+        const bool skip = stopAtMaxW && wDepth == p.maxW;
+        const bool okx = !skip && ok[x];
+        const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
+        const bool upd = okx && !(eta[x] < -p.mu);
+        const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
+                                 : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
+        float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
+        int newW = depthWeighting ? depth_weight(okx ? dm[x] : 1.0f) : 1;
+        newF = (float)wDepth * oldF + (float)newW * newF;
+        newW = wDepth + newW;
+        newF = PLAIN ? div_short(newF, (float)newW, s_rcpW[newW]) : fdiv_tame(newF, (float)newW);
+        newW = newW < p.maxW ? newW : p.maxW;
+        const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
+        const uint32_t sw = (pl.sdf[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
+        const uint32_t ww = (pl.wd[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));
+        pl.sdf[x >> 1] = upd ? sw : pl.sdf[x >> 1];
+        pl.wd[x >> 2] = upd ? ww : pl.wd[x >> 2];
+        dirtyDepth |= upd;
+        // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
+        //      voxels the depth step rejected carry eta = -1
+        const bool gateOk = !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
+        const bool gate = REJ ? (!skip && (ok[x] ? gateOk : true)) : (okx && gateOk);
+        // append to the wave's pending colour list (ordered compaction across the 64 lanes)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
+        if (gate)  // slot = number of gated lanes below this one (v_mbcnt)
+          pend[nPend + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pendWord0 + (uint32_t)x;
+        nPend += __popcll(m);
       }
-      nPend += __popcll(m);
-    }
+    };
+    if (rejectedPassGate) phaseA2(std::true_type{});
+    else phaseA2(std::false_type{});
 
     if (dirtyDepth) store_planes<VOX>(blk, vox0, pl);
 
