@@ -404,7 +404,8 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         // (measured and rejected: a second look-ahead slot during runs of misses, 580 us vs 515 us;
         //  four bucket heads at once after 8 misses in a row, 631 us; a fire-and-forget prefetch
         //  of the head 3..10 miss steps ahead into an LDS sink, 560 us; parking lanes that need a
-        //  trilinear sample until 1..48 of them can take it together, 607..896 us.  Every variant
+        //  trilinear sample until 1..48 of them can take it together, 607..896 us; giving each XCD a
+        //  band of tile columns (workgroup i -> XCD i % 8), 533 vs 512 us.  Every variant
         //  that adds requests or iterations loses: the march is bound by gather-request
         //  throughput and by the per-wave chain of dependent round trips.)
       }
