@@ -81,6 +81,9 @@ def run_case(make_engine, case):
                     ("weight", _capi.IMAGE_FREECAMERA_COLOUR_FROM_DEPTH_WEIGHT)):
         out["render_" + name] = _h(e.get_image(t, pose_m=pose)[0])
     out["render_depth"] = _h(e.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=pose, want_rgba=False, want_depth=True)[1])
+    mesh = e.mesh_scene()  # ITMMeshingEngine::MeshScene: triangle order is part of the digest
+    out["mesh_triangles"] = int(len(mesh))
+    out["mesh"] = _h(mesh)
     e.close()
     return out
 
