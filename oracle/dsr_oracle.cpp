@@ -602,7 +602,7 @@ static void integrate_into_scene(Engine &e) {
     if (he.ptr < 0) continue;
     V3i globalPos = {he.pos[0] * DSR_BLOCK_SIZE, he.pos[1] * DSR_BLOCK_SIZE, he.pos[2] * DSR_BLOCK_SIZE};
     dsr_voxel *localVoxelBlock = &e.voxels[(size_t)he.ptr * DSR_BLOCK_SIZE3];
-    long long nUpd = 0, nClr = 0; unsigned sliceMask = 0;
+    long long nUpd = 0, nClr = 0; unsigned sliceMask = 0, xMask = 0, yMask = 0;
     for (int z = 0; z < DSR_BLOCK_SIZE; z++)
       for (int y = 0; y < DSR_BLOCK_SIZE; y++)
         for (int x = 0; x < DSR_BLOCK_SIZE; x++) {
@@ -618,7 +618,7 @@ static void integrate_into_scene(Engine &e) {
           const dsr_voxel before = voxel;
           float eta = computeUpdatedVoxelDepthInfo(voxel, pt_model, M_d, projParams_d, mu, maxW, e.depth.data(),
                                                    e.W, e.H, e.depthWeighting);
-          if (g_int_stats_on && (eta != -1 && !(eta < -mu))) { nUpd++; sliceMask |= 1u << z; }
+          if (g_int_stats_on && (eta != -1 && !(eta < -mu))) { nUpd++; sliceMask |= 1u << z; xMask |= 1u << x; yMask |= 1u << y; }
           (void)before;
           if ((eta > mu) || (fabsf(eta / mu) > 0.25f)) continue;
           computeUpdatedVoxelColorInfo(voxel, pt_model, M_rgb, projParams_rgb, maxW, e.rgb.data(), e.Wr, e.Hr);
@@ -631,6 +631,7 @@ static void integrate_into_scene(Engine &e) {
         g_int_stats[3] += ((sliceMask & 0x0f) != 0) + ((sliceMask & 0xf0) != 0);
         g_int_stats[4] += __builtin_popcount(sliceMask);
         g_int_stats[5] += sliceMask != 0;
+        g_int_stats[6] += __builtin_popcount(xMask); g_int_stats[7] += __builtin_popcount(yMask);
       }
     }
   }
