@@ -48,6 +48,8 @@ enum Ctr {
   CTR_TMP_OLD_NVIS = 11,      // live visible count before the post-decay compaction
   CTR_SWAP_COUNT = 12,        // blocks in the running swap-in / swap-out transfer
   CTR_MESH_TOTAL = 13,        // triangles of the running MeshScene
+  CTR_HOST_USED = 14,         // slots of the host store (ITMGlobalCache) handed out so far
+  CTR_SWAP_FIRST_SLOT = 15,   // first host slot of the running swap-out batch
   CTR_COUNT = 16
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)
@@ -89,6 +91,9 @@ struct SceneP {
   unsigned long long *allocTile;  // per sweep tile: marked entries (low 32 bits) | excess-list ones (high)
   uint8_t *swapState;     // ITMHashSwapState::state per entry (null unless use_swapping)
   uint8_t *swapStored;    // 1 = the host store (ITMGlobalCache) holds a copy of this entry's block
+  int32_t *swapSlot;      // ... in this slot of it (most recent copy)
+  uint8_t **hostSlabs;    // device-visible table of the pinned host slabs (slabBlocks blocks each)
+  int slabBlocks;
 };
 
 // ------------------------------------------------------------------ conversions

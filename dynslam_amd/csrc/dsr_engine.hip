@@ -167,14 +167,17 @@ struct dsr_engine {
   int fifoCap = 0, fifoHead = 0, fifoLen = 0;
   int32_t *decayCand = nullptr;      // forceAll candidate list
   // host swapping (use_swapping): ITMGlobalCache = host store of plane-wise 4 KiB blocks
-  uint8_t *swapStagingDev = nullptr, *swapStagingHost = nullptr;  // 16 MiB each (host one pinned)
+  uint8_t *swapStagingDev = nullptr;             // 16 MiB: fetched host copies of a swap-in batch
   int32_t *swapIdsDev = nullptr;
   uint8_t *swapFlagsDev = nullptr;
-  std::vector<uint8_t *> hostSlabs;              // pinned, kTransferBlocks blocks each
-  int hostSlabUsed = 0;                          // slots used in the last slab
-  std::unordered_map<int, long long> hostSlot;   // entry -> slot of its most recent copy
-  std::vector<int32_t> swapIdsHost;
-  std::vector<uint8_t> swapFlagsHost;
+  // host store (ITMGlobalCache): pinned slabs the GPU reads and writes directly (k_swap.h)
+  std::vector<uint8_t *> hostSlabs;              // e->scene.slabBlocks blocks each; also listed in scene.hostSlabs
+  static constexpr int kMaxHostSlabs = 4096;     // 256 GiB of host store
+  long long hostUsedUpper = 0;                   // upper bound of CTR_HOST_USED after the enqueued frames
+  int32_t *hostUsedSeen = nullptr;               // pinned: asynchronous read-back of CTR_HOST_USED
+  hipEvent_t hostUsedEvent = nullptr;
+  bool hostUsedPending = false;
+  long long hostUsedCallsSince = 0;              // swap-out batches enqueued since that read-back was issued
   // silhouette masks (instance view split)
   uint8_t *maskScratch = nullptr;
   size_t maskCap = 0;
@@ -280,9 +283,8 @@ int reset_scene(dsr_engine *e) {
     HIP_TRY(hipMemsetAsync(e->scene.swapState, 0, (size_t)e->E, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.swapStored, 0, (size_t)e->E, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    e->hostSlot.clear();
-    for (auto p : e->hostSlabs) (void)hipHostFree(p);
-    e->hostSlabs.clear(); e->hostSlabUsed = 0;
+    // the slabs are kept; the slot counter restarts with the counters
+    e->hostUsedUpper = 0; e->hostUsedPending = false; e->hostUsedCallsSince = 0;
   }
   HIP_TRY(hipMemsetAsync(e->live.visType, 0, (size_t)e->E, e->stream));
   HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
@@ -305,7 +307,9 @@ void free_all(dsr_engine *e) {
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
   F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
-  if (e->swapStagingHost) (void)hipHostFree(e->swapStagingHost);
+  F(e->scene.swapSlot); F(e->scene.hostSlabs);
+  if (e->hostUsedSeen) (void)hipHostFree(e->hostUsedSeen);
+  if (e->hostUsedEvent) (void)hipEventDestroy(e->hostUsedEvent);
   for (auto p : e->hostSlabs) (void)hipHostFree(p);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -490,15 +494,29 @@ int ensure_fifo(dsr_engine *e, int slotsNeeded) {
   return DSR_OK;
 }
 
-// Host store (ITMGlobalCache): pinned slabs of kTransferBlocks plane-wise 4 KiB blocks.  A swap-out
-// batch is written straight into a slab by one asynchronous D2H copy (no per-block host work);
-// hostSlot maps a hash entry to its most recent copy (older copies of a re-swapped entry are
-// simply abandoned until the next reset).
+// Host store (ITMGlobalCache): a pool of pinned slabs that the swap kernels address directly
+// (k_swap.h).  The host's only job is to keep the pool ahead of the device's slot counter: it
+// tracks an upper bound of the counter (every swap-out batch takes at most kTransferBlocks
+// slots), tightened by an asynchronous read-back that is never waited for, and adds a slab when
+// the bound comes within one batch of the capacity.
 uint8_t *host_slot_ptr(dsr_engine *e, long long slot) {
-  return e->hostSlabs[(size_t)(slot / kTransferBlocks)] + (size_t)(slot % kTransferBlocks) * kBlockBytes;
+  return e->hostSlabs[(size_t)(slot / e->scene.slabBlocks)] + (size_t)(slot % e->scene.slabBlocks) * kBlockBytes;
 }
 
-// ITMSwappingEngine::IntegrateGlobalIntoLocal: host store -> staging -> merge into local blocks
+int add_host_slab(dsr_engine *e) {
+  if ((int)e->hostSlabs.size() >= dsr_engine::kMaxHostSlabs) return fail(DSR_E_NOMEM, "host store is full");
+  uint8_t *slab = nullptr;
+  if (hipHostMalloc(reinterpret_cast<void **>(&slab), (size_t)e->scene.slabBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess)
+    return fail(DSR_E_NOMEM, "host store slab allocation failed");
+  e->hostSlabs.push_back(slab);
+  // publish the pointer to the kernels (ordered on the stream before the next swap kernels)
+  HIP_TRY(hipMemcpyAsync(e->scene.hostSlabs + (e->hostSlabs.size() - 1), &e->hostSlabs.back(), sizeof(uint8_t *),
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the source of that copy is this vector's storage
+  return DSR_OK;
+}
+
+// ITMSwappingEngine::IntegrateGlobalIntoLocal: host store -> staging -> combine into the local blocks
 int swap_in(dsr_engine *e) {
   LAUNCH(e, "swap_list", (k_swap_count<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
          (const uint8_t *)e->live.visType, e->tileSums);
@@ -506,56 +524,42 @@ int swap_in(dsr_engine *e) {
          (int)kTransferBlocks);
   LAUNCH(e, "swap_list", (k_swap_write<false>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
          (const uint8_t *)e->live.visType, (const int2 *)e->tileSums, e->swapIdsDev, e->swapFlagsDev);
-  // one round trip: count, ids and flags together (this also drains the previous frame's
-  // asynchronous swap-out copy, so the slabs read below are complete)
-  int32_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->swapIdsHost.data(), e->swapIdsDev, (size_t)kTransferBlocks * 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->swapFlagsHost.data(), e->swapFlagsDev, (size_t)kTransferBlocks, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (n <= 0) return DSR_OK;
-  bool any = false;
-  for (int i = 0; i < n; ++i) {
-    if (!e->swapFlagsHost[i]) continue;
-    auto it = e->hostSlot.find(e->swapIdsHost[i]);
-    if (it == e->hostSlot.end()) return fail(DSR_E_DEVICE, "swap-in: device says the host store holds a block it does not hold");
-    memcpy(e->swapStagingHost + (size_t)i * kBlockBytes, host_slot_ptr(e, it->second), kBlockBytes);
-    any = true;
-  }
-  if (any) HIP_TRY(hipMemcpyAsync(e->swapStagingDev, e->swapStagingHost, (size_t)n * kBlockBytes, hipMemcpyHostToDevice, e->stream));
-  LAUNCH(e, "swapin_combine", k_swapin_combine, dim3(std::min(1024, div_up(n, 4))), dim3(256), e->scene, (int)e->s.max_w,
+  LAUNCH(e, "swapin_fetch", k_swapin_fetch, dim3(1024), dim3(256), e->scene, (const int32_t *)e->swapIdsDev,
+         (const uint8_t *)e->swapFlagsDev, e->swapStagingDev);
+  LAUNCH(e, "swapin_combine", k_swapin_combine, dim3(1024), dim3(256), e->scene, (int)e->s.max_w,
          (const int32_t *)e->swapIdsDev, (const uint8_t *)e->swapFlagsDev, (const uint8_t *)e->swapStagingDev);
   HIP_TRY(hipGetLastError());
-  return DSR_OK;  // no sync: the pinned staging buffer is next touched after the next frame's round trip
+  return DSR_OK;
 }
 
-// ITMSwappingEngine::SaveToGlobalMemory: invisible resident blocks -> staging -> host store
+// ITMSwappingEngine::SaveToGlobalMemory: invisible resident blocks -> host store
 int swap_out(dsr_engine *e) {
+  // tighten the bound with the last read-back, if it has arrived
+  if (e->hostUsedPending && hipEventQuery(e->hostUsedEvent) == hipSuccess) {
+    e->hostUsedUpper = std::min(e->hostUsedUpper, (long long)*e->hostUsedSeen + e->hostUsedCallsSince * kTransferBlocks);
+    e->hostUsedPending = false;
+  }
+  while ((long long)e->hostSlabs.size() * e->scene.slabBlocks < e->hostUsedUpper + kTransferBlocks) {
+    int st = add_host_slab(e);
+    if (st) return st;
+  }
   LAUNCH(e, "swap_list", (k_swap_count<true>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
          (const uint8_t *)e->live.visType, e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_SWAP_OUT,
          (int)kTransferBlocks);
   LAUNCH(e, "swap_list", (k_swap_write<true>), dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
          (const uint8_t *)e->live.visType, (const int2 *)e->tileSums, e->swapIdsDev, e->swapFlagsDev);
-  LAUNCH(e, "swapout_move", k_swapout_move, dim3(1024), dim3(256), e->scene, (const int32_t *)e->swapIdsDev, e->swapStagingDev);
-  int32_t n = 0;
-  HIP_TRY(hipMemcpyAsync(&n, e->scene.ctr + CTR_SWAP_COUNT, 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->swapIdsHost.data(), e->swapIdsDev, (size_t)kTransferBlocks * 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (n <= 0) return DSR_OK;
-  // room for n contiguous slots: the tail of the current slab or a fresh one
-  if (e->hostSlabs.empty() || e->hostSlabUsed + n > kTransferBlocks) {
-    uint8_t *slab = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&slab), (size_t)kTransferBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess)
-      return fail(DSR_E_NOMEM, "host store slab allocation failed");
-    e->hostSlabs.push_back(slab);
-    e->hostSlabUsed = 0;
+  LAUNCH(e, "swapout_move", k_swapout_move, dim3(1024), dim3(256), e->scene, (const int32_t *)e->swapIdsDev);
+  e->hostUsedUpper += kTransferBlocks;
+  e->hostUsedCallsSince++;
+  if (!e->hostUsedPending) {  // ask for the counter; the answer is picked up by a later frame
+    HIP_TRY(hipMemcpyAsync(e->hostUsedSeen, e->scene.ctr + CTR_HOST_USED, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(e->hostUsedEvent, e->stream));
+    e->hostUsedPending = true;
+    e->hostUsedCallsSince = 0;
   }
-  const long long firstSlot = (long long)(e->hostSlabs.size() - 1) * kTransferBlocks + e->hostSlabUsed;
-  HIP_TRY(hipMemcpyAsync(host_slot_ptr(e, firstSlot), e->swapStagingDev, (size_t)n * kBlockBytes, hipMemcpyDeviceToHost, e->stream));
-  for (int i = 0; i < n; ++i) e->hostSlot[e->swapIdsHost[i]] = firstSlot + i;
-  e->hostSlabUsed += n;
-  return DSR_OK;  // asynchronous: ordered before any later use by the stream
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
 }
 
 }  // namespace
@@ -659,10 +663,15 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     ALLOC(dmalloc(&e->swapStagingDev, (size_t)kTransferBlocks * kBlockBytes));
     ALLOC(dmalloc(&e->swapIdsDev, (size_t)kTransferBlocks));
     ALLOC(dmalloc(&e->swapFlagsDev, (size_t)kTransferBlocks));
-    e->swapIdsHost.assign(kTransferBlocks, 0); e->swapFlagsHost.assign(kTransferBlocks, 0);
-    if (hipHostMalloc(reinterpret_cast<void **>(&e->swapStagingHost), (size_t)kTransferBlocks * kBlockBytes, hipHostMallocDefault) != hipSuccess) {
-      free_all(e); delete e; return fail(DSR_E_NOMEM, "pinned staging buffer allocation failed");
+    ALLOC(dmalloc(&e->scene.swapSlot, (size_t)e->E));
+    ALLOC(dmalloc(&e->scene.hostSlabs, (size_t)dsr_engine::kMaxHostSlabs));
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->hostUsedSeen), 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&e->hostUsedEvent, hipEventDisableTiming) != hipSuccess) {
+      free_all(e); delete e; return fail(DSR_E_NOMEM, "host store bookkeeping allocation failed");
     }
+    e->scene.slabBlocks = kSlabBlocksDefault;
+    if (const char *sb = getenv("DSR_SLAB_BLOCKS")) e->scene.slabBlocks = std::max(1, atoi(sb));  // tests: force slab growth
+    ALLOC(add_host_slab(e));  // the first slab, so that the first frames never wait for one
   }
   ALLOC(short_division_exact(e->stream, s.mu, &e->shortDivMuExact));
   // clear image-sized buffers once so that dumps before the first frame are defined
@@ -1104,12 +1113,13 @@ int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present
   uint8_t flag = 0;
   HIP_TRY(hipMemcpy(&flag, e->scene.swapStored + entry, 1, hipMemcpyDeviceToHost));
   if (!flag) return DSR_OK;
-  auto it = e->hostSlot.find(entry);
-  if (it == e->hostSlot.end()) return fail(DSR_E_DEVICE, "host store inconsistent");
-  HIP_TRY(hipStreamSynchronize(e->stream));  // the swap-out copy is asynchronous
+  HIP_TRY(hipStreamSynchronize(e->stream));  // the swap-out kernels write the host store asynchronously
+  int32_t slot = -1;
+  HIP_TRY(hipMemcpy(&slot, e->scene.swapSlot + entry, 4, hipMemcpyDeviceToHost));
+  if (slot < 0 || slot >= (long long)e->hostSlabs.size() * e->scene.slabBlocks) return fail(DSR_E_DEVICE, "host store inconsistent");
   *present = 1;
   if (out) {
-    const uint8_t *b = host_slot_ptr(e, it->second);
+    const uint8_t *b = host_slot_ptr(e, slot);
     for (int v = 0; v < kBlockSize3; ++v) {
       dsr_voxel o; memset(&o, 0, sizeof o);
       memcpy(&o.sdf, b + kOffSdf + v * 2, 2);

@@ -227,6 +227,8 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
       if (mode == SCAN_SWAP_OUT) {
         ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];
         ctr[CTR_LAST_FREE_BLOCK] += n;
+        ctr[CTR_SWAP_FIRST_SLOT] = ctr[CTR_HOST_USED];  // the batch takes the next n host slots, in list order
+        ctr[CTR_HOST_USED] += n;
       }
     } else if (mode == SCAN_MESH) {
       ctr[CTR_MESH_TOTAL] = carry.x;

@@ -10,14 +10,25 @@
 //            state 2, resident and not visible are copied to the host store, their block is
 //            reset and returned to the free list IN ENTRY ORDER, ptr = -1, state 0.
 // Both candidate lists are ordered compactions with a cap (tile counts -> scan -> write), so the
-// free-list order equals the serial loop's.  Blocks travel through one 16 MiB pinned staging
-// buffer in the engine's plane-wise 4 KiB layout (no AoS conversion on the way).
+// free-list order equals the serial loop's.
+//
+// The host store is a pool of PINNED host slabs (16384 plane-wise 4 KiB blocks each by default) that the
+// GPU addresses directly: swap-out kernels write blocks into it over the host link, swap-in
+// kernels read them back, slots are handed out by a device counter in list order and remembered
+// per entry (swapSlot).  The host never learns the lists: no round trip, no synchronisation —
+// ITMDenseMapper::ProcessFrame stays asynchronous with swapping on.  (Upstream copies counts and
+// id lists to the host and memcpys every block through a staging buffer each frame.)
 #pragma once
 #include "dsr_device.h"
 
 namespace dsr {
 
 constexpr int kTransferBlocks = DSR_TRANSFER_BLOCK_NUM;  // SDF_TRANSFER_BLOCK_NUM
+constexpr int kSlabBlocksDefault = 16384;                 // 64 MiB of pinned host memory per slab
+
+__device__ __forceinline__ uint8_t *host_block(const SceneP &s, int slot) {
+  return s.hostSlabs[slot / s.slabBlocks] + (size_t)(slot % s.slabBlocks) * kBlockBytes;
+}
 
 template <bool OUT>
 __device__ __forceinline__ bool swap_candidate(const SceneP &s, int t, const uint8_t *__restrict__ visType) {
@@ -67,6 +78,23 @@ __global__ __launch_bounds__(kTileThreads) void k_swap_write(SceneP s, int noTot
       }
       rank++;
     }
+}
+
+// swap-in, step 1: the stored copies of the listed entries, host store -> device staging buffer
+// (16 B per lane, coalesced over the host link; one wave per block)
+__global__ __launch_bounds__(256) void k_swapin_fetch(SceneP s, const int32_t *__restrict__ ids,
+                                                      const uint8_t *__restrict__ storedFlags, uint8_t *__restrict__ staging) {
+  const int n = s.ctr[CTR_SWAP_COUNT];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+    if (!storedFlags[i]) continue;
+    const int id = __builtin_amdgcn_readfirstlane(ids[i]);
+    const uint4 *src = reinterpret_cast<const uint4 *>(host_block(s, s.swapSlot[id]));
+    uint4 *dst = reinterpret_cast<uint4 *>(staging + (size_t)i * kBlockBytes);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k * 64 + lane] = src[k * 64 + lane];
+  }
 }
 
 // ITMSwappingEngine.h combineVoxelDepthInformation / combineVoxelColorInformation on the plane-wise
@@ -127,11 +155,11 @@ __global__ __launch_bounds__(256) void k_swapin_combine(SceneP s, int maxW, cons
   }
 }
 
-// copy the block to the staging buffer, reset it, return it to the free list (list order = entry
+// copy the block into its host slot, reset it, return it to the free list (list order = entry
 // order: slot oldHead + 1 + i), ptr = -1, state 0, mark the host store as holding it
-__global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *__restrict__ ids,
-                                                      uint8_t *__restrict__ staging) {
+__global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *__restrict__ ids) {
   const int n = s.ctr[CTR_SWAP_COUNT];
+  const int firstSlot = s.ctr[CTR_SWAP_FIRST_SLOT];
   const int oldHead = s.ctr[CTR_ALLOC_OLD_HEAD_VBA];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -141,7 +169,7 @@ __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *_
     const int id = __builtin_amdgcn_readfirstlane(ids[i]);
     const int ptr = s.table[id].ptr;
     uint4 *blk = reinterpret_cast<uint4 *>(s.vba + (size_t)ptr * kBlockBytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(staging + (size_t)i * kBlockBytes);
+    uint4 *dst = reinterpret_cast<uint4 *>(host_block(s, firstSlot + i));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // 256 x 16 B per block
       const int v = k * 64 + lane;
@@ -153,6 +181,7 @@ __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *_
       s.table[id].ptr = -1;
       s.swapState[id] = 0;
       s.swapStored[id] = 1;
+      s.swapSlot[id] = firstSlot + i;
     }
   }
 }

@@ -134,3 +134,29 @@ def test_gpu_swapping_transfer_cap(hip_api, oracle_lib):
     inc = np.diff(counts)
     assert inc[0] == 4096 and (inc <= 4096).all() and inc[-1] == 0, counts
     assert_scene_equal(g, o)
+
+
+@pytest.mark.gpu
+def test_gpu_host_store_grows_slab_by_slab(hip_api, oracle_lib, monkeypatch):
+    """The host store is a pool of pinned slabs the kernels address directly; with tiny slabs
+    (64 blocks) the batches straddle slab boundaries, the pool has to grow ahead of the device's
+    slot counter without ever reading it synchronously, and every stored block must still come
+    back identical — after a reset as well (the slot counter restarts, the slabs are reused)."""
+    from tests.common import assert_scene_equal
+    monkeypatch.setenv("DSR_SLAB_BLOCKS", "64")
+    sc, g = hip_engine()
+    sc, o = oracle_engine()
+    for rnd in range(2):
+        for i in SEQ:
+            for e in (g, o):
+                step(e, sc, i)
+        assert_scene_equal(g, o)
+        st, hs = o.dump_swap_state()
+        sg = g.dump_swap_state()
+        assert np.array_equal(sg[0], st) and np.array_equal(sg[1], hs)
+        assert hs.sum() > 1000  # > 15 slabs of 64 blocks
+        for t in np.nonzero(hs)[0][::53].tolist():
+            assert np.array_equal(g.dump_stored_block(t), o.dump_stored_block(t))
+        for e in (g, o):
+            e.reset_scene()
+    g.close(); o.close()
