@@ -141,6 +141,7 @@ def main():
                     help="bracket every kernel with HIP events (default: integrate and raycast only; the events "
                          "of a full profile cost ~9 %% of the frame)")
     ap.add_argument("--decay", action="store_true", help="also run voxel GC each frame (min_age 200, max_weight 1)")
+    ap.add_argument("--decay-min-age", type=int, default=200, help="min_age of --decay (DynSLAMGUI.cpp:38-42: 200)")
     ap.add_argument("--swap", action="store_true", help="enable host swap-in/out (use_swapping; configs[4])")
     ap.add_argument("--instances", type=int, default=0,
                     help="configs[2]: also reconstruct this many moving instances in their own volumes "
@@ -215,7 +216,7 @@ def main():
         eng.process_frame()
         eng.prepare()
         if args.decay:
-            eng.decay(1, 200, False)
+            eng.decay(1, args.decay_min_age, False)
 
     def barrier():
         for ie in inst_eng:

@@ -123,6 +123,7 @@ struct dsr_engine {
   int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
   uint32_t maxSteps = 0;
   int gridPersistent = 2048;
+  int gridDecay = 2048;
   // k_integrate grid: more, finer strided shares balance the tail (5 mm bench: 1280 workgroups
   // (= resident) 918 us, 4096 872 us, 8192 840 us, 16384 835 us, whole-block variant); scaled down
   // for small volumes.
@@ -616,6 +617,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   }
   if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
+  e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
+  if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
   if (const char *iv = getenv("DSR_INTEGRATE_VARIANT")) e->integrateVariant = atoi(iv);
@@ -876,8 +879,12 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
     e->fifoHead = (e->fifoHead + 1) % e->fifoCap;
     e->fifoLen--;
   }
-  LAUNCH(e, "decay_blocks", k_decay_blocks, dim3(e->gridPersistent), dim3(256), e->scene, cand, nCandPtr, max_weight,
-         e->decayFlags);
+  // a short dependent chain per block (entry -> weights -> the other planes) and no pipelining in the
+  // kernel: many waves, few blocks each (env DSR_GRID_DECAY)
+  const float muv = e->s.mu;  // the kernels' rejectedPassGate (k_integrate.h), negated
+  const int zeroIsReset = (((-1.0f > muv) || (fabsf(-1.0f / muv) > 0.25f)) && e->s.max_w >= 1) ? 1 : 0;
+  LAUNCH(e, "decay_blocks", k_decay_blocks, dim3(e->gridDecay), dim3(256), e->scene, cand, nCandPtr, max_weight,
+         e->decayFlags, zeroIsReset);
   LAUNCH(e, "decay_count", k_flag_count, dim3(e->numTilesB), dim3(kTileThreads), (const uint8_t *)e->decayFlags, nCandPtr,
          e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene, (int)SCAN_DECAY, 0);

@@ -76,9 +76,13 @@ __global__ __launch_bounds__(256) void k_fifo_push(const int32_t *__restrict__ v
 
 // One wave per candidate block: reset voxels with w_depth <= maxWeight, flag the block when
 // all 512 voxels end up with w_depth == 0.
+// zeroIsReset: the engine guarantees that a voxel with w_depth == 0 is in the reset state already
+// (sdf 32767, no colour) — true whenever colour can only be fused together with depth (mu < 4 m:
+// voxels the depth step rejects never pass the colour gate) and max_w >= 1 —, so resetting it
+// again would only rewrite the same bytes: such voxels count as empty but are not touched.
 __global__ __launch_bounds__(256) void k_decay_blocks(SceneP s, const int32_t *__restrict__ cand,
                                                       const int32_t *__restrict__ nCandPtr, int maxWeight,
-                                                      uint8_t *__restrict__ freedFlag) {
+                                                      uint8_t *__restrict__ freedFlag, int zeroIsReset) {
   const int n = *nCandPtr;
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_DECAY], (unsigned long long)n);
   const int lane = threadIdx.x & 63;
@@ -88,9 +92,8 @@ __global__ __launch_bounds__(256) void k_decay_blocks(SceneP s, const int32_t *_
     const int ptr = s.table[t].ptr;
     if (ptr < 0) { if (lane == 0) freedFlag[i] = 0; continue; }
     uint8_t *blk = s.vba + (size_t)ptr * kBlockBytes;
-    uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
-    uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
-    uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
+    // the weights decide everything: only lanes that reset a voxel touch the other three planes
+    const uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
     uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
     uint32_t resetMask = 0;  // bit x: voxel x of this lane is reset
     int empty = 0;
@@ -98,24 +101,30 @@ __global__ __launch_bounds__(256) void k_decay_blocks(SceneP s, const int32_t *_
     for (int x = 0; x < 8; ++x) {
       int w = (int)((wdW[x >> 2] >> ((x & 3) * 8)) & 0xffu);
       if (w <= maxWeight) {
-        resetMask |= 1u << x;
-        sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (0x7fffu << ((x & 1) * 16));
+        if (!(zeroIsReset && w == 0)) resetMask |= 1u << x;
         wdW[x >> 2] &= ~(0xffu << ((x & 3) * 8));
         w = 0;
       }
       if (w == 0) empty++;
     }
     if (resetMask) {
-      *reinterpret_cast<uint4 *>(blk + kOffSdf + lane * 16) = make_uint4(sdfW[0], sdfW[1], sdfW[2], sdfW[3]);
-      *reinterpret_cast<uint2 *>(blk + kOffWDepth + lane * 8) = make_uint2(wdW[0], wdW[1]);
-      uint2 wcRaw = *reinterpret_cast<const uint2 *>(blk + kOffWColor + lane * 8);
+      // all four read-modify-writes of the lane are independent: loads first, then the stores
+      const uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
+      const uint2 wcRaw = *reinterpret_cast<const uint2 *>(blk + kOffWColor + lane * 8);
+      const uint4 c0 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32);
+      const uint4 c1 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32 + 16);
+      uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
       uint32_t wcW[2] = {wcRaw.x, wcRaw.y};
-      uint4 c0 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32);
-      uint4 c1 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32 + 16);
       uint32_t clrW[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
       for (int x = 0; x < 8; ++x)
-        if (resetMask & (1u << x)) { wcW[x >> 2] &= ~(0xffu << ((x & 3) * 8)); clrW[x] = 0u; }
+        if (resetMask & (1u << x)) {
+          sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (0x7fffu << ((x & 1) * 16));
+          wcW[x >> 2] &= ~(0xffu << ((x & 3) * 8));
+          clrW[x] = 0u;
+        }
+      *reinterpret_cast<uint4 *>(blk + kOffSdf + lane * 16) = make_uint4(sdfW[0], sdfW[1], sdfW[2], sdfW[3]);
+      *reinterpret_cast<uint2 *>(blk + kOffWDepth + lane * 8) = make_uint2(wdW[0], wdW[1]);
       *reinterpret_cast<uint2 *>(blk + kOffWColor + lane * 8) = make_uint2(wcW[0], wcW[1]);
       *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32) = make_uint4(clrW[0], clrW[1], clrW[2], clrW[3]);
       *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32 + 16) = make_uint4(clrW[4], clrW[5], clrW[6], clrW[7]);
