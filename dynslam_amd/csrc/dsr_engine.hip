@@ -1270,10 +1270,11 @@ __global__ __launch_bounds__(256) void k_selftest_division(unsigned long long n,
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    // a: sign, exponent in [-40, 40]; b: sign, exponent in [-14, 40] (>= 1e-4 as on the hot path),
+    // a: sign, exponent in [-40, 40]; b: sign, exponent in [-34, 40] (>= 1e-10: the smallest divisor a
+    // call site lets through is the frustum test's),
     // random mantissas; every 16th pair uses small integers (weights) as divisor
     const unsigned ma = (unsigned)(z & 0x7fffffu), mb = (unsigned)((z >> 23) & 0x7fffffu);
-    const int ea = (int)((z >> 46) % 81) - 40, eb = (int)((z >> 53) % 55) - 14;
+    const int ea = (int)((z >> 46) % 81) - 40, eb = (int)((z >> 53) % 75) - 34;
     float a = __uint_as_float(((unsigned)(ea + 127) << 23) | ma);
     float b = __uint_as_float(((unsigned)(eb + 127) << 23) | mb);
     if (z >> 63) a = -a;

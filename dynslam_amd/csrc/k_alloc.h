@@ -317,8 +317,10 @@ __device__ __forceinline__ void check_point_visibility(bool &isVisible, bool &is
                                                        const Mat4 &M, const float4 &proj, int W, int H) {
   float3 b = mat_mul3(M, x, y, z, 1.0f);
   if (b.z < 1e-10f) return;
-  float u = proj.x * b.x / b.z + proj.z;
-  float v = proj.y * b.y / b.z + proj.w;
+  // b.z >= 1e-10: tame divisor, the two divisions share the refined reciprocal (dsr_device.h)
+  const float yz = rcp_refined(b.z);
+  float u = div_with_rcp(proj.x * b.x, b.z, yz) + proj.z;
+  float v = div_with_rcp(proj.y * b.y, b.z, yz) + proj.w;
   if (u >= 0 && u < (float)W && v >= 0 && v < (float)H) {
     isVisible = true; isVisibleEnlarged = true;
   } else if (useSwapping) {
