@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const int nCells = mw * mh;
   const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
-  if (blockIdx.x * (int)blockDim.x >= n) return;  // nothing for this workgroup
+  if ((int)(blockIdx.x * blockDim.x) >= n) return;  // nothing for this workgroup
   for (int c = threadIdx.x; c < nCells; c += blockDim.x) cellsLds[c] = make_int2(farBits, closeBits);
   __syncthreads();
   const int lane = threadIdx.x & 63;

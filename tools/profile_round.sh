@@ -1,5 +1,5 @@
 # Round profile: kernel-trace stats of the default bench command + separate PMC passes.
-# Run on the GPU box from the repo root: bash tools/_prof.sh <tag>   (writes gpurun_out/prof_<tag>/)
+# Run on the GPU box from the repo root: bash tools/profile_round.sh <tag>   (writes gpurun_out/prof_<tag>/)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r01d}
