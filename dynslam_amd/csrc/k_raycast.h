@@ -405,7 +405,9 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         //  four bucket heads at once after 8 misses in a row, 631 us; a fire-and-forget prefetch
         //  of the head 3..10 miss steps ahead into an LDS sink, 560 us; parking lanes that need a
         //  trilinear sample until 1..48 of them can take it together, 607..896 us; giving each XCD a
-        //  band of tile columns (workgroup i -> XCD i % 8), 533 vs 512 us.  Every variant
+        //  band of tile columns (workgroup i -> XCD i % 8), 533 vs 512 us; inside runs of misses
+        //  prefetching the word of a 1 MB bucket-occupancy bitmap instead of the 16 B entry (a clear
+        //  bit is a sure miss: no table read at all), 634 us.  Every variant
         //  that adds requests or iterations loses: the march is bound by gather-request
         //  throughput and by the per-wave chain of dependent round trips.)
       }
