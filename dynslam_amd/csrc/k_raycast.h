@@ -64,8 +64,7 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
                                                            VoxCache &cache, VoxCache &cache2) {
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
-  bool f;
-  float res1, res2, v1, v2;
+  float res1, res2;
   if (((ix & 7) != 7) && ((iy & 7) != 7) && ((iz & 7) != 7)) {
     // all 8 corners inside one voxel block (2/3 of the samples): ONE lookup, then the 8 sdf
     // loads are independent and issued together instead of 8 dependent lookup+load pairs.
@@ -91,12 +90,31 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
   {
     const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
     if ((int)fx + (int)fy + (int)fz == 1) {
-      // the cell straddles exactly TWO blocks (29 % of the samples): the base block through the
-      // march cache, the neighbour through a second cache, then the 8 corner loads together —
-      // instead of 8 dependent lookup+load pairs in the generic path below.
-      int lin0, lin1;
-      const int p0 = find_block(s, p, ix, iy, iz, lin0, cache);
-      const int p1 = find_block(s, p, ix + (fx ? 1 : 0), iy + (fy ? 1 : 0), iz + (fz ? 1 : 0), lin1, cache2);
+      // the cell straddles exactly TWO blocks (29 % of the samples).  Either may be the block the
+      // march is in (cache) or the one a previous trilinear sample needed (cache2, which also
+      // remembers blocks that do NOT exist: the table does not change during the kernel); what is
+      // still unknown is looked up with the bucket heads of both blocks requested TOGETHER, then
+      // the 8 corner loads go out together — instead of 8 dependent lookup+load pairs.
+      const int b0x = ix >> 3, b0y = iy >> 3, b0z = iz >> 3;
+      const int b1x = b0x + (fx ? 1 : 0), b1y = b0y + (fy ? 1 : 0), b1z = b0z + (fz ? 1 : 0);
+      int p0 = -2, p1 = -2;  // -2: unknown, -1: no such block
+      if (b0x == cache.bx && b0y == cache.by && b0z == cache.bz) p0 = cache.ptr;
+      else if (b0x == cache2.bx && b0y == cache2.by && b0z == cache2.bz) p0 = cache2.ptr;
+      if (b1x == cache.bx && b1y == cache.by && b1z == cache.bz) p1 = cache.ptr;
+      else if (b1x == cache2.bx && b1y == cache2.by && b1z == cache2.bz) p1 = cache2.ptr;
+      int4 h0 = make_int4(0, 0, 0, -2), h1 = make_int4(0, 0, 0, -2);
+      if (p0 == -2) h0 = *reinterpret_cast<const int4 *>(s.table + hash_index(b0x, b0y, b0z, p.hashMask));
+      if (p1 == -2) h1 = *reinterpret_cast<const int4 *>(s.table + hash_index(b1x, b1y, b1z, p.hashMask));
+      auto resolve = [&](int4 raw, int bx, int by, int bz) -> int {  // ITMRepresentationAccess.h findVoxel
+        while (true) {
+          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+          if (hx == bx && hy == by && hz == bz && raw.w >= 0) return raw.w;
+          if (raw.z < 1) return -1;
+          raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
+        }
+      };
+      if (p0 == -2) { p0 = resolve(h0, b0x, b0y, b0z); cache2.bx = b0x; cache2.by = b0y; cache2.bz = b0z; cache2.ptr = p0; }
+      if (p1 == -2) { p1 = resolve(h1, b1x, b1y, b1z); cache2.bx = b1x; cache2.by = b1y; cache2.bz = b1z; cache2.ptr = p1; }
       const uint8_t *vb = s.vba + kOffSdf;
       float v[8];
 #pragma unroll
@@ -115,15 +133,61 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
       return (1.0f - cz) * res1 + cz * res2;
     }
   }
-  v1 = read_sdf_raw(s, p, ix, iy, iz, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy, iz, f, cache);
-  res1 = (1.0f - cx) * v1 + cx * v2;
-  v1 = read_sdf_raw(s, p, ix, iy + 1, iz, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy + 1, iz, f, cache);
-  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v1 + cx * v2);
-  v1 = read_sdf_raw(s, p, ix, iy, iz + 1, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy, iz + 1, f, cache);
-  res2 = (1.0f - cx) * v1 + cx * v2;
-  v1 = read_sdf_raw(s, p, ix, iy + 1, iz + 1, f, cache); v2 = read_sdf_raw(s, p, ix + 1, iy + 1, iz + 1, f, cache);
-  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v1 + cx * v2);
-  return (1.0f - cz) * res1 + cz * res2;
+  {
+    // the cell straddles 4 or 8 blocks (4 % of the samples).  The reference walks the 8 corners one
+    // after the other — lookup, voxel, lookup, voxel ...: up to 16 DEPENDENT round trips, during
+    // which the other 63 lanes of the wave wait.  Here the bucket heads of the blocks are requested two
+    // at a time (registers: the kernel must stay at 64 VGPRs), chains — rare — are then walked, and the
+    // 8 voxels are requested together: 3-5 round trips.  Lookups are pure functions of the table, so the values
+    // are the reference's.
+    const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
+    const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
+    int bptr[8];
+#pragma unroll
+    for (int pair = 0; pair < 4; ++pair) {  // blocks (ox, oy, oz) = (0|1, pair & 1, pair >> 1), two per pass
+      const int oy = pair & 1, oz = pair >> 1;
+      bptr[pair * 2] = -1; bptr[pair * 2 + 1] = -1;
+      if ((oy && !fy) || (oz && !fz)) continue;
+      int4 head[2];
+      bool want[2];
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) {
+        want[ox] = !ox || fx;
+        if (want[ox]) {
+          const int bx = bx0 + ox, by = by0 + oy, bz = bz0 + oz;
+          if (bx == cache.bx && by == cache.by && bz == cache.bz) { bptr[pair * 2 + ox] = cache.ptr; want[ox] = false; }
+          else head[ox] = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
+        }
+      }
+#pragma unroll
+      for (int ox = 0; ox < 2; ++ox) {
+        if (!want[ox]) continue;
+        const int bx = bx0 + ox, by = by0 + oy, bz = bz0 + oz;
+        int4 raw = head[ox];
+        while (true) {  // ITMRepresentationAccess.h findVoxel
+          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+          if (hx == bx && hy == by && hz == bz && raw.w >= 0) { bptr[pair * 2 + ox] = raw.w; break; }
+          if (raw.z < 1) break;
+          raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
+        }
+      }
+    }
+    const uint8_t *vb = s.vba + kOffSdf;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+      const int ptr = bptr[((fx && dx) ? 1 : 0) | ((fy && dy) ? 2 : 0) | ((fz && dz) ? 4 : 0)];
+      const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
+      v[k] = 32767.0f;
+      if (ptr >= 0) v[k] = (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + lin * 2);
+    }
+    res1 = (1.0f - cx) * v[0] + cx * v[1];
+    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+    res2 = (1.0f - cx) * v[4] + cx * v[5];
+    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+    return (1.0f - cz) * res1 + cz * res2;
+  }
 }
 __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
                                                        VoxCache &cache, VoxCache &cache2) {
@@ -446,7 +510,7 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
 }
 
 // 8x8 pixel tile per wave (4 tiles per 256-thread workgroup, laid out 2x2 => 16x16 pixels)
-__global__ __launch_bounds__(256) void k_raycast(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
+__global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
                                                  float4 *__restrict__ raycastResult) {
   if (s.ctr[ctrIdx] <= 0 && ctrIdx == CTR_NO_VISIBLE_LIVE) return;  // Prepare() is skipped without visible blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
