@@ -65,7 +65,7 @@ def make_frames(w, h, n, n_inst=0):
         return pool.map(_gen_frame, [(w, h, i, n_inst) for i in range(n)])
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_g_bench5mm_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_h_bench5mm_pmc_traffic.json")
 
 
 def pmc_traffic(args, kernel):
@@ -268,7 +268,7 @@ def main():
                             "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
                             "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                             "limiter": "VALU issue: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = 98 % of the launch duration "
-                                       "(profiles/r01_g_*_pmc_sq.json)",
+                                       "(profiles/r01_h_*_pmc_sq.json)",
                             "note": "algorithmic bytes = SURVEY 8d: V*(16+2*4096)+8P, the reference formulation's "
                                     "compulsory traffic (every voxel of every visible block read and written as an "
                                     "8 B struct). The plane-wise layout moves less than half of it (traffic), so "
