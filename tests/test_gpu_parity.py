@@ -238,3 +238,28 @@ def test_device_resident_view_equals_host_view(hip_api):
     assert_scene_equal(g2, o)
     for e in (g, o, g2):
         e.close()
+
+
+def test_asynchronous_loop_bit_exact(hip_api):
+    """The steady loop UpdateView(dev) -> ProcessFrame -> Prepare with sync_status = 0, as bench.py
+    drives it: nothing is read back and the host never waits in between; the final state must be
+    the oracle's, several times over (a missing dependency would show as a flaky difference)."""
+    import torch
+    from tests.common import assert_render_equal
+    dev = torch.device("cuda", 0)
+    for rep in range(3):
+        sc, g, o = make_pair(sync_status=0)
+        frames = [sc.frame(i) for i in range(8)]
+        r_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
+        d_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
+        torch.cuda.synchronize()
+        for i, (rgba, d, T, _) in enumerate(frames):
+            g.update_view_dev(r_dev[i].data_ptr(), d_dev[i].data_ptr())
+            g.set_pose_inv_m(T)
+            g.process_frame()
+            g.prepare()
+            o.update_view(rgba, d); o.set_pose_inv_m(T); o.process_frame(); o.prepare()
+        g.sync()
+        assert_scene_equal(g, o)
+        assert_render_equal(g, o)
+        g.close(); o.close()
