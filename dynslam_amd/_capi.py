@@ -5,6 +5,7 @@ declares; the product binds `dsr_` from libdsr_hip.so (engine.py), the test
 infrastructure binds the same signatures with the prefix `orc_` from the CPU checker library.
 """
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 ABI_VERSION = 1
@@ -129,6 +130,26 @@ SIGNATURES = {
     "mesh_free": (C.c_int, [_H]),
     "save_scene_to_mesh": (C.c_int, [_H, C.c_char_p]),
 }
+
+
+def preload_hip_runtime():
+    """If PyTorch-ROCm is installed, load ITS copy of libamdhip64.so.7 before libdsr_hip.so is
+    dlopen'ed, without importing torch.  Both the wheel and /opt/rocm ship a HIP runtime with
+    the same SONAME; whichever is loaded first serves the whole process, and a process that ends
+    up with /opt/rocm's runtime plus the wheel's HSA runtime sees no device.  With the wheel's
+    copy loaded first, `import torch` before or after the engine both work."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def bind(lib, prefix):

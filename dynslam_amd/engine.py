@@ -47,6 +47,7 @@ def load_hip_api():
             raise ImportError(
                 f"{HIP_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
+        _capi.preload_hip_runtime()
         lib = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
         api = _capi.bind(lib, "dsr_")
         if api.abi_version() != _capi.ABI_VERSION:

@@ -29,6 +29,7 @@ def test_header_and_bindings_agree():
 def test_hip_library_exports_every_symbol():
     path = os.path.join(ROOT, "dynslam_amd", "csrc", "libdsr_hip.so")
     assert os.path.exists(path), "libdsr_hip.so not built: run __graft_entry__.build()"
+    _capi.preload_hip_runtime()
     lib = C.CDLL(path)
     api = _capi.bind(lib, "dsr_")  # AttributeError if a symbol is missing
     assert api.abi_version() == _capi.ABI_VERSION
