@@ -142,6 +142,9 @@ def main():
                          "of a full profile cost ~9 %% of the frame)")
     ap.add_argument("--decay", action="store_true", help="also run voxel GC each frame (min_age 200, max_weight 1)")
     ap.add_argument("--decay-min-age", type=int, default=200, help="min_age of --decay (DynSLAMGUI.cpp:38-42: 200)")
+    ap.add_argument("--host-views", action="store_true",
+                    help="hand every frame over as pageable HOST buffers (dsr_update_view: H2D copy + stream sync per "
+                         "frame, as InfiniTamDriver::UpdateView does): the PCIe-inclusive rate quoted in DESIGN.md, never `value`")
     ap.add_argument("--swap", action="store_true", help="enable host swap-in/out (use_swapping; configs[4])")
     ap.add_argument("--instances", type=int, default=0,
                     help="configs[2]: also reconstruct this many moving instances in their own volumes "
@@ -203,7 +206,10 @@ def main():
                 for _ in range(args.instances)]
 
     def step(i):
-        eng.update_view_dev(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr())
+        if args.host_views:
+            eng.update_view(frames[i][0], frames[i][1])
+        else:
+            eng.update_view_dev(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr())
         for k, x0, y0, mask, rel in frames[i][3]:
             # ProcessSilhouette + RemoveSilhouette on the GPU, then FuseFrame of the instance
             # (InstanceReconstructor.cpp:238-263,569-700)
@@ -290,7 +296,8 @@ def main():
             "config": {"workload": f"{'configs[2]: static map + ' + str(args.instances) + ' instance volumes' if args.instances else 'configs[1]: static map only'}"
                                    f"{' + voxel GC' if args.decay else ''}{' + host swapping' if args.swap else ''}, synthetic KITTI-like street {W}x{H}, "
                                    f"preset {args.preset} (voxel {kw['voxel_size']} m, mu {kw['mu']} m), "
-                                   f"frames {Wm}..{Wm + K - 1} of a {n_frames}-frame sequence, one volume per GPU",
+                                   f"frames {Wm}..{Wm + K - 1} of a {n_frames}-frame sequence, one volume per GPU"
+                                   f"{', views handed over as pageable host buffers (PCIe inclusive)' if args.host_views else ''}",
                        "visible_blocks_last_frame": stats.no_visible_blocks,
                        "allocated_blocks": kw["sdf_local_block_num"] - 1 - stats.last_free_block_id,
                        "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
