@@ -263,3 +263,35 @@ def test_asynchronous_loop_bit_exact(hip_api):
         assert_scene_equal(g, o)
         assert_render_equal(g, o)
         g.close(); o.close()
+
+
+@pytest.mark.parametrize("size", [(203, 77), (1226 // 2, 370 // 2)])
+def test_odd_image_sizes(hip_api, size):
+    """Widths / heights that are not multiples of 4, 8 or 16: partial raycast tiles, partial cells
+    of the range image, the scalar tails of the view ingest (host and device entry points)."""
+    import torch
+    W, H = size
+    sc, g, o = make_pair(W=W, H=H)
+    dev = torch.device("cuda", 0)
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        o.update_view(rgba, d)
+        if i == 1:
+            r_dev, d_dev = torch.from_numpy(rgba).to(dev), torch.from_numpy(d).to(dev)
+            torch.cuda.synchronize()
+            g.update_view_dev(r_dev.data_ptr(), d_dev.data_ptr())
+        else:
+            g.update_view(rgba, d)
+        for e in (g, o):
+            e.set_pose_inv_m(T); e.process_frame(); e.prepare()
+        vr, vd = g.get_view(); wr, wd = o.get_view()
+        assert np.array_equal(vr, wr) and np.array_equal(vd.view(np.uint32), wd.view(np.uint32))
+    assert_scene_equal(g, o)
+    assert_render_equal(g, o)
+    for t in RENDER_TYPES[:2] + RENDER_TYPES[-1:]:
+        want_d = t == _capi.IMAGE_FREECAMERA_DEPTH
+        a = g.get_image(t, want_rgba=not want_d, want_depth=want_d)
+        b = o.get_image(t, want_rgba=not want_d, want_depth=want_d)
+        assert np.array_equal(a[1] if want_d else a[0], b[1] if want_d else b[0])
+    assert np.array_equal(g.mesh_scene().view(np.uint32), o.mesh_scene().view(np.uint32))
+    g.close(); o.close()
