@@ -107,6 +107,12 @@ SIGNATURES = {
     "get_image_dev": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
     "depth_from_disparity": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "depth_from_disparity_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "bgr_to_rgba": (C.c_int, [_P, _P, C.c_int]),
+    "bgr_to_rgba_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int]),
+    "rgba_to_bgr": (C.c_int, [_P, _P, C.c_int]),
+    "rgba_to_bgr_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int]),
+    "depth_m_to_mm": (C.c_int, [_P, _P, C.c_int]),
+    "depth_m_to_mm_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int]),
     "view_extract_silhouette": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "view_remove_silhouette": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),

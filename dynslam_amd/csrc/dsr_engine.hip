@@ -565,6 +565,33 @@ int swap_out(dsr_engine *e) {
 
 }  // namespace
 
+// per-pixel conversion kernels of the boundary (k_edges.h): device-resident and host-buffer drivers
+template <class K, class TI, class TO>
+int convert_dev(K kernel, int device, void *hip_stream, const void *in, void *out, int n) {
+  if (!in || !out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, (const TI *)in, (TO *)out, n);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+template <class K, class TI, class TO>
+int convert_host(K kernel, const void *in, size_t inBytes, void *out, size_t outBytes, int n) {
+  if (!in || !out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
+  uint8_t *d = nullptr, *o = nullptr;
+  int st = dmalloc(&d, inBytes);
+  if (st) return st;
+  if ((st = dmalloc(&o, outBytes))) { (void)hipFree(d); return st; }
+  hipError_t err = hipMemcpy(d, in, inBytes, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    st = convert_dev<K, TI, TO>(kernel, -1, nullptr, d, o, n);
+    if (st == DSR_OK) err = hipMemcpy(out, o, outBytes, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d); (void)hipFree(o);
+  if (st) return st;
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, "conversion copy failed");
+  return DSR_OK;
+}
+
 #define CHECK_E(e)                                          \
   if (!(e)) return fail(DSR_E_ARG, "null engine");          \
   { int _st = set_device(e); if (_st) return _st; }
@@ -994,6 +1021,27 @@ int dsr_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int 
   if (st) return st;
   if (err != hipSuccess) return fail(DSR_E_DEVICE, "disparity conversion copy failed");
   return DSR_OK;
+}
+
+// ---- layout shims of the host at the boundary (InfiniTamDriver.cpp:81-144)
+
+int dsr_bgr_to_rgba_dev(int device, void *hip_stream, const void *bgr_dev, void *rgba_out_dev, int n) {
+  return convert_dev<decltype(&k_bgr_to_rgba), uint8_t, uchar4>(k_bgr_to_rgba, device, hip_stream, bgr_dev, rgba_out_dev, n);
+}
+int dsr_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n) {
+  return convert_host<decltype(&k_bgr_to_rgba), uint8_t, uchar4>(k_bgr_to_rgba, bgr, (size_t)n * 3, rgba_out, (size_t)n * 4, n);
+}
+int dsr_rgba_to_bgr_dev(int device, void *hip_stream, const void *rgba_dev, void *bgr_out_dev, int n) {
+  return convert_dev<decltype(&k_rgba_to_bgr), uchar4, uint8_t>(k_rgba_to_bgr, device, hip_stream, rgba_dev, bgr_out_dev, n);
+}
+int dsr_rgba_to_bgr(const uint8_t *rgba, uint8_t *bgr_out, int n) {
+  return convert_host<decltype(&k_rgba_to_bgr), uchar4, uint8_t>(k_rgba_to_bgr, rgba, (size_t)n * 4, bgr_out, (size_t)n * 3, n);
+}
+int dsr_depth_m_to_mm_dev(int device, void *hip_stream, const void *depth_m_dev, void *depth_mm_out_dev, int n) {
+  return convert_dev<decltype(&k_depth_m_to_mm), float, short>(k_depth_m_to_mm, device, hip_stream, depth_m_dev, depth_mm_out_dev, n);
+}
+int dsr_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n) {
+  return convert_host<decltype(&k_depth_m_to_mm), float, short>(k_depth_m_to_mm, depth_m, (size_t)n * 4, depth_mm_out, (size_t)n * 2, n);
 }
 
 static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h) {

@@ -21,6 +21,24 @@ __global__ __launch_bounds__(256) void k_depth_from_disparity(const float *__res
   out[i] = (short)depth_mm;
 }
 
+// InfiniTamDriver.cpp CvToItm / ItmToCv / FloatDepthmapToShort: the host's per-pixel layout loops
+__global__ __launch_bounds__(256) void k_bgr_to_rgba(const uint8_t *__restrict__ bgr, uchar4 *__restrict__ rgba, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rgba[i] = make_uchar4(bgr[3 * i + 2], bgr[3 * i + 1], bgr[3 * i], 255);  // .r = col[2], .g = col[1], .b = col[0]
+}
+__global__ __launch_bounds__(256) void k_rgba_to_bgr(const uchar4 *__restrict__ rgba, uint8_t *__restrict__ bgr, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uchar4 c = rgba[i];
+  bgr[3 * i] = c.z; bgr[3 * i + 1] = c.y; bgr[3 * i + 2] = c.x;
+}
+__global__ __launch_bounds__(256) void k_depth_m_to_mm(const float *__restrict__ m, short *__restrict__ mm, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  mm[i] = f2s(m[i] * (float)1000);  // pixels[..] * kMetersToMillimeters (int promoted to float)
+}
+
 // dest (instance view) := default everywhere, source pixel where the bbox-local mask is 1
 __global__ __launch_bounds__(256) void k_extract_silhouette(const uchar4 *__restrict__ srcRgb,
                                                             const float *__restrict__ srcDepth,

@@ -247,6 +247,22 @@ int dsr_depth_from_disparity_dev(int device, void *hip_stream, const void *dispa
                                  int n, float baseline_m, float focal_px, float scale, float min_depth_m,
                                  float max_depth_m);
 
+/* The host's layout shims at the boundary (InfiniTamDriver.cpp:81-144),
+ * as kernels, so that frames and previews can stay in HBM in the host's own formats:
+ *   dsr_bgr_to_rgba   CvToItm(cv::Mat3b): packed BGR u8[3n] -> RGBA u8[4n], a = 255   (:81-100)
+ *   dsr_rgba_to_bgr   ItmToCv(ITMUChar4Image): RGBA u8[4n] -> packed BGR u8[3n]      (:108-120)
+ *   dsr_depth_m_to_mm FloatDepthmapToShort: (int16)(metres * 1000)                   (:128-139);
+ *                     C leaves out-of-range float->int16 undefined: defined here, as everywhere
+ *                     in this library, as the saturating float->int32 conversion wrapped to 16 bits
+ * The plain variants take host buffers; the _dev variants work on HBM buffers of `device` and
+ * enqueue on hip_stream (NULL = default stream). */
+int dsr_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n);
+int dsr_bgr_to_rgba_dev(int device, void *hip_stream, const void *bgr_dev, void *rgba_out_dev, int n);
+int dsr_rgba_to_bgr(const uint8_t *rgba, uint8_t *bgr_out, int n);
+int dsr_rgba_to_bgr_dev(int device, void *hip_stream, const void *rgba_dev, void *bgr_out_dev, int n);
+int dsr_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n);
+int dsr_depth_m_to_mm_dev(int device, void *hip_stream, const void *depth_m_dev, void *depth_mm_out_dev, int n);
+
 /* ProcessSilhouette_CPU (InstanceReconstructor.cpp:59-133) on the GPU: the view of `instance`
  * becomes the pixels of `main`'s current view that lie under the copy mask, everything else
  * rgba (255,255,255,255) / depth 0.  mask: HOST uint8[box_h][box_w] (1 = copy), placed at

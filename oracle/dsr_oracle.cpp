@@ -1471,6 +1471,42 @@ int orc_depth_from_disparity_dev(int, void *, const void *d, void *o, int n, flo
   return orc_depth_from_disparity((const float *)d, (int16_t *)o, n, b, f, s, mn, mx);
 }
 
+/* InfiniTamDriver.cpp:81-100 CvToItm(cv::Mat3b) */
+int orc_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n) {
+  if (!bgr || !rgba_out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
+  for (int idx = 0; idx < n; ++idx) {
+    const uint8_t *col = bgr + 3 * (size_t)idx;
+    uint8_t *d = rgba_out + 4 * (size_t)idx; /* Vector4u {r, g, b, a} */
+    d[2] = col[0]; /* .b */
+    d[1] = col[1]; /* .g */
+    d[0] = col[2]; /* .r */
+    d[3] = 255u;   /* .a */
+  }
+  return DSR_OK;
+}
+int orc_bgr_to_rgba_dev(int, void *, const void *i, void *o, int n) { return orc_bgr_to_rgba((const uint8_t *)i, (uint8_t *)o, n); }
+
+/* InfiniTamDriver.cpp:108-120 ItmToCv(ITMUChar4Image) */
+int orc_rgba_to_bgr(const uint8_t *rgba, uint8_t *bgr_out, int n) {
+  if (!rgba || !bgr_out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
+  for (int idx = 0; idx < n; ++idx) {
+    const uint8_t *s_ = rgba + 4 * (size_t)idx;
+    uint8_t *d = bgr_out + 3 * (size_t)idx;
+    d[0] = s_[2]; d[1] = s_[1]; d[2] = s_[0]; /* cv::Vec3b(.b, .g, .r) */
+  }
+  return DSR_OK;
+}
+int orc_rgba_to_bgr_dev(int, void *, const void *i, void *o, int n) { return orc_rgba_to_bgr((const uint8_t *)i, (uint8_t *)o, n); }
+
+/* InfiniTamDriver.cpp:128-139 FloatDepthmapToShort; out-of-range conversions as f2i (saturating) */
+int orc_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n) {
+  if (!depth_m || !depth_mm_out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
+  const int kMetersToMillimeters = 1000;
+  for (int i = 0; i < n; ++i) depth_mm_out[i] = (int16_t)f2i(depth_m[i] * kMetersToMillimeters);
+  return DSR_OK;
+}
+int orc_depth_m_to_mm_dev(int, void *, const void *i, void *o, int n) { return orc_depth_m_to_mm((const float *)i, (int16_t *)o, n); }
+
 /* ProcessSilhouette_CPU (InstanceReconstructor.cpp:59-133), restated on the engines' views. */
 int orc_view_extract_silhouette(dsr_engine *m, dsr_engine *inst, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
   if (!m || !inst || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");

@@ -243,6 +243,24 @@ inline void dsr_throw(int st) {
 using namespace ITMLib::Objects;
 using ITMLib::Engine::WeightParams;
 
+// The layout loops of InfiniTamDriver.cpp:81-144 on the GPU, for hosts without OpenCV types at hand:
+// raw buffers in, raw buffers out (a cv::Mat3b is `rows*cols` packed BGR triples, a cv::Mat1s `short`s).
+namespace dynslam_shim {
+inline void CvToItm(const unsigned char *bgr, int rows, int cols, ITMUChar4Image *out_itm) {  // :81-100
+  out_itm->ChangeDims(Vector2i(cols, rows));
+  ITMLib::Engine::dsr_throw(dsr_bgr_to_rgba(bgr, reinterpret_cast<uint8_t *>(out_itm->GetData(MEMORYDEVICE_CPU)), rows * cols));
+}
+inline void ItmToCv(const ITMUChar4Image &itm, unsigned char *bgr_out) {  // :108-120
+  ITMLib::Engine::dsr_throw(dsr_rgba_to_bgr(reinterpret_cast<const uint8_t *>(itm.GetData(MEMORYDEVICE_CPU)), bgr_out, itm.noDims.x * itm.noDims.y));
+}
+inline void FloatDepthmapToShort(const float *pixels, short *out_mm, int n) {  // :128-139
+  ITMLib::Engine::dsr_throw(dsr_depth_m_to_mm(pixels, out_mm, n));
+}
+inline void ItmDepthToCv(const ITMFloatImage &itm, short *out_mm) {  // :141-144
+  FloatDepthmapToShort(itm.GetData(MEMORYDEVICE_CPU), out_mm, itm.noDims.x * itm.noDims.y);
+}
+}  // namespace dynslam_shim
+
 // scene facade: only the counters the host reads (InfiniTamDriver.h:241-244)
 template <class TVoxel, class TIndex> struct ITMScene {
   dsr_engine *e = nullptr;

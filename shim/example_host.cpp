@@ -96,6 +96,13 @@ int main(int argc, char **argv) {
     uint64_t h = fnv(out.GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4);
     h = fnv(outf.GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4, h);
     h = fnv(drv.GetView()->depth->GetData(MEMORYDEVICE_CPU), (size_t)W * H * 4, h);
+    // the host's preview conversions (InfiniTamDriver.cpp:108-144) through the GPU
+    std::vector<short> preview_mm((size_t)W * H);
+    std::vector<unsigned char> preview_bgr((size_t)W * H * 3);
+    dynslam_shim::ItmDepthToCv(outf, preview_mm.data());
+    dynslam_shim::ItmToCv(out, preview_bgr.data());
+    h = fnv(preview_mm.data(), (size_t)W * H * 2, h);
+    h = fnv(preview_bgr.data(), (size_t)W * H * 3, h);
     unsigned triangles = 0;
     if (argc > 4) {  // InstanceReconstructor.cpp:749-757
       auto *meshing_engine = new ITMMeshingEngine_CUDA<ITMVoxel, ITMVoxelIndex>(settings.sdfLocalBlockNum);

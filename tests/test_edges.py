@@ -48,6 +48,41 @@ def test_oracle_depth_from_disparity(oracle_lib):
     assert oracle_lib.depth_from_disparity(vp(d), vp(out), len(d), 0.5, 700.0, 1.0, 0.5, 40.0) != 0
 
 
+def conversion_case(n=1242 * 375 + 3, seed=9):
+    rng = np.random.default_rng(seed)
+    bgr = rng.integers(0, 256, (n, 3), dtype=np.uint8)
+    depth_m = rng.uniform(-1.0, 40.0, n).astype(np.float32)
+    depth_m[::101] = 0.0
+    depth_m[1::101] = 32.7675          # just past the int16 range in millimetres
+    depth_m[2::101] = 1e9
+    depth_m[3::101] = -1e9
+    depth_m[4::101] = np.nan
+    depth_m[5::101] = np.float32(12.3456)
+    return bgr, depth_m
+
+
+def test_oracle_boundary_conversions(oracle_lib):
+    """CvToItm / ItmToCv / FloatDepthmapToShort (InfiniTamDriver.cpp:81-144) against numpy statements."""
+    bgr, depth_m = conversion_case(20_003)
+    n = len(bgr)
+    rgba = np.empty((n, 4), np.uint8)
+    assert oracle_lib.bgr_to_rgba(vp(bgr), vp(rgba), n) == 0
+    assert np.array_equal(rgba[:, :3], bgr[:, ::-1]) and (rgba[:, 3] == 255).all()
+    back = np.empty((n, 3), np.uint8)
+    assert oracle_lib.rgba_to_bgr(vp(rgba), vp(back), n) == 0
+    assert np.array_equal(back, bgr)
+    mm = np.empty(n, np.int16)
+    assert oracle_lib.depth_m_to_mm(vp(depth_m), vp(mm), n) == 0
+    x = (depth_m * np.float32(1000)).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        sat = np.where(np.isnan(x), 0, np.clip(np.trunc(x.astype(np.float64)), -2**31, 2**31 - 1)).astype(np.int64)
+    want = (sat & 0xFFFF).astype(np.uint16).view(np.int16)
+    assert np.array_equal(mm, want)
+    ok = (depth_m >= 0) & (depth_m < 32.7)
+    assert np.array_equal(mm[ok], np.trunc(x[ok]).astype(np.int16))  # the in-range values are the plain cast
+    assert oracle_lib.depth_m_to_mm(vp(depth_m), vp(mm), 0) != 0
+
+
 def box_mask(H, W, y0, x0, h, w, seed):
     rng = np.random.default_rng(seed)
     m = (rng.random((h, w)) < 0.7).astype(np.uint8)
@@ -127,6 +162,34 @@ def test_gpu_depth_from_disparity(hip_api, oracle_lib):
     assert st == 0
     torch.cuda.synchronize()
     assert np.array_equal(to.cpu().numpy(), o)
+
+
+@pytest.mark.gpu
+def test_gpu_boundary_conversions(hip_api, oracle_lib):
+    import torch
+    bgr, depth_m = conversion_case()
+    n = len(bgr)
+    res = {}
+    for name, api in (("g", hip_api), ("o", oracle_lib)):
+        rgba = np.empty((n, 4), np.uint8); back = np.empty((n, 3), np.uint8); mm = np.empty(n, np.int16)
+        assert api.bgr_to_rgba(vp(bgr), vp(rgba), n) == 0
+        assert api.rgba_to_bgr(vp(rgba), vp(back), n) == 0
+        assert api.depth_m_to_mm(vp(depth_m), vp(mm), n) == 0
+        res[name] = (rgba, back, mm)
+    for a, b in zip(res["g"], res["o"]):
+        assert np.array_equal(a, b)
+    # HBM-resident variants on the caller's stream
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    t_bgr = torch.from_numpy(bgr).cuda(); t_rgba = torch.empty((n, 4), dtype=torch.uint8, device="cuda")
+    t_back = torch.empty((n, 3), dtype=torch.uint8, device="cuda")
+    t_m = torch.from_numpy(depth_m).cuda(); t_mm = torch.empty(n, dtype=torch.int16, device="cuda")
+    assert hip_api.bgr_to_rgba_dev(0, stream, C.c_void_p(t_bgr.data_ptr()), C.c_void_p(t_rgba.data_ptr()), n) == 0
+    assert hip_api.rgba_to_bgr_dev(0, stream, C.c_void_p(t_rgba.data_ptr()), C.c_void_p(t_back.data_ptr()), n) == 0
+    assert hip_api.depth_m_to_mm_dev(0, stream, C.c_void_p(t_m.data_ptr()), C.c_void_p(t_mm.data_ptr()), n) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(t_rgba.cpu().numpy(), res["o"][0]) and np.array_equal(t_back.cpu().numpy(), bgr)
+    assert np.array_equal(t_mm.cpu().numpy(), res["o"][2])
+    assert hip_api.bgr_to_rgba_dev(0, stream, None, C.c_void_p(t_rgba.data_ptr()), n) != 0
 
 
 @pytest.mark.gpu

@@ -65,6 +65,12 @@ def test_shim_host_matches_python_mirror(hip_api, tmp_path):
     _, dep = e.get_image(_capi.IMAGE_FREECAMERA_DEPTH, want_rgba=False, want_depth=True)
     vdepth = e.get_view()[1]
     h = fnv(vdepth.tobytes(), fnv(dep.tobytes(), fnv(col.tobytes())))
+    import ctypes as C
+    mm = np.empty(W * H, np.int16); bgr = np.empty((W * H, 3), np.uint8)
+    assert e.api.depth_m_to_mm(dep.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p), W * H) == 0
+    assert e.api.rgba_to_bgr(col.ctypes.data_as(C.c_void_p), bgr.ctypes.data_as(C.c_void_p), W * H) == 0
+    assert np.array_equal(bgr.reshape(H, W, 3), col[..., 2::-1])
+    h = fnv(bgr.tobytes(), fnv(mm.tobytes(), h))
     st = e.get_stats()
     assert int(got["visible"]) == st.no_visible_blocks
     assert int(got["used_bytes"]) == 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id)
