@@ -3,11 +3,15 @@
 // Replaces: convertDepthAffineToFloat_device, buildHashAllocAndVisibleType,
 // allocateVoxelBlocksList, buildVisibleList, setToType3 of upstream's *_CUDA engines — with a
 // DETERMINISTIC formulation whose result equals the serial _CPU engine:
+//   * K0b re-tests the previous frame's visible list against the frustum DENSELY (a thread per list
+//     entry) instead of inside the sweep over all entries;
 //   * K1 marks per pixel; for every target entry the LAST writer in (raster pixel, step)
-//     order wins, selected with an atomicMax on a 32-bit order key;
-//   * the commit recomputes the winner's block position and pops the voxel/excess free
-//     lists in ASCENDING ENTRY ORDER through ordered tile prefix sums (ballot-free wave64
-//     shuffle scans + a single-workgroup scan of tile sums);
+//     order wins, selected with an atomicMax on a 32-bit order key; the first writer of an
+//     entry also counts it (a byte per 8 entries, a word per sweep tile);
+//   * the commit pops the voxel/excess free lists in ASCENDING ENTRY ORDER through ordered tile
+//     prefix sums (wave64 shuffle scans + a single-workgroup scan of tile sums), reading one
+//     byte per 8 entries, compacts the marked entries into an ordered work list and lets a dense
+//     kernel recompute each winner's block position and write the table;
 //   * the visible list is an ordered compaction, so visibleEntryIDs is ascending.
 #pragma once
 #include "dsr_device.h"

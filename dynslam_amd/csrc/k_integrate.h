@@ -2,11 +2,10 @@
 //
 // Replaces integrateIntoScene_device (upstream: one 512-thread CUDA block per voxel block,
 // 8 B array-of-structs voxels).  CDNA4 formulation:
-//   * A WAVE64 PER HALF BLOCK (VOX = 4 voxels along x per lane; 4 z-slices = 256 voxels per wave)
-//     or per whole block (VOX = 8).  With the plane-wise block layout (dsr_device.h) a lane moves
-//     2*VOX B of sdf and VOX B of w_depth in fully coalesced accesses (lane l owns voxels
-//     [VOX*l, VOX*l+VOX) of its half).  VOX = 4 halves the per-lane register arrays, which is what
-//     lets the kernel run at more waves per SIMD (VOX = 8: 96 VGPRs, 5 waves).
+//   * A WAVE64 PER BLOCK, 8 voxels along x per lane (VOX = 8; 71 VGPRs, 7 waves per SIMD: the
+//     default), or per HALF block (VOX = 4: 4 z-slices = 256 voxels per wave, 8 waves per SIMD).
+//     With the plane-wise block layout (dsr_device.h) a lane moves 2*VOX B of sdf and VOX B of
+//     w_depth in fully coalesced accesses (lane l owns voxels [VOX*l, VOX*l+VOX) of its task).
 //   * PHASE A1 (project): branch-free; all depth-image gathers of a lane are issued before any is
 //     consumed.  A task none of whose voxels passes the depth tests ends right after it.
 //   * PHASE A2 (depth): branch-free SDF running mean.  Voxels that also pass the colour gate
@@ -14,15 +13,15 @@
 //     list {task, voxel} — one word per voxel — (wave64 ballot + prefix popcount) that PERSISTS
 //     ACROSS TASKS.
 //   * PHASE B (colour): whenever the list holds 64 voxels the wave updates them DENSELY, one per
-//     lane: re-reads the voxel's hash entry, re-projects it, gathers its 4 B colour + 1 B weight, bilinear RGB sample,
-//     running mean, scatter back.  The divergent colour branch of the per-voxel formulation (every
+//     lane: re-reads the voxel's hash entry, re-projects it, gathers its 4 B colour + 1 B weight,
+//     bilinear RGB sample, running mean, scatter back.  The divergent colour branch of the per-voxel formulation (every
 //     lane paying ~150 instructions for the few that need it, once per task) is paid once per 64
 //     colour voxels instead, and the colour planes of untouched voxels are never read.
 //   * A persistent grid strides over the visible list whose length is read from device memory
 //     (the host never synchronises to learn noVisibleBlocks); hash entries are fetched two tasks
 //     ahead and voxel planes one task ahead of the arithmetic.
-//   * The kernel is VALU-issue bound (~95 instructions per voxel quartet and lane before this
-//     formulation), not HBM bound, so instruction count is what is optimised: divisions use the
+//   * The kernel is VALU-issue bound (SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = 98 % of its duration),
+//     not HBM bound, so instruction count is what is optimised: divisions use the
 //     shared-reciprocal form of the IEEE sequence (dsr_device.h "correctly rounded division for
 //     tame operands"), and for divisors with a correctly rounded reciprocal at hand (mu, 32767,
 //     255, the integer weights) the one-correction form div_short below.
