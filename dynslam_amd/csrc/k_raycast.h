@@ -194,49 +194,6 @@ __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const Fr
   return sdf_to_float(read_sdf_interpolated_raw(s, p, x, y, z, cache, cache2));
 }
 
-// One ray-march sample: castRay's
-//     sdf = readFromSDF_float_uninterpolated(p); if (found && -0.5 <= sdf <= 0.1) sdf = readFromSDF_float_interpolated(p)
-// fused.  The rounded voxel is always one of the 8 corners of the trilinear cell (round(x) is
-// floor(x) or floor(x)+1), so when the cell lies inside one voxel block (2/3 of all samples) ONE
-// block lookup and ONE batch of 8 independent sdf loads serve both reads.  Divergent lanes of a
-// wave then serialise two memory phases per step instead of up to four.  Values and the
-// arithmetic on them are unchanged (lookups are pure functions of the table).
-// MEASURED AND REJECTED (round 1): 937 us vs 666 us for the two-phase form — kept, disabled, as
-// the record of the experiment (see the comment in cast_ray and DESIGN.md "raycast").
-#if 0
-__device__ __forceinline__ float sample_sdf_march(const SceneP &s, const FrameP &p, float x, float y, float z, bool &found,
-                                                  VoxCache &cache) {
-  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
-  if (((ix & 7) != 7) && ((iy & 7) != 7) && ((iz & 7) != 7)) {
-    int lin;
-    const int ptr = find_block(s, p, ix, iy, iz, lin, cache);
-    found = ptr >= 0;
-    if (!found) return sdf_to_float(32767.0f);
-    const short *b = reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf) + lin;
-    const short s0 = b[0], s1 = b[1], s2 = b[8], s3 = b[9], s4 = b[64], s5 = b[65], s6 = b[72], s7 = b[73];
-    const float v0 = (float)s0, v1 = (float)s1, v2 = (float)s2, v3 = (float)s3, v4 = (float)s4, v5 = (float)s5,
-                v6 = (float)s6, v7 = (float)s7;
-    // uninterpolated: voxel (ROUND(x), ROUND(y), ROUND(z))
-    const bool ox = f2i(roundf_itm(x)) != ix, oy = f2i(roundf_itm(y)) != iy, oz = f2i(roundf_itm(z)) != iz;
-    const float a0 = ox ? v1 : v0, a1 = ox ? v3 : v2, a2 = ox ? v5 : v4, a3 = ox ? v7 : v6;
-    const float b0 = oy ? a1 : a0, b1 = oy ? a3 : a2;
-    float sdfValue = sdf_to_float(oz ? b1 : b0);
-    if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) {
-      const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
-      float res1 = (1.0f - cx) * v0 + cx * v1;
-      res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v2 + cx * v3);
-      float res2 = (1.0f - cx) * v4 + cx * v5;
-      res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v6 + cx * v7);
-      sdfValue = sdf_to_float((1.0f - cz) * res1 + cz * res2);
-    }
-    return sdfValue;
-  }
-  float sdfValue = read_sdf_uninterpolated(s, p, x, y, z, found, cache);
-  if (found && (sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = read_sdf_interpolated(s, p, x, y, z, cache, cache);
-  return sdfValue;
-}
-#endif
-
 // --------------------------------------------------------- K6: expected depths
 
 __global__ __launch_bounds__(256) void k_minmax_init(float2 *__restrict__ minmax, int n, const int32_t *__restrict__ ctr,
@@ -591,13 +548,47 @@ __global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const floa
 // ------------------------------------------------------- free-view shading (K8)
 
 // ITMRepresentationAccess.h computeSingleNormalFromSDF
-__device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP &p, float x, float y, float z) {
-  VoxCache cache; cache_init(cache);
-  bool f;
+// The 32 voxels it reads lie in the 4x4x4 neighbourhood [i-1, i+2]^3, i.e. in at most 2x2x2 blocks.
+// The reference reads them one after the other through a one-entry cache that a neighbourhood
+// across a block boundary keeps evicting (76 % of the pixels): up to 32 dependent lookups.  Here
+// the <= 8 blocks are resolved first (bucket heads requested two at a time, chains then walked;
+// their indices kept in a per-thread LDS row), after which the 32 loads are independent.
+__device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                  int *__restrict__ bptr /* [8], per thread */) {
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   const float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
-#define RD(dx, dy, dz) read_sdf_raw(s, p, ix + (dx), iy + (dy), iz + (dz), f, cache)
+  const int b0x = (ix - 1) >> 3, b0y = (iy - 1) >> 3, b0z = (iz - 1) >> 3;
+  const bool fx = ((ix + 2) >> 3) != b0x, fy = ((iy + 2) >> 3) != b0y, fz = ((iz + 2) >> 3) != b0z;
+#pragma unroll
+  for (int pair = 0; pair < 4; ++pair) {  // blocks (ox, oy, oz) = (0|1, pair & 1, pair >> 1)
+    const int oy = pair & 1, oz = pair >> 1;
+    int r0 = -1, r1 = -1;
+    if (!((oy && !fy) || (oz && !fz))) {
+      const int by = b0y + oy, bz = b0z + oz;
+      int4 h0 = *reinterpret_cast<const int4 *>(s.table + hash_index(b0x, by, bz, p.hashMask)), h1 = make_int4(0, 0, 0, -2);
+      if (fx) h1 = *reinterpret_cast<const int4 *>(s.table + hash_index(b0x + 1, by, bz, p.hashMask));
+      auto resolve = [&](int4 raw, int bx) -> int {  // ITMRepresentationAccess.h findVoxel
+        while (true) {
+          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+          if (hx == bx && hy == by && hz == bz && raw.w >= 0) return raw.w;
+          if (raw.z < 1) return -1;
+          raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
+        }
+      };
+      r0 = resolve(h0, b0x);
+      if (fx) r1 = resolve(h1, b0x + 1);
+    }
+    bptr[pair * 2] = r0; bptr[pair * 2 + 1] = r1;
+  }
+  const uint8_t *vb = s.vba + kOffSdf;
+  auto rd = [&](int dx, int dy, int dz) -> float {  // readVoxel(...).sdf as float; missing voxel: TVoxel() => 32767
+    const int vx = ix + dx, vy = iy + dy, vz = iz + dz;
+    const int ptr = bptr[((vx >> 3) - b0x) | (((vy >> 3) - b0y) << 1) | (((vz >> 3) - b0z) << 2)];
+    if (ptr < 0) return 32767.0f;
+    return (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + (((vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6)) * 2));
+  };
+#define RD(dx, dy, dz) rd((dx), (dy), (dz))
   float4 front, back, tmp;
   front.x = RD(0, 0, 0); front.y = RD(1, 0, 0); front.z = RD(0, 1, 0); front.w = RD(1, 1, 0);
   back.x = RD(0, 0, 1); back.y = RD(1, 0, 1); back.z = RD(0, 1, 1); back.w = RD(1, 1, 1);
@@ -662,6 +653,7 @@ __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const Fram
 // (definitions adopted in oracle/dsr_oracle.cpp render_image()).
 __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, const float4 *__restrict__ pointsRay,
                                                 uchar4 *__restrict__ outRgba, float *__restrict__ outDepth) {
+  __shared__ int s_blocks[256][9];  // normal_from_sdf: the <= 8 blocks of a pixel's neighbourhood (row padded)
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= p.W || y >= p.H) return;
   const int locId = x + y * p.W;
@@ -682,7 +674,7 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
       float3 n = make_float3(0, 0, 0);
       float angle = 0;
       if (foundPoint) {
-        n = normal_from_sdf(s, p, pt.x, pt.y, pt.z);
+        n = normal_from_sdf(s, p, pt.x, pt.y, pt.z, s_blocks[threadIdx.x]);
         float normScale = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
         n.x *= normScale; n.y *= normScale; n.z *= normScale;
         angle = n.x * lsx + n.y * lsy + n.z * lsz;
