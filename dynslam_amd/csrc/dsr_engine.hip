@@ -143,6 +143,15 @@ struct dsr_engine {
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
   int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
+  // free-view cache: DynSLAM renders several image types from ONE pose per redraw (GetImage colour +
+  // GetFloatImage depth, InfiniTamDriver.cpp:165-209); while neither the scene nor the camera has
+  // changed, FindVisibleBlocks + CreateExpectedDepths + the raycast are reused and only the
+  // shading runs again
+  unsigned long long sceneVersion = 0;
+  bool fvValid = false;
+  unsigned long long fvVersion = 0;
+  Mat4 fvM;
+  float fvProj[4] = {0, 0, 0, 0};
   dsr_triangle *meshTris = nullptr;  // current mesh (dsr_mesh_scene), device
   uint64_t meshCount = 0;
 
@@ -274,6 +283,7 @@ void depth_proj(const dsr_engine *e, float proj[4]) {
 }
 
 int reset_scene(dsr_engine *e) {
+  e->sceneVersion++;
   LAUNCH(e, "reset", k_reset_table, dim3(div_up(e->E, 256)), dim3(256), e->scene.table, e->E, e->scene.allocKey);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noExcess, 256)), dim3(256), e->scene.excessAllocList, e->noExcess);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noBlocks, 256)), dim3(256), e->scene.voxelAllocList, e->noBlocks);
@@ -382,6 +392,7 @@ int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthD
 
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
 int allocate_scene(dsr_engine *e) {
+  e->sceneVersion++;
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
@@ -405,6 +416,7 @@ int allocate_scene(dsr_engine *e) {
 }
 
 int integrate_scene(dsr_engine *e) {
+  e->sceneVersion++;
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
@@ -882,6 +894,7 @@ int dsr_prepare(dsr_engine *e) {
 int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) {
   CHECK_E(e);
   if (min_age < 0) return fail(DSR_E_ARG, "negative min_age");
+  e->sceneVersion++;
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -955,6 +968,10 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       if (intrinsics) memcpy(proj, intrinsics, sizeof proj);
       FrameP p = make_frame_params(e, M, invM, proj);
       RenderStateDev &rs = e->freeview;
+      dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+      const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
+                          memcmp(e->fvProj, proj, sizeof proj) == 0 && !getenv("DSR_NO_FREEVIEW_CACHE");
+      if (!cached) {
       // FindVisibleBlocks: ordered compaction of entries inside the free camera's frustum
       LAUNCH(e, "freeview_visible", (k_visible_count<true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
              rs.visType, e->tileSums);
@@ -964,8 +981,9 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
              (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0);
       int st = expected_depths(e, rs, p);
       if (st) return st;
-      dim3 g(div_up(e->W, 16), div_up(e->H, 16));
       launch_raycast(e, "raycast_freeview", p, rs);
+      e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+      }
       LAUNCH(e, "render", k_render, g, dim3(256), p, e->scene, type, (const float4 *)rs.raycastResult, rs.raycastImage,
              depth_out ? e->freeDepth : (float *)nullptr);
       HIP_TRY(hipGetLastError());

@@ -295,3 +295,40 @@ def test_odd_image_sizes(hip_api, size):
         assert np.array_equal(a[1] if want_d else a[0], b[1] if want_d else b[0])
     assert np.array_equal(g.mesh_scene().view(np.uint32), o.mesh_scene().view(np.uint32))
     g.close(); o.close()
+
+
+def test_free_view_cache(hip_api):
+    """Several image types from ONE pose (what a DynSLAM redraw asks for) reuse the free-view visible
+    list, range image and raycast; a change of the scene (fusion, voxel GC, reset), of the pose or of
+    the intrinsics must invalidate them.  Every image is compared with the oracle, which always
+    recomputes."""
+    sc, g, o = make_pair()
+    for i in range(3):
+        feed((g, o), sc, i)
+
+    def same_images(pose, intr=None):
+        for t in RENDER_TYPES + RENDER_TYPES[:2]:
+            want_depth = t == _capi.IMAGE_FREECAMERA_DEPTH
+            a = g.get_image(t, pose_m=pose, intrinsics=intr, want_rgba=True, want_depth=want_depth)
+            b = o.get_image(t, pose_m=pose, intrinsics=intr, want_rgba=True, want_depth=want_depth)
+            assert np.array_equal(a[0], b[0]), t
+            if want_depth:
+                assert np.array_equal(a[1], b[1])
+        assert_render_equal(g, o, freeview=True)
+
+    pose_a = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
+    pose_b = np.linalg.inv(sc.pose(2).astype(np.float64)).astype(np.float32)
+    same_images(pose_a)
+    same_images(pose_b)                                   # new pose
+    fx, fy, cx, cy = sc.intrinsics()
+    same_images(pose_b, np.array([fx * 0.8, fy * 0.8, cx, cy], np.float32))  # new intrinsics
+    feed((g, o), sc, 3)                                   # the scene changed
+    same_images(pose_b)
+    for e in (g, o):
+        e.decay(2, 0, True)                               # voxel GC changed it again
+    same_images(pose_b)
+    for e in (g, o):
+        e.reset_scene()
+    feed((g, o), sc, 4)
+    same_images(pose_b)
+    g.close(); o.close()
