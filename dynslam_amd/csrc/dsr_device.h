@@ -50,7 +50,8 @@ enum Ctr {
   CTR_MESH_TOTAL = 13,        // triangles of the running MeshScene
   CTR_HOST_USED = 14,         // slots of the host store (ITMGlobalCache) handed out so far
   CTR_SWAP_FIRST_SLOT = 15,   // first host slot of the running swap-out batch
-  CTR_COUNT = 16
+  CTR_NO_ALLOCATED = 16,      // length of the cached list of allocated entries (free-view culling)
+  CTR_COUNT = 32
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)
 enum Work {

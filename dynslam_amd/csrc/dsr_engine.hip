@@ -148,6 +148,8 @@ struct dsr_engine {
   // changed, FindVisibleBlocks + CreateExpectedDepths + the raycast are reused and only the
   // shading runs again
   unsigned long long sceneVersion = 0;
+  int32_t *allocList = nullptr;              // ascending list of the allocated entries, valid for allocListVersion
+  unsigned long long allocListVersion = ~0ull;
   bool fvValid = false;
   unsigned long long fvVersion = 0;
   Mat4 fvM;
@@ -313,7 +315,7 @@ void free_all(dsr_engine *e) {
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
-  F(e->tileSums); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
+  F(e->tileSums); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
@@ -699,6 +701,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->freeDepth, (size_t)e->P));
   ALLOC(dmalloc(&e->decayFlags, (size_t)e->noBlocks));
   ALLOC(dmalloc(&e->decayCand, (size_t)e->noBlocks));
+  ALLOC(dmalloc(&e->allocList, (size_t)e->noBlocks));
   if (s.use_swapping) {
     ALLOC(dmalloc(&e->scene.swapState, (size_t)e->E));
     ALLOC(dmalloc(&e->scene.swapStored, (size_t)e->E));
@@ -972,13 +975,25 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
                           memcmp(e->fvProj, proj, sizeof proj) == 0 && !getenv("DSR_NO_FREEVIEW_CACHE");
       if (!cached) {
-      // FindVisibleBlocks: ordered compaction of entries inside the free camera's frustum
-      LAUNCH(e, "freeview_visible", (k_visible_count<true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
-             rs.visType, e->tileSums);
-      LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+      // FindVisibleBlocks: the allocated entries (ascending list, rebuilt when the scene has changed)
+      // are tested densely against the free camera's frustum, the visible ones compacted in order
+      if (e->allocListVersion != e->sceneVersion) {
+        LAUNCH(e, "allocated_list", k_allocated_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
+        LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+               (int)SCAN_ALLOCATED, e->noBlocks);
+        LAUNCH(e, "allocated_list", k_allocated_write, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E,
+               (const int2 *)e->tileSums, e->allocList, e->noBlocks);
+        e->allocListVersion = e->sceneVersion;
+      }
+      const int32_t *nAlloc = e->scene.ctr + CTR_NO_ALLOCATED;
+      LAUNCH(e, "freeview_visible", k_freeview_test, dim3(4096), dim3(256), p, e->scene, (const int32_t *)e->allocList, nAlloc,
+             e->decayFlags);
+      LAUNCH(e, "freeview_visible", k_flag_count, dim3(e->numTilesB), dim3(kTileThreads), (const uint8_t *)e->decayFlags, nAlloc,
+             e->tileSums);
+      LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene,
              (int)SCAN_VISIBLE_FREE, e->noBlocks);
-      LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E,
-             (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0);
+      LAUNCH(e, "freeview_visible", k_flag_write, dim3(e->numTilesB), dim3(kTileThreads), (const int32_t *)e->allocList,
+             (const uint8_t *)e->decayFlags, nAlloc, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
       int st = expected_depths(e, rs, p);
       if (st) return st;
       launch_raycast(e, "raycast_freeview", p, rs);

@@ -206,7 +206,7 @@ __device__ __forceinline__ void alloc_winner_pos(const FrameP &p, const float *_
 }
 
 // Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
-enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7, SCAN_MESH = 8 };
+enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7, SCAN_MESH = 8, SCAN_ALLOCATED = 9 };
 __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tileSums, int numTiles, SceneP s, int mode,
                                                          int capacity) {
   __shared__ int2 lds[1024 / 64];
@@ -251,6 +251,8 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
         ctr[CTR_SWAP_FIRST_SLOT] = ctr[CTR_HOST_USED];  // the batch takes the next n host slots, in list order
         ctr[CTR_HOST_USED] += n;
       }
+    } else if (mode == SCAN_ALLOCATED) {
+      ctr[CTR_NO_ALLOCATED] = carry.x < capacity ? carry.x : capacity;
     } else if (mode == SCAN_MESH) {
       ctr[CTR_MESH_TOTAL] = carry.x;
     } else if (mode == SCAN_NCAND) {
