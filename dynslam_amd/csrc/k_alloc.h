@@ -211,13 +211,32 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
                                                          int capacity) {
   __shared__ int2 lds[1024 / 64];
   int2 carry = make_int2(0, 0);
-  for (int base = 0; base < numTiles; base += 1024) {
-    int i = base + threadIdx.x;
-    int2 v = (i < numTiles) ? tileSums[i] : make_int2(0, 0);
-    int2 total;
-    int2 ex = wg_exclusive_scan2<1024>(v, total, lds);
-    if (i < numTiles) tileSums[i] = make_int2(carry.x + ex.x, carry.y + ex.y);
-    carry.x += total.x; carry.y += total.y;
+  constexpr int kPer = 8;
+  if (numTiles <= 1024 * kPer) {
+    // the usual case (<= 8192 tiles = 16.8 M entries): 8 consecutive sums per thread, ONE workgroup scan
+    const int base = threadIdx.x * kPer;
+    int2 v[kPer];
+    int2 sum = make_int2(0, 0);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      v[j] = (base + j < numTiles) ? tileSums[base + j] : make_int2(0, 0);
+      sum.x += v[j].x; sum.y += v[j].y;
+    }
+    int2 run = wg_exclusive_scan2<1024>(sum, carry, lds);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+      if (base + j < numTiles) tileSums[base + j] = run;
+      run.x += v[j].x; run.y += v[j].y;
+    }
+  } else {
+    for (int base = 0; base < numTiles; base += 1024) {
+      int i = base + threadIdx.x;
+      int2 v = (i < numTiles) ? tileSums[i] : make_int2(0, 0);
+      int2 total;
+      int2 ex = wg_exclusive_scan2<1024>(v, total, lds);
+      if (i < numTiles) tileSums[i] = make_int2(carry.x + ex.x, carry.y + ex.y);
+      carry.x += total.x; carry.y += total.y;
+    }
   }
   if (threadIdx.x == 0) {
     int32_t *ctr = s.ctr;
