@@ -283,7 +283,7 @@ def main():
                             "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                             "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 item
             try:
                 cpu = cpu_baseline(frames, W, H, args.preset, args.cpu_budget_s)
             except Exception as ex:  # the baseline must never take the bench line down
