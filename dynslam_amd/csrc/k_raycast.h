@@ -428,7 +428,8 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         //  trilinear sample until 1..48 of them can take it together, 607..896 us; giving each XCD a
         //  band of tile columns (workgroup i -> XCD i % 8), 533 vs 512 us; inside runs of misses
         //  prefetching the word of a 1 MB bucket-occupancy bitmap instead of the 16 B entry (a clear
-        //  bit is a sure miss: no table read at all), 634 us.  Every variant
+        //  bit is a sure miss: no table read at all), 634 us; workgroups of 64 / 512 / 1024 threads
+        //  (1 / 8 / 16 neighbouring tiles) instead of 256: 601 / 536 / 519 vs 488 us.  Every variant
         //  that adds requests or iterations loses: the march is bound by gather-request
         //  throughput and by the per-wave chain of dependent round trips.)
       }
