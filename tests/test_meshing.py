@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from dynslam_amd.engine import InfiniTamDriver, default_settings, make_calib
+from dynslam_amd.engine import InfiniTamDriver, make_calib
 from tests.common import SMALL, feed, make_pair
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
