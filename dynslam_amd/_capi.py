@@ -66,7 +66,8 @@ class Stats(C.Structure):
         ("no_total_entries", C.c_int32), ("voxel_bytes", C.c_int32), ("block_voxels", C.c_int32),
         ("sticky_status", C.c_int32), ("decayed_block_count", C.c_int64),
         ("frames_processed", C.c_int64), ("no_visible_blocks_freeview", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("host_store_slots", C.c_int32), ("host_store_capacity_slots", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -27,7 +27,6 @@
 #include "k_edges.h"
 #include "k_integrate.h"
 #include "k_raycast.h"
-#include "k_raycast_lds.h"
 #include "k_swap.h"
 #include "k_mesh.h"
 
@@ -129,13 +128,6 @@ struct dsr_engine {
   // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
-  // k_integrate variant = voxels per lane x waves per SIMD.  48 (half block per wave, 62 VGPRs,
-  // 8 waves/SIMD): 757 us at the 5 mm bench; 85 (whole block per wave, 94 VGPRs, 5 waves): 797 us.
-  int integrateVariant = 87;
-  // 0 = per-lane raycast (default, 0.66 ms at the 5 mm bench); 2/4/8 = experimental wave-cooperative
-  // LDS cache of sdf planes (k_raycast_lds.h: bit-exact, measured 1.5 ms — kept selectable through
-  // env DSR_RAYCAST_SLOTS for further work)
-  int raycastSlots = 0;
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
@@ -193,7 +185,8 @@ struct dsr_engine {
   // silhouette masks (instance view split)
   uint8_t *maskScratch = nullptr;
   size_t maskCap = 0;
-  hipEvent_t xEvent = nullptr;       // orders the instance stream after a view split
+  hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
+  hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
   uint8_t *decayFlags = nullptr;
 
   // profiling
@@ -295,6 +288,7 @@ int reset_scene(dsr_engine *e) {
   if (e->scene.swapState) {
     HIP_TRY(hipMemsetAsync(e->scene.swapState, 0, (size_t)e->E, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.swapStored, 0, (size_t)e->E, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scene.swapSlot, 0xff, (size_t)e->E * 4, e->stream));  // -1: the entry owns no host slot yet
     HIP_TRY(hipStreamSynchronize(e->stream));
     // the slabs are kept; the slot counter restarts with the counters
     e->hostUsedUpper = 0; e->hostUsedPending = false; e->hostUsedCallsSince = 0;
@@ -325,6 +319,7 @@ void free_all(dsr_engine *e) {
   if (e->hostUsedEvent) (void)hipEventDestroy(e->hostUsedEvent);
   for (auto p : e->hostSlabs) (void)hipHostFree(p);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
+  if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -430,13 +425,7 @@ int integrate_scene(dsr_engine *e) {
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
     else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC); else LAUNCH_INTEGRATE(false, false, VOX, OCC); }         \
   } while (0)
-  switch (e->integrateVariant) {  // voxels per lane x waves per SIMD (env DSR_INTEGRATE_VARIANT)
-    case 48: LAUNCH_INTEGRATE_V(4, 8); break;
-    case 46: LAUNCH_INTEGRATE_V(4, 6); break;
-    case 86: LAUNCH_INTEGRATE_V(8, 6); break;
-    case 85: LAUNCH_INTEGRATE_V(8, 5); break;
-    default: LAUNCH_INTEGRATE_V(8, 7); break;
-  }
+  LAUNCH_INTEGRATE_V(8, 7);  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h)
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
@@ -462,15 +451,13 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
 
 int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderStateDev &rs) {
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  if (e->raycastSlots == 8)
-    LAUNCH(e, name, (k_raycast_lds<8>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
-  else if (e->raycastSlots == 4)
-    LAUNCH(e, name, (k_raycast_lds<4>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
-  else if (e->raycastSlots == 2)
-    LAUNCH(e, name, (k_raycast_lds<2>), g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
-  else
-    LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
   return DSR_OK;
+}
+
+const char *status_text(int status) {
+  return status == DSR_E_OUT_OF_BLOCKS ? "out of voxel blocks / excess list entries"
+                                       : "allocation ray longer than the order key allows: the pose is not rigid (k_alloc.h)";
 }
 
 int sticky_status(dsr_engine *e, int *status) {
@@ -656,13 +643,11 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (S * (double)e->P >= 4294967295.0) { delete e; return fail(DSR_E_ARG, "mu/voxel_size ratio too large for the 32-bit allocation key"); }
     e->maxSteps = (uint32_t)S;
   }
-  if (const char *rs = getenv("DSR_RAYCAST_SLOTS")) e->raycastSlots = atoi(rs);
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
-  if (const char *iv = getenv("DSR_INTEGRATE_VARIANT")) e->integrateVariant = atoi(iv);
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();
@@ -842,7 +827,7 @@ int dsr_allocate_scene_from_depth(dsr_engine *e) {
     int status = DSR_OK;
     st = sticky_status(e, &status);
     if (st) return st;
-    if (status != DSR_OK) return fail(status, "out of voxel blocks / excess list entries");
+    if (status != DSR_OK) return fail(status, status_text(status));
   }
   return DSR_OK;
 }
@@ -872,7 +857,7 @@ int dsr_process_frame(dsr_engine *e) {
     if (status != DSR_OK) {
       // the fork throws per failing frame: clear the sticky word after reporting it
       (void)hipMemsetAsync(e->scene.ctr + CTR_STATUS, 0, 4, e->stream);
-      return fail(status, "out of voxel blocks / excess list entries");
+      return fail(status, status_text(status));
     }
   }
   return DSR_OK;
@@ -1103,14 +1088,19 @@ int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, c
   if (st) return st;
   dsr_engine *e = main_engine;
   // runs on the MAIN engine's stream (ordered after the view's producer and before any later
-  // blanking); the instance stream then waits for it
+  // blanking); the instance stream then waits for it.  The kernel OVERWRITES the instance's view,
+  // which work already queued on the instance's stream (the previous frame's integrate, a set_view
+  // copy) may still be reading: the main stream first waits for that work.
+  if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(instance->xEvent, instance->stream));
+  HIP_TRY(hipStreamWaitEvent(e->stream, instance->xEvent, 0));
   LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
          (const uchar4 *)e->rgb, (const float *)e->depth, instance->rgb, instance->depth, e->W, e->H,
          (const uint8_t *)e->maskScratch, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
-  if (!e->xEvent) HIP_TRY(hipEventCreateWithFlags(&e->xEvent, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(e->xEvent, e->stream));
-  HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent, 0));
+  if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->xEvent2, e->stream));
+  HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent2, 0));
   instance->hasView = true;
   return DSR_OK;
 }
@@ -1415,6 +1405,8 @@ int dsr_get_stats(dsr_engine *e, dsr_stats *out) {
   out->decayed_block_count = (int64_t)work[WORK_DECAYED_BLOCKS];
   out->frames_processed = e->framesProcessed;
   out->no_visible_blocks_freeview = ctr[CTR_NO_VISIBLE_FREE];
+  out->host_store_slots = e->s.use_swapping ? ctr[CTR_HOST_USED] : 0;
+  out->host_store_capacity_slots = (int32_t)std::min<long long>((long long)e->hostSlabs.size() * e->scene.slabBlocks, 0x7fffffff);
   return DSR_OK;
 }
 

@@ -132,6 +132,13 @@ __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const fl
   if (x >= p.W || y >= p.H) return;
   AllocRay r;
   if (!alloc_ray(p, depth, x, y, r)) return;
+  if ((uint32_t)(r.noSteps > 0 ? r.noSteps : 0) > p.maxSteps) {
+    // the order key holds maxSteps steps per pixel (bound derived for a rigid pose, dsr_engine.hip):
+    // a scaled / non-orthonormal pose would make the commit replay the wrong step — report it
+    // instead of writing a wrong block position
+    s.ctr[CTR_STATUS] = DSR_E_ARG;
+    return;
+  }
   const uint32_t keyBase = (uint32_t)(x + y * p.W) * p.maxSteps + 1u;
   float px = r.px, py = r.py, pz = r.pz;
   // The steps of a ray are independent (stores of the same value, atomicMax, exactly-once counting),
@@ -177,7 +184,7 @@ __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const fl
           const bool isExcess = firstFree < 0;
           const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
           if (!isExcess) visType[target] = 1;
-          uint32_t step = (uint32_t)i < p.maxSteps ? (uint32_t)i : p.maxSteps - 1u;
+          const uint32_t step = (uint32_t)i;  // < maxSteps (checked above)
           // the first writer of an entry in this frame (its key is still 0) also counts it: per group
           // of 8 entries and per sweep tile, so that the commit finds the ~1 % marked entries
           // without reading all the keys
@@ -267,8 +274,9 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
       if (mode == SCAN_SWAP_OUT) {
         ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];
         ctr[CTR_LAST_FREE_BLOCK] += n;
-        ctr[CTR_SWAP_FIRST_SLOT] = ctr[CTR_HOST_USED];  // the batch takes the next n host slots, in list order
-        ctr[CTR_HOST_USED] += n;
+        // first host slot for the entries of this batch that do not own one yet (k_swap.h
+        // k_swap_write<true> hands them out in list order and advances CTR_HOST_USED)
+        ctr[CTR_SWAP_FIRST_SLOT] = ctr[CTR_HOST_USED];
       }
     } else if (mode == SCAN_ALLOCATED) {
       ctr[CTR_NO_ALLOCATED] = carry.x < capacity ? carry.x : capacity;
@@ -301,9 +309,11 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP 
   const uint32_t byte = (word >> (((base >> 3) & 3) * 8)) & 0xffu;
   const int2 c = make_int2((int)(byte & 15u), (int)(byte >> 4));
   if (word != 0u && (threadIdx.x & 3) == 0) *grpWord = 0u;  // ready for the next frame
+  // every thread reads the tile offset BEFORE the scan: the scan's __syncthreads() then orders all
+  // these loads before thread 0 clears the word for the next frame's marks
+  const int2 tileOff = tileOffsets[blockIdx.x];
   int2 total;
   int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
-  const int2 tileOff = tileOffsets[blockIdx.x];
   if (threadIdx.x == 0) tileOffsets[blockIdx.x] = make_int2(0, 0);  // k_alloc_mark accumulates into it again
   if (c.x == 0) return;
   int rank12 = tileOff.x + ex.x, rank2 = tileOff.y + ex.y;

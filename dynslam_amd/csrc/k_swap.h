@@ -14,8 +14,11 @@
 //
 // The host store is a pool of PINNED host slabs (16384 plane-wise 4 KiB blocks each by default) that the
 // GPU addresses directly: swap-out kernels write blocks into it over the host link, swap-in
-// kernels read them back, slots are handed out by a device counter in list order and remembered
-// per entry (swapSlot).  The host never learns the lists: no round trip, no synchronisation —
+// kernels read them back.  As in upstream's ITMGlobalCache an entry OWNS ONE SLOT for the life of the
+// scene (swapSlot[entry], -1 until its first swap-out): it is handed out once, by a device counter in
+// list order, and every later swap-out of that entry — also after voxel GC dropped the copy or a
+// tombstone was reused for another block — overwrites it, so the store is bounded by the number of
+// entries that were ever swapped out instead of growing by up to 16 MiB per frame.  The host never learns the lists: no round trip, no synchronisation —
 // ITMDenseMapper::ProcessFrame stays asynchronous with swapping on.  (Upstream copies counts and
 // id lists to the host and memcpys every block through a staging buffer each frame.)
 #pragma once
@@ -42,10 +45,13 @@ __global__ __launch_bounds__(kTileThreads) void k_swap_count(SceneP s, int noTot
                                                              int2 *__restrict__ tileSums) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
-  int2 c = make_int2(0, 0);
+  int2 c = make_int2(0, 0);  // x: candidates, y (swap-out): those that do not own a host slot yet
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
-    if (base + j < noTotalEntries && swap_candidate<OUT>(s, base + j, visType)) c.x++;
+    if (base + j < noTotalEntries && swap_candidate<OUT>(s, base + j, visType)) {
+      c.x++;
+      if (OUT && s.swapSlot[base + j] < 0) c.y++;
+    }
   int2 total;
   wg_exclusive_scan2<kTileThreads>(c, total, lds);
   if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
@@ -58,25 +64,36 @@ __global__ __launch_bounds__(kTileThreads) void k_swap_write(SceneP s, int noTot
                                                              int32_t *__restrict__ ids, uint8_t *__restrict__ storedFlags) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
-  bool cand[kTileItems];
+  bool cand[kTileItems], fresh[kTileItems];
   int2 c = make_int2(0, 0);
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j) {
     cand[j] = base + j < noTotalEntries && swap_candidate<OUT>(s, base + j, visType);
+    fresh[j] = OUT && cand[j] && s.swapSlot[base + j] < 0;
     if (cand[j]) c.x++;
+    if (fresh[j]) c.y++;
   }
   int2 total;
   int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
   if (total.x == 0) return;
-  int rank = tileOffsets[blockIdx.x].x + ex.x;
+  const int2 off = tileOffsets[blockIdx.x];
+  int rank = off.x + ex.x, freshRank = off.y + ex.y;
+  const int firstSlot = OUT ? s.ctr[CTR_SWAP_FIRST_SLOT] : 0;
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
     if (cand[j]) {
       if (rank < kTransferBlocks) {
         ids[rank] = base + j;
         if (!OUT) storedFlags[rank] = s.swapStored[base + j];
+        if (fresh[j]) {
+          // first swap-out of this entry: it takes the next host slot, in list order (every candidate
+          // before it is inside the cap too, so freshRank counts exactly the slots handed out before)
+          s.swapSlot[base + j] = firstSlot + freshRank;
+          atomicMax(&s.ctr[CTR_HOST_USED], firstSlot + freshRank + 1);
+        }
       }
       rank++;
+      if (fresh[j]) freshRank++;
     }
 }
 
@@ -155,11 +172,11 @@ __global__ __launch_bounds__(256) void k_swapin_combine(SceneP s, int maxW, cons
   }
 }
 
-// copy the block into its host slot, reset it, return it to the free list (list order = entry
-// order: slot oldHead + 1 + i), ptr = -1, state 0, mark the host store as holding it
+// copy the block into the entry's host slot (k_swap_write<true> gave it one if it had none), reset it,
+// return it to the free list (list order = entry order: slot oldHead + 1 + i), ptr = -1, state 0,
+// mark the host store as holding it
 __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *__restrict__ ids) {
   const int n = s.ctr[CTR_SWAP_COUNT];
-  const int firstSlot = s.ctr[CTR_SWAP_FIRST_SLOT];
   const int oldHead = s.ctr[CTR_ALLOC_OLD_HEAD_VBA];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *_
     const int id = __builtin_amdgcn_readfirstlane(ids[i]);
     const int ptr = s.table[id].ptr;
     uint4 *blk = reinterpret_cast<uint4 *>(s.vba + (size_t)ptr * kBlockBytes);
-    uint4 *dst = reinterpret_cast<uint4 *>(host_block(s, firstSlot + i));
+    uint4 *dst = reinterpret_cast<uint4 *>(host_block(s, s.swapSlot[id]));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {  // 256 x 16 B per block
       const int v = k * 64 + lane;
@@ -181,7 +198,6 @@ __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *_
       s.table[id].ptr = -1;
       s.swapState[id] = 0;
       s.swapStored[id] = 1;
-      s.swapSlot[id] = firstSlot + i;
     }
   }
 }

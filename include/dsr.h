@@ -145,7 +145,10 @@ typedef struct dsr_stats {
   int64_t decayed_block_count;        /* denseMapper->GetDecayedBlockCount()        */
   int64_t frames_processed;
   int32_t no_visible_blocks_freeview;
-  int32_t reserved[5];
+  int32_t host_store_slots;           /* ITMGlobalCache: 4 KiB block slots handed out so far (one per
+                                         entry ever swapped out; 0 without use_swapping)           */
+  int32_t host_store_capacity_slots;  /* slots the allocated (pinned) host store can hold          */
+  int32_t reserved[3];
 } dsr_stats;
 
 typedef struct dsr_engine dsr_engine; /* opaque: one ITMMainEngine (scene + render

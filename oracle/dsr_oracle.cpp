@@ -204,6 +204,8 @@ struct Engine {
   std::vector<uint8_t> swapStates;
   std::vector<uint8_t> hasStored;
   std::unordered_map<int, std::vector<dsr_voxel>> storedBlocks;
+  std::vector<uint8_t> ownsSlot; /* ITMGlobalCache keeps one fixed slot per entry: entries ever swapped out */
+  int hostStoreSlots = 0;
 
   int threads = 1;
 };
@@ -234,6 +236,8 @@ static void reset_scene(Engine &e) {
   std::fill(e.swapStates.begin(), e.swapStates.end(), 0);
   std::fill(e.hasStored.begin(), e.hasStored.end(), 0);
   e.storedBlocks.clear();
+  std::fill(e.ownsSlot.begin(), e.ownsSlot.end(), 0);
+  e.hostStoreSlots = 0;
   e.stickyStatus = DSR_OK;
 }
 
@@ -1172,6 +1176,7 @@ static void swap_out(Engine &e) {
       dsr_voxel *blk = &e.voxels[(size_t)localPtr * DSR_BLOCK_SIZE3];
       e.storedBlocks[t].assign(blk, blk + DSR_BLOCK_SIZE3);
       e.hasStored[t] = 1;
+      if (!e.ownsSlot[t]) { e.ownsSlot[t] = 1; e.hostStoreSlots++; }
       e.swapStates[t] = 0;
       int vbaIdx = noAllocatedVoxelEntries;
       if (vbaIdx < e.noBlocks - 1) {
@@ -1289,7 +1294,7 @@ int orc_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e.voxels.resize((size_t)e.noBlocks * DSR_BLOCK_SIZE3);
     e.voxelAllocationList.resize(e.noBlocks);
     e.entriesAllocType.resize(e.noTotalEntries);
-    if (s.use_swapping) { e.swapStates.assign(e.noTotalEntries, 0); e.hasStored.assign(e.noTotalEntries, 0); }
+    if (s.use_swapping) { e.swapStates.assign(e.noTotalEntries, 0); e.hasStored.assign(e.noTotalEntries, 0); e.ownsSlot.assign(e.noTotalEntries, 0); }
     e.blockCoords.resize(4 * (size_t)e.noTotalEntries);
     const int mw = (e.W + 7) / 8, mh = (e.H + 7) / 8;
     for (RenderState *rs : {&e.live, &e.freeview}) {
@@ -1601,6 +1606,8 @@ int orc_get_stats(dsr_engine *h, dsr_stats *out) {
   out->decayed_block_count = E.decayedBlockCount;
   out->frames_processed = E.framesProcessed;
   out->no_visible_blocks_freeview = E.freeview.noVisibleBlocks;
+  out->host_store_slots = E.hostStoreSlots;
+  out->host_store_capacity_slots = E.hostStoreSlots;
   return DSR_OK;
 }
 

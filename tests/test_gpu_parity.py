@@ -177,20 +177,6 @@ def test_division_selftest(hip_api):
     assert bad.value == 0
 
 
-def test_lds_raycast_variant(hip_api, monkeypatch):
-    """The experimental wave-cooperative LDS raycast (k_raycast_lds.h, off by default) must give
-    the same bits as the oracle too."""
-    monkeypatch.setenv("DSR_RAYCAST_SLOTS", "4")
-    sc, g, o = make_pair()
-    for i in range(4):
-        feed((g, o), sc, i)
-    assert_render_equal(g, o)
-    pose = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
-    ig, dg = g.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
-    io, do = o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=pose, want_depth=True)
-    assert np.array_equal(ig, io) and np.array_equal(dg, do)
-
-
 def test_device_resident_view_equals_host_view(hip_api):
     """dsr_update_view_dev / dsr_set_view_float_dev (the entry bench.py and the multi-GPU path use: inputs
     already in HBM) give the same view and the same scene as the host-buffer entry points — through

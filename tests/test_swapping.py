@@ -108,6 +108,9 @@ def test_gpu_swapping_parity(hip_api, oracle_lib, decay):
     ht = o.dump_hash_table()
     st, hs = o.dump_swap_state()
     assert hs.sum() > 1000
+    # ITMGlobalCache: one slot per entry for the life of the scene — the backward half of the drive
+    # swaps the same entries out again and must reuse their slots (no growth per frame)
+    assert g.get_stats().host_store_slots == o.get_stats().host_store_slots
     for t in np.nonzero(hs)[0][::37].tolist():
         assert np.array_equal(g.dump_stored_block(t), o.dump_stored_block(t))
     assert g.dump_stored_block(int(np.nonzero(hs == 0)[0][0])) is None
@@ -160,3 +163,44 @@ def test_gpu_host_store_grows_slab_by_slab(hip_api, oracle_lib, monkeypatch):
         for e in (g, o):
             e.reset_scene()
     g.close(); o.close()
+
+
+def test_oracle_host_store_is_bounded_by_entries(oracle_lib):
+    """Driving back and forth swaps the same entries out again and again; the store holds one
+    slot per entry that was ever out, not one per transfer."""
+    sc, e = oracle_engine()
+    ever = np.zeros(0x10000 + 0x4000, dtype=bool)
+    slots = []
+    for rnd in range(2):
+        for i in SEQ:
+            step(e, sc, i)
+            ever |= e.dump_swap_state()[1] == 1
+        slots.append(e.get_stats().host_store_slots)
+        assert slots[-1] == int(ever.sum()) > 1000
+    # the second lap swaps ~6000 blocks out again and needs only the slots of the few entries it
+    # sees for the first time
+    assert slots[1] - slots[0] < 0.05 * slots[0]
+
+
+@pytest.mark.gpu
+def test_gpu_host_store_slots_are_reused(hip_api, oracle_lib):
+    """every swap-out used to take fresh slots (up to 16 MiB of pinned memory per frame,
+    for ever).  Two laps over the same street: the second lap re-uses the slots of the first, with
+    voxel GC dropping host copies in between as well."""
+    for decay in (None, (1, 2)):
+        sc, g = hip_engine()
+        sc, o = oracle_engine()
+        laps = []
+        for rnd in range(2):
+            for i in SEQ:
+                for e in (g, o):
+                    step(e, sc, i, decay)
+            laps.append((g.get_stats().host_store_slots, o.get_stats().host_store_slots))
+        assert laps[0][0] == laps[0][1] > 1000 and laps[1][0] == laps[1][1], laps
+        assert laps[1][0] - laps[0][0] < 0.05 * laps[0][0]  # the second lap re-uses the first lap's slots
+        st = g.get_stats()
+        assert st.host_store_capacity_slots >= st.host_store_slots
+        hs = o.dump_swap_state()[1]
+        for t in np.nonzero(hs)[0][::41].tolist():
+            assert np.array_equal(g.dump_stored_block(t), o.dump_stored_block(t))
+        g.close(); o.close()
