@@ -65,23 +65,26 @@ def make_frames(w, h, n, n_inst=0):
         return pool.map(_gen_frame, [(w, h, i, n_inst) for i in range(n)])
 
 
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_h_bench5mm_pmc_traffic.json")
-
-
-def pmc_traffic(args, kernel):
+def pmc_traffic(args, kernel, visible_blocks_per_launch):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
     WRITE_SIZE, separate passes, MI355X_MICROARCH.md corrections; summarised by the round's
-    profiling run into profiles/).  PMC counters cannot be collected from inside this process, so
-    the figure is only reported for the exact command those passes profiled."""
-    same_cmd = (args.preset == "5mm" and args.width == 1242 and args.height == 375 and args.steps == 45
-                and args.warmup == 5 and not args.decay and not args.swap and not args.instances and args.gpus == 1)
-    if not same_cmd or not os.path.exists(PMC_TRAFFIC_FILE):
-        return None
-    try:
-        k = json.load(open(PMC_TRAFFIC_FILE))["kernels"].get(kernel)
-        return round(k["hbm_bytes"], 0) if k else None
-    except Exception:
-        return None
+    profiling run into profiles/).  PMC counters cannot be collected from inside this process.
+    k_integrate's traffic is proportional to the visible blocks it walks, so the profile stores
+    bytes PER VISIBLE BLOCK (measured over the profiled launches) and the figure reported here is
+    that x this run's visible blocks per launch — valid for any --steps / --warmup of the same
+    workload (preset, image size, static map only).  Returns (bytes per launch, source file)."""
+    if args.width != 1242 or args.height != 375 or args.decay or args.swap or args.instances:
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench{args.preset}_pmc_traffic.json")))
+    for f in reversed(files):  # newest set that has the per-block figure
+        try:
+            k = json.load(open(f))["kernels"].get(kernel)
+            if k and k.get("hbm_bytes_per_visible_block"):
+                return round(k["hbm_bytes_per_visible_block"] * visible_blocks_per_launch, 0), os.path.relpath(f, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def settings_kwargs(preset):
@@ -90,10 +93,7 @@ def settings_kwargs(preset):
     return kw
 
 
-def cpu_baseline(frames, w, h, preset, budget_s):
-    """The CPU oracle (kind "port": our restatement of ITMSceneReconstructionEngine_CPU +
-    ITMVisualisationEngine_CPU; the reference's own engines are not in /root/reference) on
-    the first frames of the same sequence, single thread, bounded by budget_s."""
+def _cpu_run(frames, w, h, preset, budget_s, threads):
     from dynslam_amd.engine import make_calib
     from dynslam_amd.synth import StreetScene
     from oracle.oracle import OracleEngine, oracle_settings
@@ -103,7 +103,7 @@ def cpu_baseline(frames, w, h, preset, budget_s):
     kw["hash_bucket_num"] = min(kw["hash_bucket_num"], 1 << 22)
     kw["excess_list_size"] = min(kw["excess_list_size"], 1 << 20)
     sc = StreetScene(w, h)
-    e = OracleEngine(oracle_settings(**kw), make_calib(*sc.intrinsics(), w, h), threads=1)
+    e = OracleEngine(oracle_settings(**kw), make_calib(*sc.intrinsics(), w, h), threads=threads)
     done, t_total = 0, 0.0
     for rgba, d, T, _ in frames:
         e.update_view(rgba, d)
@@ -116,14 +116,26 @@ def cpu_baseline(frames, w, h, preset, budget_s):
         e.prepare()
         t_total += time.perf_counter() - t0
         done += 1
-        if t_total > budget_s:
+        if t_total > budget_s or done >= 12:  # the sample's voxel array holds ~12 frames at 5 mm
             break
     e.close()
-    if done == 0:
+    return done, t_total
+
+
+def cpu_baseline(frames, w, h, preset, budget_s):
+    """The CPU oracle (kind "port": our restatement of ITMSceneReconstructionEngine_CPU +
+    ITMVisualisationEngine_CPU, whose loops are `#pragma omp parallel for` like upstream's; the
+    reference's own engines are not in /root/reference) on the first frames of the same sequence:
+    once on ALL host cores (`value`, `cores`), once on one thread, each bounded by budget_s."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    d1, t1 = _cpu_run(frames, w, h, preset, budget_s, 1)
+    dn, tn = _cpu_run(frames, w, h, preset, budget_s, cores) if cores > 1 else (d1, t1)
+    if d1 == 0 or dn == 0:
         return None
-    return {"value": done / t_total, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"first {done} frames of the same sequence ({w}x{h}, preset {preset}), "
-                      f"allocate+integrate+raycast, oracle/dsr_oracle.cpp single thread, {t_total:.1f} s"}
+    return {"value": round(dn / tn, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_value": round(d1 / t1, 4),
+            "sample": f"first {dn} frames of the same sequence ({w}x{h}, preset {preset}), allocate+integrate+raycast, "
+                      f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {tn:.1f} s; single thread: first {d1} frames, {t1:.1f} s"}
 
 
 def main():
@@ -134,7 +146,7 @@ def main():
     ap.add_argument("--preset", default="5mm", choices=sorted(PRESETS))
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--height", type=int, default=375)
-    ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="per CPU leg (all cores, one thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--profile-all", action="store_true",
@@ -177,23 +189,16 @@ def main():
     poses = [f[2] for f in frames]
     torch.cuda.synchronize()
 
-    # measured device-to-device copy bandwidth of this GPU (1 GiB, read + write), reported next to
-    # the nominal 8 TB/s peak the roofline fraction is quoted against
+    # measured device-to-device copy bandwidth of this GPU with the library's float4 grid-stride copy
+    # (MI355X_MICROARCH.md: 6.29 TB/s for that kernel), 1 GiB read + 1 GiB written per pass, reported
+    # next to the nominal 8 TB/s the roofline fraction is quoted against
     copy_gbs = None
     if rank == 0:
-        a = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        b = torch.empty_like(a)
-        b.copy_(a)
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(5):
-            b.copy_(a)
-        ev1.record()
-        torch.cuda.synchronize()
-        copy_gbs = round(5 * 2 * a.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9, 1)
-        del a, b
-        torch.cuda.empty_cache()
+        import ctypes as C
+        from dynslam_amd.engine import load_hip_api
+        g = C.c_double(0.0)
+        if load_hip_api().measure_copy_bandwidth(local_rank, 1 << 30, 10, C.byref(g)) == 0:
+            copy_gbs = round(g.value, 1)
 
     sc = StreetScene(W, H)
     kw = settings_kwargs(args.preset)
@@ -264,24 +269,31 @@ def main():
                                   "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
                                   "GBps": round(r["bytes"] / (r["total_ms"] * 1e6), 1) if r["total_ms"] > 0 and r["bytes"] > 0 else None}
             if r["name"] == "integrate" and r["total_ms"] > 0:
-                achieved = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
-                traffic = pmc_traffic(args, "k_integrate")
                 avg_s = r["total_ms"] * 1e-3 / r["launches"]
+                v_per_launch = r["units"] / r["launches"]
+                layout = r["bytes_layout"] / r["launches"]   # compulsory bytes of the layout in use (DESIGN.md byte model)
+                aos = r["bytes"] / r["launches"]             # the reference's AoS formulation
+                achieved = layout / avg_s / 1e9
+                traffic, traffic_src = pmc_traffic(args, "k_integrate", v_per_launch)
                 roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                             "traffic": traffic,
                             # the same launch priced with the bytes it really moved (PMC, profiles/)
                             "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
                             "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                            "limiter": "VALU issue: SQ_INSTS_VALU x 4 cycles / 1024 SIMDs = 98 % of the launch duration "
-                                       "(profiles/r01_h_*_pmc_sq.json)",
-                            "note": "algorithmic bytes = SURVEY 8d: V*(16+2*4096)+8P, the reference formulation's "
-                                    "compulsory traffic (every voxel of every visible block read and written as an "
-                                    "8 B struct). The plane-wise layout moves less than half of it (traffic), so "
-                                    "frac can pass 1; traffic_frac prices the bytes really moved",
+                            "traffic_source": traffic_src,
                             "measured_copy_GBps": copy_gbs,
-                            "avg_launch_us": round(1e3 * r["total_ms"] / r["launches"], 2),
-                            "bytes_per_launch": round(r["bytes"] / r["launches"], 0)}
+                            "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                            "avg_launch_us": round(1e6 * avg_s, 2),
+                            "bytes_per_launch": round(layout, 0),
+                            "visible_blocks_per_launch": round(v_per_launch, 1),
+                            "algorithmic_aos": {"bytes_per_launch": round(aos, 0), "GBps": round(aos / avg_s / 1e9, 1),
+                                                "note": "SURVEY 8d: V*(16+2*4096)+8P — every voxel of every visible block read "
+                                                        "and written as an 8 B struct; NOT what this layout moves, kept for reference"},
+                            "note": "achieved = layout-true compulsory bytes / HIP-event duration: per visible block 4 B list id "
+                                    "+ 16 B hash entry + 1536 B sdf and w_depth planes read, 24 B written per lane that updated a "
+                                    "voxel, 10 B per colour voxel, 8 B per pixel of the frames (tallied by the kernel itself); "
+                                    "traffic = rocprofv3 PMC bytes per visible block (profiles/) x this run's visible blocks"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 item
             try:

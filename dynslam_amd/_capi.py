@@ -73,7 +73,7 @@ class Stats(C.Structure):
 
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64),
-                ("bytes", C.c_double)]
+                ("bytes", C.c_double), ("bytes_layout", C.c_double), ("units", C.c_double)]
 
 
 assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8
@@ -90,6 +90,8 @@ SIGNATURES = {
     "engine_destroy": (None, [_H]),
     "reset_scene": (C.c_int, [_H]),
     "sync": (C.c_int, [_H]),
+    "wait_for_stream": (C.c_int, [_H, _P]),
+    "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "update_view": (C.c_int, [_H, _P, _P]),
     "update_view_dev": (C.c_int, [_H, _P, _P]),
     "set_view_float": (C.c_int, [_H, _P, _P]),
@@ -128,6 +130,7 @@ SIGNATURES = {
     "dump_swap_state": (C.c_int, [_H, _P, _P]),
     "dump_stored_block": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int)]),
     "selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "profile_enable": (C.c_int, [_H, C.c_int]),
     "profile_reset": (C.c_int, [_H]),
     "profile_get": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),

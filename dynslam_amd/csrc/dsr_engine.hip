@@ -134,6 +134,7 @@ struct dsr_engine {
   SceneP scene{};
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
+  uint2 *integrateStats = nullptr;  // per wave of k_integrate: {lanes that stored depth planes, colour voxels}
   int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
   // free-view cache: DynSLAM renders several image types from ONE pose per redraw (GetImage colour +
   // GetFloatImage depth, InfiniTamDriver.cpp:165-209); while neither the scene nor the camera has
@@ -187,6 +188,7 @@ struct dsr_engine {
   size_t maskCap = 0;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
+  hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
   uint8_t *decayFlags = nullptr;
 
   // profiling
@@ -309,7 +311,7 @@ void free_all(dsr_engine *e) {
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
-  F(e->tileSums); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
+  F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
   for (auto p : e->fifoSlots) F(p);
   F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
@@ -320,6 +322,7 @@ void free_all(dsr_engine *e) {
   for (auto p : e->hostSlabs) (void)hipHostFree(p);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
+  if (e->orderEvent) (void)hipEventDestroy(e->orderEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -419,7 +422,7 @@ int integrate_scene(dsr_engine *e) {
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
   LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
-         (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs)
+         (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs, e->integrateStats)
 #define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
   do {                                                                                                       \
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
@@ -677,6 +680,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->live.visibleIDsAlt, (size_t)e->noBlocks));
   e->live.ctrIdx = CTR_NO_VISIBLE_LIVE; e->freeview.ctrIdx = CTR_NO_VISIBLE_FREE;
   ALLOC(dmalloc(&e->tileSums, (size_t)e->numTilesMax + 1));
+  ALLOC(dmalloc(&e->integrateStats, (size_t)e->gridIntegrate * kIntegrateWaves));
+  (void)hipMemsetAsync(e->integrateStats, 0, (size_t)e->gridIntegrate * kIntegrateWaves * sizeof(uint2), e->stream);
   ALLOC(dmalloc(&e->rgb, (size_t)e->Wr * e->Hr));
   ALLOC(dmalloc(&e->depth, (size_t)e->P));
   ALLOC(dmalloc(&e->depthTmp, (size_t)e->P));
@@ -736,6 +741,24 @@ int dsr_reset_scene(dsr_engine *e) {
 int dsr_sync(dsr_engine *e) {
   CHECK_E(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return DSR_OK;
+}
+
+// ---- stream ordering without host synchronisation (dsr.h)
+
+int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
+  CHECK_E(e);
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
+  HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
+  return DSR_OK;
+}
+
+int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
+  CHECK_E(e);
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e->orderEvent, e->stream));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->orderEvent, 0));
   return DSR_OK;
 }
 
@@ -1383,6 +1406,42 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
   return DSR_OK;
 }
 
+// ---- HBM ceiling probe (roofline harness)
+
+__global__ __launch_bounds__(256) void k_copy16(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gbps_out) {
+  if (!gbps_out || bytes < 16 || iters <= 0) return fail(DSR_E_ARG, "bad bandwidth probe arguments");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  float4 *a = nullptr, *b = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a), bytes));
+  if (hipMalloc(reinterpret_cast<void **>(&b), bytes) != hipSuccess) { (void)hipFree(a); return fail(DSR_E_NOMEM, "probe buffers"); }
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t err = hipMemset(a, 1, bytes);
+  if (err == hipSuccess) err = hipMemset(b, 2, bytes);
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  float ms = 0.0f;
+  if (err == hipSuccess) {
+    const size_t n = bytes / 16;
+    const int grid = 256 * 16;  // 16 workgroups per CU, 16 B per lane: the guide's copy kernel
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const float4 *)a, b, n);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const float4 *)a, b, n);
+    (void)hipEventRecord(e1, 0);
+    err = hipEventSynchronize(e1);
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b);
+  if (err != hipSuccess || !(ms > 0.0f)) return fail(DSR_E_DEVICE, "bandwidth probe failed");
+  *gbps_out = 2.0 * (double)(bytes / 16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
+  return DSR_OK;
+}
+
 // ---- statistics / dumps
 
 int dsr_get_stats(dsr_engine *e, dsr_stats *out) {
@@ -1504,6 +1563,7 @@ int dsr_profile_reset(dsr_engine *e) {
   HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_INTEGRATED, &zero, 8, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_EXPECTED, &zero, 8, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_DECAY, &zero, 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->integrateStats, 0, (size_t)e->gridIntegrate * kIntegrateWaves * sizeof(uint2), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return DSR_OK;
 }
@@ -1515,6 +1575,13 @@ int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
   unsigned long long work[WORK_COUNT];
   if (hipMemcpy(work, e->scene.work, sizeof work, hipMemcpyDeviceToHost) != hipSuccess) return 0;
   const double P = (double)e->P, E = (double)e->E, B = (double)kBlockBytes;
+  // k_integrate's own tallies: lanes that stored their 24 B of depth planes, voxels that got colour
+  double storeLanes = 0.0, colourVoxels = 0.0;
+  {
+    std::vector<uint2> ws((size_t)e->gridIntegrate * kIntegrateWaves);
+    if (hipMemcpy(ws.data(), e->integrateStats, ws.size() * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    for (const uint2 &w : ws) { storeLanes += (double)w.x; colourVoxels += (double)w.y; }
+  }
   int n = 0;
   for (auto &r : e->profRecs) {
     if (n >= cap) break;
@@ -1525,7 +1592,15 @@ int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
     k.total_ms = r.ms; k.launches = r.launches;
     const double L = (double)r.launches;
     // algorithmic bytes, SURVEY.md 8(d) / DESIGN.md "byte model"
-    if (r.name == "integrate") k.bytes = (double)work[WORK_V_INTEGRATED] * (16.0 + 2.0 * B) + L * 8.0 * P;
+    if (r.name == "integrate") {
+      const double V = (double)work[WORK_V_INTEGRATED];
+      k.bytes = V * (16.0 + 2.0 * B) + L * 8.0 * P;  // the reference's AoS formulation
+      // what THIS layout has to move (DESIGN.md "byte model"): per visible block its list id (4 B), hash
+      // entry (16 B) and the sdf + w_depth planes (1536 B) read; 24 B written back per lane that updated
+      // a voxel; per colour voxel 4 + 1 B read and written; the depth and RGB frames (8 B per pixel)
+      k.bytes_layout = V * (4.0 + 16.0 + 1536.0) + storeLanes * 24.0 + colourVoxels * 10.0 + L * 8.0 * P;
+      k.units = V;
+    }
     else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;
     else if (r.name == "expected_depth") k.bytes = (double)work[WORK_V_EXPECTED] * 16.0 + L * 8.0 * std::ceil(e->W / 8.0) * std::ceil(e->H / 8.0);
     else if (r.name == "icp_maps") k.bytes = L * P * (16.0 + 16.0 + 16.0 + 4.0);

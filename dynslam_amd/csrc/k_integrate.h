@@ -102,7 +102,8 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
-                                                                         const int32_t *__restrict__ visibleIDs) {
+                                                                         const int32_t *__restrict__ visibleIDs,
+                                                                         uint2 *__restrict__ waveStats) {
   constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
   constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
   // per wave: the voxels waiting for their colour update, one word each:
@@ -202,6 +203,9 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   // software pipeline over this wave's tasks: entries two ahead, voxel planes one ahead
   const dsr_hash_entry kNone = {{0, 0, 0}, 0, 0, -2};
   int nPend = 0;  // wave-uniform length of the pending colour list (< 64 between tasks)
+  // byte-model bookkeeping (wave-uniform, scalar registers): lanes that stored their 24 B of
+  // sdf + w_depth, voxels that took the colour update; added to this wave's own slot at the end
+  uint32_t statStoreLanes = 0, statColour = 0;
   int t = t0;
   int taskNo = 0;  // t == t0 + taskNo * stride
   dsr_hash_entry heCur = (t < noTasks) ? task_entry(t) : kNone;
@@ -316,12 +320,14 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         if (gate)  // slot = number of gated lanes below this one (v_mbcnt)
           pend[nPend + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pendWord0 + (uint32_t)x;
         nPend += __popcll(m);
+        statColour += (uint32_t)__popcll(m);
       }
     };
     if (rejectedPassGate) phaseA2(std::true_type{});
     else phaseA2(std::false_type{});
 
     if (dirtyDepth) store_planes<VOX>(blk, vox0, pl);
+    statStoreLanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(dirtyDepth));
 
     // ------------------------------------------------------------ phase B: colour, 64 at a time
     while (nPend >= 64) {
@@ -330,6 +336,11 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     }
   }
   if (nPend > 0) colour_pass(0, nPend);
+  if (lane == 0 && (statStoreLanes | statColour)) {  // one private 8-byte slot per wave: no atomics
+    uint2 *slot = waveStats + (blockIdx.x * kIntegrateWaves + wave);
+    const uint2 old = *slot;
+    *slot = make_uint2(old.x + statStoreLanes, old.y + statColour);
+  }
 }
 
 }  // namespace dsr

@@ -320,7 +320,7 @@ class EngineCore:
         buf = (KernelTime * 64)()
         n = self.api.profile_get(self._h, buf, 64)
         return [dict(name=buf[i].name.decode(), total_ms=buf[i].total_ms, launches=buf[i].launches,
-                     bytes=buf[i].bytes) for i in range(n)]
+                     bytes=buf[i].bytes, bytes_layout=buf[i].bytes_layout, units=buf[i].units) for i in range(n)]
 
 
 class VoxelDecayParams:

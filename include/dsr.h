@@ -176,6 +176,22 @@ int dsr_reset_scene(dsr_engine *e);
  * (cudaDeviceSynchronize at DynSlam.cpp:165-172). */
 int dsr_sync(dsr_engine *e);
 
+/* Stream ordering for the "_dev" entry points, WITHOUT host synchronisation.  Every engine
+ * enqueues on its own private HIP stream and "_dev" calls return before the work has run, so a
+ * caller that produces the inputs or consumes the outputs on another stream (torch's current
+ * stream, the RCCL stream of the preview all-gather) must order the two:
+ *   dsr_wait_for_stream(e, s)        — work queued on the engine AFTER this call starts only when
+ *                                      everything queued on `s` so far has finished (call it before
+ *                                      dsr_update_view_dev / dsr_set_view_float_dev when `s` wrote
+ *                                      the buffers);
+ *   dsr_stream_wait_for_engine(e, s) — work queued on `s` after this call starts only when
+ *                                      everything queued on the engine so far has finished (call it
+ *                                      after dsr_get_image_dev, before `s` reads the buffers).
+ * `hip_stream` is a hipStream_t (NULL = the legacy default stream).  dsr_sync() remains the
+ * blocking alternative. */
+int dsr_wait_for_stream(dsr_engine *e, void *hip_stream);
+int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
+
 /* ---- view ------------------------------------------------------------------- */
 
 /* viewBuilder->UpdateView(&view, rgb, rawDepth, useBilateralFilter, ...)
@@ -347,13 +363,23 @@ int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present
  * patterns (must be 0).  Synchronises. */
 int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *mismatches);
 
+/* Device-to-device bandwidth of `device` as THIS library's float4 grid-stride copy kernel
+ * measures it (the kernel MI355X_MICROARCH.md quotes 6.29 TB/s for): `bytes` read + `bytes`
+ * written per pass, `iters` timed passes after one warm-up; *gbps_out = 2*bytes*iters / time.
+ * The roofline harness reports it next to the nominal 8 TB/s.  Allocates 2*bytes of HBM
+ * for the duration of the call; synchronises. */
+int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gbps_out);
+
 /* ---- per-kernel timing (roofline harness) -------------------------------------- */
 
 typedef struct dsr_kernel_time {
   char name[32];
   double total_ms;   /* sum of HIP-event durations on the engine's stream */
   int64_t launches;
-  double bytes;      /* algorithmic bytes accumulated (SURVEY.md 8d model) */
+  double bytes;      /* algorithmic bytes accumulated (SURVEY.md 8d model: the reference's AoS voxels) */
+  double bytes_layout; /* integrate: compulsory bytes of the plane-wise layout actually used (DESIGN.md
+                          "byte model"), from the kernel's own tallies; 0 for the other kernels       */
+  double units;      /* integrate: visible blocks processed over all launches                     */
 } dsr_kernel_time;
 /* enable == 1 brackets every kernel launch with HIP events, enable == 2 only the two
  * dominant kernels (integrate, raycast); 0 = off.  Events cost ~3 us per bracketed launch

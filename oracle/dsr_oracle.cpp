@@ -1671,6 +1671,11 @@ int orc_dump_stored_block(dsr_engine *h, int entry, dsr_voxel *out, int *present
 /* the oracle divides with the C `/` operator everywhere: nothing to self-test */
 int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (mismatches) *mismatches = 0; return DSR_OK; }
 
+/* stream ordering / bandwidth probe: nothing to order or measure on the CPU */
+int orc_wait_for_stream(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
+int orc_stream_wait_for_engine(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
+int orc_measure_copy_bandwidth(int, uint64_t, int, double *gbps_out) { if (gbps_out) *gbps_out = 0.0; return DSR_OK; }
+
 int orc_profile_enable(dsr_engine *h, int) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_reset(dsr_engine *h) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_get(dsr_engine *, dsr_kernel_time *, int) { return 0; }

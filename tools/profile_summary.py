@@ -54,7 +54,7 @@ def pmc(dirs):
     return {k: {c: {"mean": v[0] / v[1], "launches": v[1]} for c, v in cs.items()} for k, cs in acc.items()}
 
 
-def traffic(fetch_dir, write_dir, last_n):
+def traffic(fetch_dir, write_dir, last_n, bench_line=None):
     """HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes, averaged over the LAST
     last_n launches of every kernel (the timed steps of bench.py; earlier launches are warm-up).
     Units per MI355X_MICROARCH.md / tools/pmc_calibrate.py: both counters are in KB; FETCH_SIZE
@@ -78,6 +78,17 @@ def traffic(fetch_dir, write_dir, last_n):
         w = wr.get(k, (0.0, 0))[0] * 1024.0
         kernels[k] = {"launches": max(fe.get(k, (0, 0))[1], wr.get(k, (0, 0))[1]),
                       "fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w}
+    # k_integrate's traffic is proportional to the visible blocks it walks: normalise with the visible
+    # blocks per launch of the SAME frames (bench line of the same command), so that bench.py can
+    # report traffic for any --steps/--warmup of the workload
+    if bench_line and "k_integrate" in kernels:
+        try:
+            line = [l for l in open(bench_line) if l.startswith('{"metric"')][-1]
+            v = json.loads(line)["roofline"]["visible_blocks_per_launch"]
+            kernels["k_integrate"]["visible_blocks_per_launch"] = v
+            kernels["k_integrate"]["hbm_bytes_per_visible_block"] = kernels["k_integrate"]["hbm_bytes"] / v
+        except Exception as ex:  # keep the per-launch figures
+            kernels["k_integrate"]["per_block_error"] = str(ex)
     return {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `python bench.py --steps 45 "
                     "--warmup 5 --no-cpu-baseline --no-profile`; KB per launch averaged over the last %d launches "
                     "of each kernel (the timed steps); FETCH_SIZE x2 per MI355X_MICROARCH.md (calibrated with "
@@ -88,7 +99,7 @@ def traffic(fetch_dir, write_dir, last_n):
 if __name__ == "__main__":
     mode = sys.argv[1]
     if mode == "traffic":
-        res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+        res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         res = stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0) if mode == "stats" else pmc(sys.argv[2:])
     json.dump(res, sys.stdout, indent=1)
