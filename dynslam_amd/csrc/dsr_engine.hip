@@ -578,21 +578,44 @@ int convert_dev(K kernel, int device, void *hip_stream, const void *in, void *ou
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
+// Host-buffer form of the conversions (what InfiniTamDriver.cpp:81-144 calls every frame): the device
+// scratch is kept per thread and per GPU and only ever grows, so a frame costs two copies and one
+// launch — no hipMalloc / hipFree (both synchronise the device) on the per-frame path.
+struct ConvScratch {
+  int device = -1;
+  uint8_t *in = nullptr, *out = nullptr;
+  size_t inCap = 0, outCap = 0;
+  // never freed at thread / process exit: the HIP runtime may already be gone by then
+};
+static int conv_reserve(uint8_t **buf, size_t *cap, size_t bytes) {
+  if (*cap >= bytes) return DSR_OK;
+  if (*buf) (void)hipFree(*buf);
+  *buf = nullptr; *cap = 0;
+  const size_t want = bytes + bytes / 4;  // head room: images of a sequence differ little in size
+  int st = dmalloc(buf, want);
+  if (st) return st;
+  *cap = want;
+  return DSR_OK;
+}
 template <class K, class TI, class TO>
 int convert_host(K kernel, const void *in, size_t inBytes, void *out, size_t outBytes, int n) {
   if (!in || !out || n <= 0) return fail(DSR_E_ARG, "bad conversion arguments");
-  uint8_t *d = nullptr, *o = nullptr;
-  int st = dmalloc(&d, inBytes);
-  if (st) return st;
-  if ((st = dmalloc(&o, outBytes))) { (void)hipFree(d); return st; }
-  hipError_t err = hipMemcpy(d, in, inBytes, hipMemcpyHostToDevice);
-  if (err == hipSuccess) {
-    st = convert_dev<K, TI, TO>(kernel, -1, nullptr, d, o, n);
-    if (st == DSR_OK) err = hipMemcpy(out, o, outBytes, hipMemcpyDeviceToHost);
+  static thread_local ConvScratch sc;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (sc.device != dev) {  // the scratch belongs to the GPU it was allocated on
+    if (sc.in) (void)hipFree(sc.in);
+    if (sc.out) (void)hipFree(sc.out);
+    sc.in = sc.out = nullptr; sc.inCap = sc.outCap = 0;
+    sc.device = dev;
   }
-  (void)hipFree(d); (void)hipFree(o);
+  int st = conv_reserve(&sc.in, &sc.inCap, inBytes);
   if (st) return st;
-  if (err != hipSuccess) return fail(DSR_E_DEVICE, "conversion copy failed");
+  if ((st = conv_reserve(&sc.out, &sc.outCap, outBytes))) return st;
+  HIP_TRY(hipMemcpy(sc.in, in, inBytes, hipMemcpyHostToDevice));
+  st = convert_dev<K, TI, TO>(kernel, -1, nullptr, sc.in, sc.out, n);
+  if (st) return st;
+  if (hipMemcpy(out, sc.out, outBytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(DSR_E_DEVICE, "conversion copy failed");
   return DSR_OK;
 }
 

@@ -645,7 +645,7 @@ static void integrate_into_scene(Engine &e) {
 
 struct IndexCache { /* ITMVoxelBlockHash::IndexCache */
   V3i blockPos = {0x7fffffff, 0x7fffffff, 0x7fffffff};
-  int blockPtr = -1;
+  long long blockPtr = -1; /* upstream: int (ptr * SDF_BLOCK_SIZE3 overflows it beyond 2^22 blocks; the fork's runtime sdfLocalBlockNum allows more) */
 };
 
 /* ITMRepresentationAccess.h pointToVoxelBlockPos */
@@ -670,7 +670,7 @@ static inline dsr_voxel readVoxel(const Engine &e, const V3i &point, bool &isFou
     const dsr_hash_entry &he = e.hashTable[hashIdx];
     if (he.pos[0] == blockPos.x && he.pos[1] == blockPos.y && he.pos[2] == blockPos.z && he.ptr >= 0) {
       isFound = true;
-      if (cache) { cache->blockPos = blockPos; cache->blockPtr = he.ptr * DSR_BLOCK_SIZE3; }
+      if (cache) { cache->blockPos = blockPos; cache->blockPtr = (long long)he.ptr * DSR_BLOCK_SIZE3; }
       return e.voxels[(size_t)he.ptr * DSR_BLOCK_SIZE3 + linearIdx];
     }
     if (he.offset < 1) break;

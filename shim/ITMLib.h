@@ -203,7 +203,21 @@ class ITMPose {
 struct ITMTrackingState { ITMPose *pose_d = new ITMPose; ~ITMTrackingState() { delete pose_d; } };
 
 struct ITMRenderState { virtual ~ITMRenderState() {} };
-struct ITMRenderState_VH : ITMRenderState { int noVisibleBlocks = 0; };
+// noVisibleBlocks is read by the host once per frame (InfiniTamDriver.h:150); it lives in device memory,
+// so the value is fetched (one stream synchronisation) when it is READ, not after every engine call
+struct ITMRenderState_VH : ITMRenderState {
+  struct LazyCount {
+    dsr_engine *e = nullptr;
+    mutable int cached = 0;
+    mutable bool valid = true;
+    operator int() const {
+      if (!valid && e) { dsr_stats s; if (dsr_get_stats(e, &s) == DSR_OK) cached = s.no_visible_blocks; valid = true; }
+      return cached;
+    }
+    LazyCount &operator=(int v) { cached = v; valid = true; return *this; }
+    void invalidate(dsr_engine *engine) { e = engine; valid = false; }
+  } noVisibleBlocks;
+};
 
 class ITMView {
  public:
@@ -323,14 +337,12 @@ template <class TVoxel, class TIndex> class ITMDenseMapper {
     push_view(view);
     ITMLib::Engine::dsr_throw(ts->pose_d->apply(e_));
     int st = dsr_process_frame(e_);
-    dsr_stats s; dsr_get_stats(e_, &s);
-    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks = s.no_visible_blocks;
+    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks.invalidate(e_);
     ITMLib::Engine::dsr_throw(st);
   }
   void Decay(ITMScene<TVoxel, TIndex> *, ITMRenderState *rs, int maxWeight, int minAge, bool forceAllVoxels) {
     ITMLib::Engine::dsr_throw(dsr_decay(e_, maxWeight, minAge, forceAllVoxels));
-    dsr_stats s; dsr_get_stats(e_, &s);
-    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks = s.no_visible_blocks;
+    static_cast<ITMRenderState_VH *>(rs)->noVisibleBlocks.invalidate(e_);
   }
   size_t GetDecayedBlockCount() const { dsr_stats s; dsr_get_stats(e_, &s); return (size_t)s.decayed_block_count; }
   void ResetScene(ITMScene<TVoxel, TIndex> *) { ITMLib::Engine::dsr_throw(dsr_reset_scene(e_)); }

@@ -1,0 +1,212 @@
+// shim/host_bench.cpp — a C++ host that drives the engines the way DynSLAM does, frame by frame,
+// through the ITMLib names of shim/ITMLib.h, and reports what the call sequence sustains
+// ("through-shim" frames/s) next to a digest of everything it produced.
+//
+// Two builds of the SAME main():
+//   * default: `HostDriver` below — our own driver class written against the shim, raw BGR / int16
+//     buffers, the layout conversions of InfiniTamDriver.cpp:81-144 done on the GPU
+//     (dynslam_shim::CvToItm / ItmToCv / ItmDepthToCv).  bench.py's `through_shim` leg runs this one.
+//   * -DDSR_HOST_REFERENCE_DRIVER (tests/test_reference_compiles.py; needs /root/reference at BUILD
+//     time only): the reference's UNMODIFIED `dynslam::drivers::InfiniTamDriver`
+//     (src/DynSLAM/InfiniTamDriver.{h,cpp}, compiled from where they lie against shim/ITMLib.h and
+//     the stand-in third-party headers of tests/stubs/) — the proof that the reference's host code
+//     runs on the HIP engines unchanged.
+//
+// usage: host_bench frames.bin W H fx fy cx cy n_frames warmup voxel mu blocks buckets excess [decay_max_w decay_min_age]
+//   frames.bin: per frame  BGR u8[H*W*3], depth int16[H*W] (mm), pose float[16] (camera->world, ROW-major);
+//               then float[16]: model-view matrix (world->camera, row-major) of the final free-view render
+// prints one line: key=value ... (frames_per_s over the frames after `warmup`, FNV-1a digest of the
+// final free-view colour + float depth renders, the view depth and the previews)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#ifdef DSR_HOST_REFERENCE_DRIVER
+#include "InfiniTamDriver.h"  // the reference's own header (-I /root/reference/src/DynSLAM)
+using RefDriver = dynslam::drivers::InfiniTamDriver;
+#else
+#include "ITMLib.h"
+#endif
+
+namespace {
+
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+#ifndef DSR_HOST_REFERENCE_DRIVER
+// Our own host-side driver: same sequence of ITMLib calls as the reference's InfiniTamDriver
+// (InfiniTamDriver.h:79-300), raw buffers instead of cv::Mat.
+class HostDriver : public ITMMainEngine {
+ public:
+  HostDriver(const ITMLibSettings *s, const ITMRGBDCalib *c, Vector2i size, bool decay, int decayMaxW, int decayMinAge)
+      : ITMMainEngine(s, c, size, size), rgb_(size, true, true), rawDepth_(size, true, true), previewMm_((size_t)size.x * size.y),
+        previewBgr_((size_t)size.x * size.y * 3), decay_(decay), decayMaxW_(decayMaxW), decayMinAge_(decayMinAge) {}
+  void UpdateView(const unsigned char *bgr, const short *depthMm) {  // InfiniTamDriver.cpp:211-224
+    dynslam_shim::CvToItm(bgr, rawDepth_.noDims.y, rawDepth_.noDims.x, &rgb_);
+    std::memcpy(rawDepth_.GetData(MEMORYDEVICE_CPU), depthMm, rawDepth_.dataSize * sizeof(short));
+    viewBuilder->UpdateView(&view, &rgb_, &rawDepth_, settings->useBilateralFilter, settings->modelSensorNoise);
+  }
+  void SetPose(const Matrix4f &invM) { trackingState->pose_d->SetInvM(invM); }  // .h:131-134
+  void Integrate() {                                                         // .h:137-146
+    denseMapper->SetFusionWeightParams(weights_);
+    denseMapper->ProcessFrame(view, trackingState, scene, renderState_live);
+  }
+  void PrepareNextStep() {  // .h:148-158 (incl. the two preview conversions)
+    if (static_cast<ITMRenderState_VH *>(renderState_live)->noVisibleBlocks > 0) {
+      trackingController->Prepare(trackingState, view, renderState_live);
+      dynslam_shim::ItmToCv(*view->rgb, previewBgr_.data());
+      dynslam_shim::ItmDepthToCv(*view->depth, previewMm_.data());
+    }
+  }
+  void Decay() { if (decay_) denseMapper->Decay(scene, renderState_live, decayMaxW_, decayMinAge_, false); }  // .h:201-206
+  size_t GetUsedMemoryBytes() const {                                                                       // .h:241-244
+    return sizeof(ITMVoxel) * SDF_BLOCK_SIZE3 * (size_t)(scene->index.getNumAllocatedVoxelBlocks() - scene->localVBA.lastFreeBlockId);
+  }
+  size_t GetSavedDecayMemoryBytes() const { return denseMapper->GetDecayedBlockCount() * sizeof(ITMVoxel) * SDF_BLOCK_SIZE3; }
+  void Render(ITMUChar4Image *out, ITMFloatImage *outF, const Matrix4f &M) {  // InfiniTamDriver.cpp:165-209
+    ITMPose pose; pose.SetM(M); pose.Coerce();
+    ITMIntrinsics intr = viewBuilder->GetCalib()->intrinsics_d;
+    if (out) GetImage(out, nullptr, InfiniTAM_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, &pose, &intr);
+    if (outF) GetImage(nullptr, outF, InfiniTAM_IMAGE_FREECAMERA_DEPTH, &pose, &intr);
+  }
+
+ private:
+  ITMUChar4Image rgb_;
+  ITMShortImage rawDepth_;
+  std::vector<short> previewMm_;
+  std::vector<unsigned char> previewBgr_;
+  WeightParams weights_;
+  bool decay_;
+  int decayMaxW_, decayMinAge_;
+};
+#endif
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 15) {
+    fprintf(stderr, "usage: %s frames.bin W H fx fy cx cy n_frames warmup voxel mu blocks buckets excess [decay_max_w decay_min_age]\n", argv[0]);
+    return 2;
+  }
+  const char *path = argv[1];
+  const int W = atoi(argv[2]), H = atoi(argv[3]), nFrames = atoi(argv[8]), warmup = atoi(argv[9]);
+  const float fx = (float)atof(argv[4]), fy = (float)atof(argv[5]), cx = (float)atof(argv[6]), cy = (float)atof(argv[7]);
+  const bool decay = argc > 16;
+  const int decayMaxW = decay ? atoi(argv[15]) : 0, decayMinAge = decay ? atoi(argv[16]) : 0;
+  const size_t P = (size_t)W * H;
+
+  ITMLibSettings settings;
+  settings.sceneParams.voxelSize = (float)atof(argv[10]); settings.sceneParams.mu = (float)atof(argv[11]);
+  settings.sceneParams.maxW = 100; settings.sceneParams.viewFrustum_min = 0.2f; settings.sceneParams.viewFrustum_max = 30.0f;
+  settings.sdfLocalBlockNum = atol(argv[12]); settings.hashBucketNum = atoi(argv[13]); settings.excessListSize = atoi(argv[14]);
+
+  FILE *f = fopen(path, "rb");
+  if (!f) { perror(path); return 2; }
+  std::vector<std::vector<unsigned char>> bgr(nFrames);
+  std::vector<std::vector<short>> dep(nFrames);
+  std::vector<float> poses((size_t)nFrames * 16);
+  for (int i = 0; i < nFrames; i++) {
+    bgr[i].resize(P * 3); dep[i].resize(P);
+    if (fread(bgr[i].data(), 1, P * 3, f) != P * 3 || fread(dep[i].data(), 2, P, f) != P || fread(&poses[(size_t)i * 16], 4, 16, f) != 16) {
+      fprintf(stderr, "%s: short read at frame %d\n", path, i);
+      return 2;
+    }
+  }
+  float renderM[16];  // trailer: the model-view matrix (world->camera, row-major) of the final free-view render
+  if (fread(renderM, 4, 16, f) != 16) { fprintf(stderr, "%s: render pose missing\n", path); return 2; }
+  fclose(f);
+
+  try {
+#ifdef DSR_HOST_REFERENCE_DRIVER
+    Eigen::Matrix<double, 3, 4> proj;  // CreateItmCalib (InfiniTamDriver.cpp:49-79) reads fx, fy, cx, cy from P2
+    proj(0, 0) = fx; proj(1, 1) = fy; proj(0, 2) = cx; proj(1, 2) = cy; proj(2, 2) = 1.0;
+    ITMRGBDCalib *calib = dynslam::drivers::CreateItmCalib(proj, Eigen::Vector2i(W, H));
+    RefDriver drv(&settings, calib, Vector2i(W, H), Vector2i(W, H), dynslam::VoxelDecayParams(decay, decayMinAge, decayMaxW), false);
+    cv::Mat3b rgbCv(H, W);
+    cv::Mat1s depthCv(H, W);
+#else
+    ITMRGBDCalib calibStore, *calib = &calibStore;
+    calib->intrinsics_rgb.SetFrom(fx, fy, cx, cy, (float)W, (float)H);
+    calib->intrinsics_d = calib->intrinsics_rgb;
+    Matrix4f identity; identity.setIdentity();
+    calib->trafo_rgb_to_depth.SetFrom(identity);
+    calib->disparityCalib.SetFrom(1.0f / 1000.0f, 0.0f, ITMDisparityCalib::TRAFO_AFFINE);
+    HostDriver drv(&settings, calib, Vector2i(W, H), decay, decayMaxW, decayMinAge);
+#endif
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < nFrames; i++) {
+      if (i == warmup) t0 = std::chrono::steady_clock::now();
+      const float *T = &poses[(size_t)i * 16];
+#ifdef DSR_HOST_REFERENCE_DRIVER
+      std::memcpy(rgbCv.data, bgr[i].data(), P * 3);
+      std::memcpy(depthCv.data, dep[i].data(), P * 2);
+      Eigen::Matrix4f pose;
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose(r, c) = T[r * 4 + c];
+      drv.UpdateView(rgbCv, depthCv);
+      drv.SetPose(pose);
+#else
+      Matrix4f invM;
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) invM.at(c, r) = T[r * 4 + c];
+      drv.UpdateView(bgr[i].data(), dep[i].data());
+      drv.SetPose(invM);
+#endif
+      drv.Integrate();
+      drv.PrepareNextStep();
+      drv.Decay();
+    }
+    // GetUsedMemoryBytes reads the free-list head from the device: it also drains the stream
+    const size_t used = drv.GetUsedMemoryBytes();
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    // a free-view colour + depth render from the pose in the file's trailer
+    ITMUChar4Image out(Vector2i(W, H), true, true);
+    ITMFloatImage outF(Vector2i(W, H), true, true);
+    Matrix4f M;
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) M.at(c, r) = renderM[r * 4 + c];
+#ifdef DSR_HOST_REFERENCE_DRIVER
+    pangolin::OpenGlMatrix mv;
+    for (int k = 0; k < 16; k++) mv.m[k] = M.m[k];
+    drv.GetImage(&out, dynslam::PreviewType::kColor, mv);
+    drv.GetFloatImage(&outF, dynslam::PreviewType::kDepth, mv);
+#else
+    drv.Render(&out, &outF, M);
+#endif
+    drv.GetView()->depth->UpdateHostFromDevice();
+    uint64_t h = fnv(out.GetData(MEMORYDEVICE_CPU), P * 4);
+    h = fnv(outF.GetData(MEMORYDEVICE_CPU), P * 4, h);
+    h = fnv(drv.GetView()->depth->GetData(MEMORYDEVICE_CPU), P * 4, h);
+    // the host's preview conversions of the renders (InfiniTamDriver.cpp:108-144)
+    std::vector<short> mm(P);
+    std::vector<unsigned char> pbgr(P * 3);
+#ifdef DSR_HOST_REFERENCE_DRIVER
+    cv::Mat1s mmCv(H, W);
+    cv::Mat3b bgrCv(H, W);
+    dynslam::drivers::ItmDepthToCv(outF, &mmCv);  // the reference's CPU loops
+    dynslam::drivers::ItmToCv(out, &bgrCv);
+    std::memcpy(mm.data(), mmCv.data, P * 2);
+    std::memcpy(pbgr.data(), bgrCv.data, P * 3);
+#else
+    dynslam_shim::ItmDepthToCv(outF, mm.data());
+    dynslam_shim::ItmToCv(out, pbgr.data());
+#endif
+    h = fnv(mm.data(), P * 2, h);
+    h = fnv(pbgr.data(), P * 3, h);
+    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu hash=%016llx\n",
+#ifdef DSR_HOST_REFERENCE_DRIVER
+           "reference",
+#else
+           "shim",
+#endif
+           nFrames, nFrames - warmup, (nFrames - warmup) / secs, 1e3 * secs / (nFrames - warmup), used, drv.GetSavedDecayMemoryBytes(),
+           (unsigned long long)h);
+  } catch (const std::exception &ex) {
+    fprintf(stderr, "error: %s\n", ex.what());
+    return 1;
+  }
+  return 0;
+}

@@ -197,7 +197,7 @@ def test_gpu_host_store_slots_are_reused(hip_api, oracle_lib):
                     step(e, sc, i, decay)
             laps.append((g.get_stats().host_store_slots, o.get_stats().host_store_slots))
         assert laps[0][0] == laps[0][1] > 1000 and laps[1][0] == laps[1][1], laps
-        assert laps[1][0] - laps[0][0] < 0.05 * laps[0][0]  # the second lap re-uses the first lap's slots
+        assert laps[1][0] - laps[0][0] < 0.10 * laps[0][0]  # the second lap re-uses the first lap's slots
         st = g.get_stats()
         assert st.host_store_capacity_slots >= st.host_store_slots
         hs = o.dump_swap_state()[1]

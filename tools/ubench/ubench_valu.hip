@@ -28,14 +28,45 @@
 enum Op {
   OP_FMA, OP_MUL, OP_ADD, OP_CNDMASK, OP_CVT_I32_F32, OP_CVT_F32_I32, OP_AND, OP_LSHL, OP_BFE, OP_PK_FMA, OP_PK_MUL, OP_RCP,
   OP_MUL_LO_U32, OP_MAD_U32_U24, OP_CVT_UBYTE, OP_CMP_VCC, OP_CMP_SGPR, OP_MBCNT, OP_FMA_SGPR, OP_MOV, OP_PERM,
-  OP_MIX_SALU_1_3, OP_MIX_SALU_1_1, OP_SALU, OP_FMA_DEP, OP_COUNT
+  OP_MIX_SALU_1_3, OP_MIX_SALU_1_1, OP_SALU, OP_FMA_DEP,
+  OP_CND_E64, OP_CND_NODEP, OP_MIN_F32, OP_MAX_F32, OP_MED3_F32, OP_BFI, OP_AND_OR, OP_LSHL_OR, OP_LSHL_ADD, OP_ADD_U32, OP_SUB_F32, OP_ASHR, OP_MAX_I32, OP_XOR, OP_OR, OP_FMAC, OP_MUL_LIT, OP_MUL_INL, OP_ADD_SGPR, OP_MUL_U24, OP_WRITELANE, OP_CVT_PKRTZ, OP_FLOOR, OP_RNDNE, OP_SQRT, OP_MAD_I32_I24, OP_ADD3, OP_SDWA_UB,
+  OP_CMP_CND_PAIR, OP_READLANE, OP_DS_READ, OP_COUNT
 };
 static const char *kNames[OP_COUNT] = {
     "v_fma_f32", "v_mul_f32", "v_add_f32", "v_cndmask_b32", "v_cvt_i32_f32", "v_cvt_f32_i32", "v_and_b32", "v_lshlrev_b32",
     "v_bfe_u32", "v_pk_fma_f32 (2 flop-lanes)", "v_pk_mul_f32", "v_rcp_f32", "v_mul_lo_u32", "v_mad_u32_u24",
     "v_cvt_f32_ubyte1", "v_cmp_lt_f32 -> vcc", "v_cmp_lt_f32 -> sgpr pair", "v_mbcnt_lo_u32_b32", "v_fma_f32 (sgpr operand)",
     "v_mov_b32", "v_perm_b32", "3 v_fma : 1 s_add (counted: the 24 VALU)", "1 v_fma : 1 s_add (counted: the 16 VALU)", "s_add_u32 (SALU only)",
-    "v_fma_f32 DEPENDENT chain (1 accumulator)"};
+    "v_fma_f32 DEPENDENT chain (1 accumulator)",
+    "v_cndmask_b32 (e64, sgpr-pair mask)",
+    "v_cndmask_b32 (dst not a source)",
+    "v_min_f32",
+    "v_max_f32",
+    "v_med3_f32",
+    "v_bfi_b32",
+    "v_and_or_b32",
+    "v_lshl_or_b32",
+    "v_lshl_add_u32",
+    "v_add_u32",
+    "v_sub_f32",
+    "v_ashrrev_i32",
+    "v_max_i32",
+    "v_xor_b32",
+    "v_or_b32",
+    "v_fmac_f32 (VOP2)",
+    "v_mul_f32 (32-bit literal operand)",
+    "v_mul_f32 (inline constant 2.0)",
+    "v_add_f32 (sgpr operand)",
+    "v_mul_u32_u24",
+    "v_writelane_b32",
+    "v_cvt_pkrtz_f16_f32",
+    "v_floor_f32",
+    "v_rndne_f32",
+    "v_sqrt_f32",
+    "v_mad_i32_i24",
+    "v_add3_u32",
+    "v_cvt_f32_ubyte0 sdwa (byte select)",
+    "v_cmp_lt_f32 vcc + v_cndmask (counted: both)", "v_readlane_b32", "ds_read_b32 (8 in flight, then waitcnt)"};
 
 // 32 instructions per iteration on 8 independent accumulators
 #define REP8(fmt)                                                                                        \
@@ -50,6 +81,11 @@ __global__ __launch_bounds__(256) void k_issue(int iters, float *sink, unsigned 
   float2 p0 = make_float2(a0, a1), p1 = make_float2(a2, a3), p2 = make_float2(a4, a5), p3 = make_float2(a6, a7);
   float2 pb = make_float2(b, b), pc = make_float2(c, c);
   asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(a4) : "vcc");
+  asm volatile("v_cmp_lt_f32 s[22:23], %0, %1" ::"v"(a0), "v"(a4) : "s22", "s23");
+  __shared__ float s_lds[1024];
+  s_lds[threadIdx.x] = a0; s_lds[threadIdx.x + 256] = a1; s_lds[threadIdx.x + 512] = a2; s_lds[threadIdx.x + 768] = a3;
+  __syncthreads();
+  const unsigned ldsAddr = (unsigned)(size_t)(&s_lds[0]) + (threadIdx.x & 63) * 4;
   const unsigned long long t0 = __builtin_readcyclecounter();  // s_memtime
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
@@ -150,6 +186,112 @@ __global__ __launch_bounds__(256) void k_issue(int iters, float *sink, unsigned 
     } else if (OP == OP_FMA_DEP) {
 #pragma unroll
       for (int k = 0; k < 32; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2\n" : "+v"(a0) : "v"(b), "v"(c));
+    } else if (OP == OP_CND_E64) {
+#define I_N0(d) "v_cndmask_b32_e64 " d ", " d ", %8, s[22:23]\n"
+      BODY4(ONE8(I_N0))
+    } else if (OP == OP_CND_NODEP) {
+#define I_N1(d) "v_cndmask_b32 " d ", %8, %9, vcc\n"
+      BODY4(ONE8(I_N1))
+    } else if (OP == OP_MIN_F32) {
+#define I_N2(d) "v_min_f32 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N2))
+    } else if (OP == OP_MAX_F32) {
+#define I_N3(d) "v_max_f32 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N3))
+    } else if (OP == OP_MED3_F32) {
+#define I_N4(d) "v_med3_f32 " d ", " d ", %8, %9\n"
+      BODY4(ONE8(I_N4))
+    } else if (OP == OP_BFI) {
+#define I_N5(d) "v_bfi_b32 " d ", %8, " d ", %9\n"
+      BODY4(ONE8(I_N5))
+    } else if (OP == OP_AND_OR) {
+#define I_N6(d) "v_and_or_b32 " d ", " d ", %8, %9\n"
+      BODY4(ONE8(I_N6))
+    } else if (OP == OP_LSHL_OR) {
+#define I_N7(d) "v_lshl_or_b32 " d ", " d ", 1, %8\n"
+      BODY4(ONE8(I_N7))
+    } else if (OP == OP_LSHL_ADD) {
+#define I_N8(d) "v_lshl_add_u32 " d ", " d ", 1, %8\n"
+      BODY4(ONE8(I_N8))
+    } else if (OP == OP_ADD_U32) {
+#define I_N9(d) "v_add_u32 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N9))
+    } else if (OP == OP_SUB_F32) {
+#define I_N10(d) "v_sub_f32 " d ", " d ", %9\n"
+      BODY4(ONE8(I_N10))
+    } else if (OP == OP_ASHR) {
+#define I_N11(d) "v_ashrrev_i32 " d ", 3, " d "\n"
+      BODY4(ONE8(I_N11))
+    } else if (OP == OP_MAX_I32) {
+#define I_N12(d) "v_max_i32 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N12))
+    } else if (OP == OP_XOR) {
+#define I_N13(d) "v_xor_b32 " d ", %8, " d "\n"
+      BODY4(ONE8(I_N13))
+    } else if (OP == OP_OR) {
+#define I_N14(d) "v_or_b32 " d ", %8, " d "\n"
+      BODY4(ONE8(I_N14))
+    } else if (OP == OP_FMAC) {
+#define I_N15(d) "v_fmac_f32 " d ", %8, %9\n"
+      BODY4(ONE8(I_N15))
+    } else if (OP == OP_MUL_LIT) {
+#define I_N16(d) "v_mul_f32 " d ", 0x3f800008, " d "\n"
+      BODY4(ONE8(I_N16))
+    } else if (OP == OP_MUL_INL) {
+#define I_N17(d) "v_mul_f32 " d ", 2.0, " d "\n"
+      BODY4(ONE8(I_N17))
+    } else if (OP == OP_ADD_SGPR) {
+#define I_N18(d) "v_add_f32 " d ", %10, " d "\n"
+      BODY4(ONE8(I_N18))
+    } else if (OP == OP_MUL_U24) {
+#define I_N19(d) "v_mul_u32_u24 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N19))
+    } else if (OP == OP_WRITELANE) {
+#define I_N20(d) "v_writelane_b32 " d ", %10, 3\n"
+      BODY4(ONE8(I_N20))
+    } else if (OP == OP_CVT_PKRTZ) {
+#define I_N21(d) "v_cvt_pkrtz_f16_f32 " d ", " d ", %8\n"
+      BODY4(ONE8(I_N21))
+    } else if (OP == OP_FLOOR) {
+#define I_N22(d) "v_floor_f32 " d ", " d "\n"
+      BODY4(ONE8(I_N22))
+    } else if (OP == OP_RNDNE) {
+#define I_N23(d) "v_rndne_f32 " d ", " d "\n"
+      BODY4(ONE8(I_N23))
+    } else if (OP == OP_SQRT) {
+#define I_N24(d) "v_sqrt_f32 " d ", " d "\n"
+      BODY4(ONE8(I_N24))
+    } else if (OP == OP_MAD_I32_I24) {
+#define I_N25(d) "v_mad_i32_i24 " d ", " d ", %8, %9\n"
+      BODY4(ONE8(I_N25))
+    } else if (OP == OP_ADD3) {
+#define I_N26(d) "v_add3_u32 " d ", " d ", %8, %9\n"
+      BODY4(ONE8(I_N26))
+    } else if (OP == OP_SDWA_UB) {
+#define I_N27(d) "v_cvt_f32_ubyte0_sdwa " d ", " d " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2\n"
+      BODY4(ONE8(I_N27))
+    } else if (OP == OP_CMP_CND_PAIR) {
+#define I_PAIR(d) "v_cmp_lt_f32 vcc, " d ", %8\nv_cndmask_b32 " d ", " d ", %9, vcc\n"
+      asm volatile(I_PAIR("%0") I_PAIR("%1") I_PAIR("%2") I_PAIR("%3") I_PAIR("%4") I_PAIR("%5") I_PAIR("%6") I_PAIR("%7")
+                   I_PAIR("%0") I_PAIR("%1") I_PAIR("%2") I_PAIR("%3") I_PAIR("%4") I_PAIR("%5") I_PAIR("%6") I_PAIR("%7")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                   : "v"(b), "v"(c)
+                   : "vcc");
+    } else if (OP == OP_READLANE) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        asm volatile("v_readlane_b32 s20, %0, 3\nv_readlane_b32 s21, %1, 3\nv_readlane_b32 s22, %2, 3\nv_readlane_b32 s23, %3, 3\n"
+                     "v_readlane_b32 s24, %4, 3\nv_readlane_b32 s25, %5, 3\nv_readlane_b32 s26, %6, 3\nv_readlane_b32 s27, %7, 3\n"
+                     : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7)
+                     : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
+    } else if (OP == OP_DS_READ) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        asm volatile("ds_read_b32 %0, %8\nds_read_b32 %1, %8 offset:256\nds_read_b32 %2, %8 offset:512\nds_read_b32 %3, %8 offset:768\n"
+                     "ds_read_b32 %4, %8 offset:1024\nds_read_b32 %5, %8 offset:1280\nds_read_b32 %6, %8 offset:1536\nds_read_b32 %7, %8 offset:1792\n"
+                     "s_waitcnt lgkmcnt(0)\n"
+                     : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3), "=v"(a4), "=v"(a5), "=v"(a6), "=v"(a7)
+                     : "v"(ldsAddr));
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
@@ -212,7 +354,7 @@ int main(int argc, char **argv) {
   for (int op = 0; op < OP_COUNT; ++op) {
     for (int W : {1, 2, 4, 7, 8}) {
       const int grid = cus * W;
-      const long long perIter = (op == OP_MIX_SALU_1_3) ? 24 : (op == OP_MIX_SALU_1_1) ? 16 : 32;
+      const long long perIter = (op == OP_MIX_SALU_1_3) ? 24 : (op == OP_MIX_SALU_1_1) ? 16 : 32;  // (cmp+cndmask pairs: 16 pairs = 32 instructions)
       const long long N = perIter * iters;
       hipLaunchKernelGGL(table[op], dim3(grid), dim3(256), 0, 0, 200, sink, spans);  // warm-up
       CHECK(hipDeviceSynchronize());
