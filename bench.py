@@ -4,9 +4,16 @@
 A "step" is one pass of the hot path over one frame of the synthetic KITTI-like sequence
 (dynslam_amd/synth.py): UpdateView (inputs already resident in HBM) -> SetPose ->
 ProcessFrame (allocate + integrate) -> Prepare (expected depths + raycast + ICP maps).
-Workload = BASELINE.json configs[1]: static map only, 1242x375, 5 mm voxels, one GPU.
-With --gpus N every rank runs the same workload on its own volume (the path shards by
-volume): weak scaling, no data-path collective; value = N*K / max-rank time.
+At N = 1 the workload is BASELINE.json configs[1]: static map only, 1242x375, 5 mm voxels.
+With --gpus N > 1 it is configs[3]: ONE VOLUME PER GPU — the static map on rank 0, instance volume k
+(0.035 m voxels, mu 1.0, 7142 blocks) on rank k — fused every frame, plus the one real exchange of the
+path inside the timed step: every rank raycasts its volume from the shared camera, the per-volume
+depth + colour layers are ALL-GATHERED over RCCL and rank 0 z-composites them over the static map's
+render (dynslam_amd/multigpu.py ShardedScene).  value = volume-frames/s = N*K / max-rank time (weak
+scaling: one volume per GPU); the line also carries composited frames/s and, measured on rank 0 after the
+timed region, the same N volumes TIME-SLICED ON ONE GPU (north_star's denominator).
+`--volumes V` runs that workload with V volumes on any number of GPUs (N = 1: all time-sliced);
+`--replicas` restores N independent copies of configs[1] (no collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
 extra objects "roofline" (dominant kernel: integrate) and "cpu_baseline" (the CPU oracle on
@@ -73,7 +80,7 @@ def pmc_traffic(args, kernel, visible_blocks_per_launch):
     bytes PER VISIBLE BLOCK (measured over the profiled launches) and the figure reported here is
     that x this run's visible blocks per launch — valid for any --steps / --warmup of the same
     workload (preset, image size, static map only).  Returns (bytes per launch, source file)."""
-    if args.width != 1242 or args.height != 375 or args.decay or args.swap or args.instances:
+    if args.width != 1242 or args.height != 375 or args.decay or args.swap or args.instances or getattr(args, "volumes", 0) > 1:
         return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench{args.preset}_pmc_traffic.json")))
@@ -138,6 +145,181 @@ def cpu_baseline(frames, w, h, preset, budget_s):
                       f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {tn:.1f} s; single thread: first {d1} frames, {t1:.1f} s"}
 
 
+def through_shim(frames, w, h, intr, kw, warmup):
+    """SURVEY 8d "through-shim" rate: the C++ host shim/host_bench (our driver class over shim/ITMLib.h, the
+    ITMLib names DynSLAM's InfiniTamDriver uses) fed with the SAME frames as pageable host buffers; per frame
+    it pays what DynSLAM's host pays around the engine: BGR->RGBA conversion, the H2D copy of the frame,
+    ProcessFrame, one status / noVisibleBlocks synchronisation, Prepare, the two preview conversions with their
+    D2H copies.  PCIe inclusive — never `value`."""
+    exe = os.path.join(ROOT, "shim", "host_bench")
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_through_shim import run
+    r = run(exe, frames, w, h, intr, kw, warmup)
+    return {"frames_per_s": float(r["frames_per_s"]), "ms_per_frame": float(r["ms_per_frame"]), "host": "shim/host_bench.cpp (C++)",
+            "note": "same frames and table sizes, handed over as pageable host BGR + int16 buffers through shim/ITMLib.h; "
+                    "includes BGR->RGBA, H2D, one host synchronisation per frame, preview conversions + D2H (PCIe inclusive)"}
+
+
+def roofline_from_profile(prof, args, copy_gbs):
+    """-> (roofline object of the dominant kernel k_integrate, per-kernel timing dict) from the engine's HIP-event
+    profile (dsr_profile_get) of the timed region."""
+    roofline = None
+    kernels = {}
+    for r in prof:
+        kernels[r["name"]] = {"ms_total": round(r["total_ms"], 4), "launches": r["launches"],
+                              "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
+                              "GBps": round(r["bytes"] / (r["total_ms"] * 1e6), 1) if r["total_ms"] > 0 and r["bytes"] > 0 else None}
+        if r["name"] == "integrate" and r["total_ms"] > 0:
+            avg_s = r["total_ms"] * 1e-3 / r["launches"]
+            v_per_launch = r["units"] / r["launches"]
+            layout = r["bytes_layout"] / r["launches"]   # compulsory bytes of the layout in use (DESIGN.md byte model)
+            aos = r["bytes"] / r["launches"]             # SURVEY 8d: the reference's AoS formulation
+            achieved = layout / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(args, "k_integrate", v_per_launch)
+            roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic,
+                        # the same launch priced with the bytes it really moved (PMC, profiles/)
+                        "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
+                        "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                        "traffic_source": traffic_src,
+                        "measured_copy_GBps": copy_gbs,
+                        "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                        "avg_launch_us": round(1e6 * avg_s, 2),
+                        "bytes_per_launch": round(layout, 0),
+                        "visible_blocks_per_launch": round(v_per_launch, 1),
+                        "algorithmic_aos": {"bytes_per_launch": round(aos, 0), "GBps": round(aos / avg_s / 1e9, 1),
+                                            "note": "SURVEY 8d: V*(16+2*4096)+8P — every voxel of every visible block read "
+                                                    "and written as an 8 B struct; NOT what this layout moves, kept for reference"},
+                        "note": "achieved = layout-true compulsory bytes / HIP-event duration: per visible block 4 B list id "
+                                "+ 16 B hash entry + 1536 B sdf and w_depth planes read, 24 B written per lane that updated a "
+                                "voxel, 10 B per colour voxel, 8 B per pixel of the frames (tallied by the kernel itself); "
+                                "traffic = rocprofv3 PMC bytes per visible block (profiles/) x this run's visible blocks"}
+    return roofline, kernels
+
+
+def main_volumes(args):
+    """BASELINE configs[3] (see the module docstring): V volumes sharded over the ranks, fusion + fused preview per step."""
+    V = args.volumes
+    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
+    frames = make_frames(W, H, Wm + K, V - 1)  # before HIP / RCCL start (fork)
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+    from dynslam_amd.multigpu import ShardedScene, volumes_of_rank
+    from dynslam_amd.synth import StreetScene
+    sc = StreetScene(W, H, n_instances=V - 1)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    kw = settings_kwargs(args.preset)
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                   sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
+    view_kw = dict(kw, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
+    kinds = {"static": kw, "instance": inst_kw, "view": view_kw}
+
+    def make_engine(kind):
+        return EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib)
+
+    rgb_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    dep_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    track_ids = {k: 1 + k for k in range(V - 1)}
+    pose_m = [np.linalg.inv(np.asarray(f[2], np.float64)).astype(np.float32) for f in frames]
+    inst_m = [{k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in f[3]} for f in frames]
+    torch.cuda.synchronize()
+
+    def run(scene, nranks):
+        def step(i):
+            scene.step(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr(), frames[i][2], frames[i][3])
+            scene.preview(pose_m[i], inst_m[i], track_ids)
+
+        def barrier():
+            scene.sync()
+            torch.cuda.synchronize()
+            if nranks > 1:
+                dist.barrier()
+            scene.sync()
+            torch.cuda.synchronize()
+        for i in range(Wm):
+            step(i)
+        if getattr(scene, "after_warmup", None):
+            scene.after_warmup()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            step(i)
+        barrier()
+        return time.perf_counter() - t0
+
+    scene = ShardedScene(make_engine, W, H, V, world, rank, dev)
+    prof = []
+    if scene.owns_static and not args.no_profile:  # HIP events around the static map's integrate + raycast
+        scene.static.profile_enable(2)
+
+        def _reset():
+            scene.static.sync()
+            scene.static.profile_reset()
+        scene.after_warmup = _reset
+    elapsed = run(scene, world)
+    if scene.owns_static and not args.no_profile:
+        prof = scene.static.profile_get()
+        scene.static.profile_enable(False)
+    stats = scene.static.get_stats() if scene.owns_static else None
+    hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
+    scene.close()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sliced = None
+    if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
+        one = ShardedScene(make_engine, W, H, V, 1, 0, dev)
+        t1 = run(one, 1)
+        one.close()
+        sliced = {"composited_frames_per_s": round(K / t1, 3), "ms_per_step": round(1e3 * t1 / K, 4),
+                  "note": f"the same {V} volumes fused + previewed sequentially on rank 0's GPU, same frames"}
+
+    if rank == 0:
+        roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's static map: the dominant kernel of the job
+        out = {
+            "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
+            "value": round(V * K / elapsed, 3) if world > 1 else round(K / elapsed, 3),
+            "unit": "volume-frames/s" if world > 1 else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[3]: static map (preset {args.preset}) + {V - 1} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
+                                   f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1)), synthetic "
+                                   f"KITTI-like street {W}x{H} with {V - 1} moving boxes, frames {Wm}..{Wm + K - 1}; every step = silhouette "
+                                   f"split + fusion (allocate, integrate, raycast) of every volume + fused preview: colour and depth raycast "
+                                   f"of every volume from the frame's camera, RCCL all-gather of the {V - 1} instance layers "
+                                   f"({(V - 1) * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
+                       "volumes": V, "volumes_per_rank": [len(volumes_of_rank(r, V, world)) for r in range(world)],
+                       "composited_frames_per_s": round(K / elapsed, 3),
+                       "preview_hit_fraction": round(hit, 4),
+                       "static_visible_blocks_last_frame": stats.no_visible_blocks if stats else None,
+                       "status": stats.sticky_status if stats else None},
+            "time_sliced_1gpu": sliced,
+            "speedup_vs_time_sliced_1gpu": round((K / elapsed) / sliced["composited_frames_per_s"], 3) if sliced else None,
+            "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +330,8 @@ def main():
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="per CPU leg (all cores, one thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-through-shim", action="store_true",
+                    help="skip the C++-host leg (shim/host_bench: the same frames as pageable host buffers through the ITMLib shim)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--profile-all", action="store_true",
                     help="bracket every kernel with HIP events (default: integrate and raycast only; the events "
@@ -161,7 +345,17 @@ def main():
     ap.add_argument("--instances", type=int, default=0,
                     help="configs[2]: also reconstruct this many moving instances in their own volumes "
                          "(voxel 0.035, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379), split on the GPU")
+    ap.add_argument("--volumes", type=int, default=0,
+                    help="configs[3]: static map + (V-1) instance volumes sharded one per GPU with the fused-preview "
+                         "all-gather + composite in the timed step (default when --gpus > 1: V = number of GPUs)")
+    ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
+    ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of the configs[3] line")
     args = ap.parse_args()
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.volumes == 0 and world_env > 1 and not args.replicas:
+        args.volumes = world_env
+    if args.volumes > 1:
+        return main_volumes(args)
 
     # synthetic frames first: the worker pool forks, which must happen before HIP / RCCL start
     frames = make_frames(args.width, args.height, args.warmup + args.steps, args.instances)
@@ -262,44 +456,19 @@ def main():
 
     if rank == 0:
         total_frames = K * world
-        roofline = None
-        kernels = {}
-        for r in prof:
-            kernels[r["name"]] = {"ms_total": round(r["total_ms"], 4), "launches": r["launches"],
-                                  "avg_us": round(1e3 * r["total_ms"] / max(1, r["launches"]), 2),
-                                  "GBps": round(r["bytes"] / (r["total_ms"] * 1e6), 1) if r["total_ms"] > 0 and r["bytes"] > 0 else None}
-            if r["name"] == "integrate" and r["total_ms"] > 0:
-                avg_s = r["total_ms"] * 1e-3 / r["launches"]
-                v_per_launch = r["units"] / r["launches"]
-                layout = r["bytes_layout"] / r["launches"]   # compulsory bytes of the layout in use (DESIGN.md byte model)
-                aos = r["bytes"] / r["launches"]             # the reference's AoS formulation
-                achieved = layout / avg_s / 1e9
-                traffic, traffic_src = pmc_traffic(args, "k_integrate", v_per_launch)
-                roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                            "traffic": traffic,
-                            # the same launch priced with the bytes it really moved (PMC, profiles/)
-                            "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
-                            "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                            "traffic_source": traffic_src,
-                            "measured_copy_GBps": copy_gbs,
-                            "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
-                            "avg_launch_us": round(1e6 * avg_s, 2),
-                            "bytes_per_launch": round(layout, 0),
-                            "visible_blocks_per_launch": round(v_per_launch, 1),
-                            "algorithmic_aos": {"bytes_per_launch": round(aos, 0), "GBps": round(aos / avg_s / 1e9, 1),
-                                                "note": "SURVEY 8d: V*(16+2*4096)+8P — every voxel of every visible block read "
-                                                        "and written as an 8 B struct; NOT what this layout moves, kept for reference"},
-                            "note": "achieved = layout-true compulsory bytes / HIP-event duration: per visible block 4 B list id "
-                                    "+ 16 B hash entry + 1536 B sdf and w_depth planes read, 24 B written per lane that updated a "
-                                    "voxel, 10 B per colour voxel, 8 B per pixel of the frames (tallied by the kernel itself); "
-                                    "traffic = rocprofv3 PMC bytes per visible block (profiles/) x this run's visible blocks"}
+        roofline, kernels = roofline_from_profile(prof, args, copy_gbs)
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is an N = 1 item
             try:
                 cpu = cpu_baseline(frames, W, H, args.preset, args.cpu_budget_s)
             except Exception as ex:  # the baseline must never take the bench line down
                 cpu = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {ex}"}
+        shim = None
+        if (not args.no_through_shim and world == 1 and not (args.decay or args.swap or args.instances or args.host_views)):
+            try:  # the engines above are idle by now; the host process creates its own
+                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm)
+            except Exception as ex:
+                shim = {"frames_per_s": None, "note": f"failed: {ex}"}
         out = {
             "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
             "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -313,7 +482,7 @@ def main():
                        "visible_blocks_last_frame": stats.no_visible_blocks,
                        "allocated_blocks": kw["sdf_local_block_num"] - 1 - stats.last_free_block_id,
                        "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "through_shim": shim, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
     for ie in inst_eng:

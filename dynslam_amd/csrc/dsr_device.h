@@ -21,11 +21,12 @@ constexpr int kBlockBytes = 4096;             // one voxel block in HBM
 // Plane-wise voxel block layout in HBM (4096 B per block, DESIGN.md "HBM layout"):
 //   [   0,1024) int16  sdf[512]
 //   [1024,1536) uint8  w_depth[512]
-//   [1536,2048) uint8  w_color[512]
-//   [2048,4096) uchar4 clr[512]   (r,g,b,0)
+//   [1536,2048) unused
+//   [2048,4096) uchar4 clr[512]   (r,g,b,w_color): colour and its weight in ONE word — the colour update of
+//               a voxel reads and writes a single 4-byte word (one cache line per voxel instead of two:
+//               the colour phase touches lines sparsely, every line it does not touch is traffic saved)
 constexpr int kOffSdf = 0;
 constexpr int kOffWDepth = 1024;
-constexpr int kOffWColor = 1536;
 constexpr int kOffClr = 2048;
 
 constexpr float kFarAway = 999999.9f;  // FAR_AWAY

@@ -134,6 +134,7 @@ struct dsr_engine {
   SceneP scene{};
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
+  int integrateVar = 1;             // k_integrate formulation (k_integrate.h VAR); env DSR_INTEGRATE_VAR
   uint2 *integrateStats = nullptr;  // per wave of k_integrate: {lanes that stored depth planes, colour voxels}
   int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
   // free-view cache: DynSLAM renders several image types from ONE pose per redraw (GetImage colour +
@@ -167,8 +168,8 @@ struct dsr_engine {
   long long framesProcessed = 0;
 
   // voxel GC FIFO of visible lists
-  std::vector<int32_t *> fifoSlots;  // ring storage (device), each noBlocks ints
-  int32_t *fifoCounts = nullptr;     // device, one int per slot
+  uint32_t *fifoPlanes = nullptr;    // ring storage (device): fifoCap planes of fifoPlaneWords words, a bit per entry (k_decay.h)
+  size_t fifoPlaneWords = 0;
   int fifoCap = 0, fifoHead = 0, fifoLen = 0;
   int32_t *decayCand = nullptr;      // forceAll candidate list
   // host swapping (use_swapping): ITMGlobalCache = host store of plane-wise 4 KiB blocks
@@ -313,8 +314,7 @@ void free_all(dsr_engine *e) {
   }
   F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
-  for (auto p : e->fifoSlots) F(p);
-  F(e->fifoCounts); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
+  F(e->fifoPlanes); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
   F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
   F(e->scene.swapSlot); F(e->scene.hostSlabs);
   if (e->hostUsedSeen) (void)hipHostFree(e->hostUsedSeen);
@@ -420,15 +420,18 @@ int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
-#define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
-  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
+#define LAUNCH_INTEGRATE(A, B, VOX, OCC, VAR)                                                                \
+  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, VAR>), dim3(e->gridIntegrate), dim3(256), p, e->scene,  \
          (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs, e->integrateStats)
-#define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
+#define LAUNCH_INTEGRATE_V(VOX, OCC, VAR)                                                                    \
   do {                                                                                                       \
-    if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
-    else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC); else LAUNCH_INTEGRATE(false, false, VOX, OCC); }         \
+    if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC, VAR); else LAUNCH_INTEGRATE(true, false, VOX, OCC, VAR); } \
+    else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC, VAR); else LAUNCH_INTEGRATE(false, false, VOX, OCC, VAR); }         \
   } while (0)
-  LAUNCH_INTEGRATE_V(8, 7);  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h)
+  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h); formulation 1 unless the
+  // image is too small for its bounds test on float bits (W - 2 >= 1 needed) or DSR_INTEGRATE_VAR=0
+  if (e->integrateVar == 1 && e->W >= 3 && e->H >= 3) LAUNCH_INTEGRATE_V(8, 7, 1);
+  else LAUNCH_INTEGRATE_V(8, 7, 0);
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
@@ -471,29 +474,21 @@ int sticky_status(dsr_engine *e, int *status) {
 
 int ensure_fifo(dsr_engine *e, int slotsNeeded) {
   if (slotsNeeded <= e->fifoCap) return DSR_OK;
-  // grow the ring, keeping queue order
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  std::vector<int32_t *> ns((size_t)slotsNeeded, nullptr);
-  int32_t *ncounts = nullptr;
-  int st = dmalloc(&ncounts, (size_t)slotsNeeded);
+  // grow the ring (min_age went up), keeping queue order; (min_age + 1) x E / 8 bytes in total
+  e->fifoPlaneWords = ((size_t)e->E + 31) / 32;
+  uint32_t *np = nullptr;
+  int st = dmalloc(&np, (size_t)slotsNeeded * e->fifoPlaneWords);
   if (st) return st;
-  for (int i = 0; i < slotsNeeded; ++i) {
-    if (i < e->fifoLen) {
-      int old = (e->fifoHead + i) % e->fifoCap;
-      ns[i] = e->fifoSlots[old];
-      e->fifoSlots[old] = nullptr;
-      HIP_TRY(hipMemcpy(ncounts + i, e->fifoCounts + old, 4, hipMemcpyDeviceToDevice));
-    }
+  for (int i = 0; i < e->fifoLen; ++i) {
+    const int old = (e->fifoHead + i) % e->fifoCap;
+    HIP_TRY(hipMemcpyAsync(np + (size_t)i * e->fifoPlaneWords, e->fifoPlanes + (size_t)old * e->fifoPlaneWords,
+                           e->fifoPlaneWords * 4, hipMemcpyDeviceToDevice, e->stream));
   }
-  for (auto p : e->fifoSlots) if (p) { // unused old slots are recycled
-    for (int i = 0; i < slotsNeeded; ++i) if (!ns[i]) { ns[i] = p; p = nullptr; break; }
-    if (p) (void)hipFree(p);
+  if (e->fifoPlanes) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->fifoPlanes);
   }
-  for (int i = 0; i < slotsNeeded; ++i)
-    if (!ns[i]) { st = dmalloc(&ns[i], (size_t)e->noBlocks); if (st) return st; }
-  if (e->fifoCounts) (void)hipFree(e->fifoCounts);
-  e->fifoCounts = ncounts;
-  e->fifoSlots.swap(ns);
+  e->fifoPlanes = np;
   e->fifoCap = slotsNeeded;
   e->fifoHead = 0;
   return DSR_OK;
@@ -674,6 +669,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
+  if (const char *iv = getenv("DSR_INTEGRATE_VAR")) e->integrateVar = atoi(iv);
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();
@@ -944,12 +940,21 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
     int st = ensure_fifo(e, std::max(min_age + 1, e->fifoLen + 1));
     if (st) return st;
     const int slot = (e->fifoHead + e->fifoLen) % e->fifoCap;
-    LAUNCH(e, "decay_fifo_push", k_fifo_push, dim3(512), dim3(256), (const int32_t *)rs.visibleIDs,
-           (const int32_t *)e->scene.ctr, e->fifoSlots[slot], e->fifoCounts + slot);
+    uint32_t *plane = e->fifoPlanes + (size_t)slot * e->fifoPlaneWords;
+    HIP_TRY(hipMemsetAsync(plane, 0, e->fifoPlaneWords * 4, e->stream));
+    LAUNCH(e, "decay_fifo_push", k_fifo_push_bits, dim3(512), dim3(256), (const int32_t *)rs.visibleIDs,
+           (const int32_t *)e->scene.ctr, plane);
     e->fifoLen++;
     if (e->fifoLen <= min_age) { HIP_TRY(hipGetLastError()); return DSR_OK; }
-    cand = e->fifoSlots[e->fifoHead];
-    nCandPtr = e->fifoCounts + e->fifoHead;
+    // pop the oldest plane: ordered compaction of its set bits = the visible list that was pushed
+    const uint8_t *oldest = reinterpret_cast<const uint8_t *>(e->fifoPlanes + (size_t)e->fifoHead * e->fifoPlaneWords);
+    LAUNCH(e, "decay_candidates", k_bits_count, dim3(e->numTilesE), dim3(kTileThreads), oldest, e->E, e->tileSums);
+    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_NCAND,
+           e->noBlocks);
+    LAUNCH(e, "decay_candidates", k_bits_write, dim3(e->numTilesE), dim3(kTileThreads), oldest, e->E, (const int2 *)e->tileSums,
+           e->decayCand, e->noBlocks);
+    cand = e->decayCand;
+    nCandPtr = e->scene.ctr + CTR_DECAY_NCAND;
     e->fifoHead = (e->fifoHead + 1) % e->fifoCap;
     e->fifoLen--;
   }
@@ -1247,7 +1252,7 @@ int dsr_dump_stored_block(dsr_engine *e, int entry, dsr_voxel *out, int *present
     for (int v = 0; v < kBlockSize3; ++v) {
       dsr_voxel o; memset(&o, 0, sizeof o);
       memcpy(&o.sdf, b + kOffSdf + v * 2, 2);
-      o.w_depth = b[kOffWDepth + v]; o.w_color = b[kOffWColor + v];
+      o.w_depth = b[kOffWDepth + v]; o.w_color = b[kOffClr + v * 4 + 3];
       o.clr[0] = b[kOffClr + v * 4]; o.clr[1] = b[kOffClr + v * 4 + 1]; o.clr[2] = b[kOffClr + v * 4 + 2];
       out[v] = o;
     }

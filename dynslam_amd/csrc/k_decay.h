@@ -55,9 +55,9 @@ __global__ __launch_bounds__(256) void k_blocks_to_aos(const uint8_t *__restrict
       dsr_voxel o;
       o.sdf = *reinterpret_cast<const short *>(blk + kOffSdf + v * 2);
       o.w_depth = blk[kOffWDepth + v];
-      o.w_color = blk[kOffWColor + v];
       uchar4 c = *reinterpret_cast<const uchar4 *>(blk + kOffClr + v * 4);
       o.clr[0] = c.x; o.clr[1] = c.y; o.clr[2] = c.z;
+      o.w_color = c.w;
       o._pad = 0;
       out[(size_t)b * kBlockSize3 + v] = o;
     }
@@ -67,11 +67,46 @@ __global__ __launch_bounds__(256) void k_blocks_to_aos(const uint8_t *__restrict
 // ------------------------------------------------------------------- voxel GC
 
 // copy the live visible list into a FIFO slot (ids + count)
-__global__ __launch_bounds__(256) void k_fifo_push(const int32_t *__restrict__ visibleIDs, const int32_t *__restrict__ ctr,
-                                                   int32_t *__restrict__ slotIDs, int32_t *__restrict__ slotCount) {
+// The voxel-GC FIFO holds the visible list of each of the last min_age + 1 Decay calls.  A list is
+// ASCENDING in entry index (ordered compaction), so it is stored as a BIT PER HASH ENTRY: a plane of
+// E / 8 bytes per queued frame (2.6 MB at 21 M entries) instead of a slot sized for the worst case
+// (noBlocks ints: 13.5 GB for min_age 200 at 2^24 blocks) — fixed size, independent of how many blocks
+// are visible, and popping a plane (k_bits_count / k_bits_write: ordered compaction again) gives back
+// exactly the list that was pushed.
+__global__ __launch_bounds__(256) void k_fifo_push_bits(const int32_t *__restrict__ visibleIDs, const int32_t *__restrict__ ctr,
+                                                        uint32_t *__restrict__ plane) {
   const int n = ctr[CTR_NO_VISIBLE_LIVE];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *slotCount = n;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) slotIDs[i] = visibleIDs[i];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t id = (uint32_t)visibleIDs[i];
+    atomicOr(&plane[id >> 5], 1u << (id & 31u));
+  }
+}
+// a thread owns kTileItems = 8 consecutive entries = one byte of the plane
+static_assert(kTileItems == 8, "one plane byte per thread");
+__global__ __launch_bounds__(kTileThreads) void k_bits_count(const uint8_t *__restrict__ plane, int noTotalEntries,
+                                                             int2 *__restrict__ tileSums) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  int2 c = make_int2(0, 0);
+  if (base < noTotalEntries) c.x = __popc((uint32_t)plane[base >> 3]);
+  int2 total;
+  wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kTileThreads) void k_bits_write(const uint8_t *__restrict__ plane, int noTotalEntries,
+                                                             const int2 *__restrict__ tileOffsets, int32_t *__restrict__ out,
+                                                             int capacity) {
+  __shared__ int2 lds[kTileThreads / 64];
+  const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
+  const uint32_t bits = base < noTotalEntries ? (uint32_t)plane[base >> 3] : 0u;
+  int2 c = make_int2(__popc(bits), 0);
+  int2 total;
+  int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
+  if (total.x == 0) return;
+  int rank = tileOffsets[blockIdx.x].x + ex.x;
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j)
+    if (bits & (1u << j)) { if (rank < capacity) out[rank] = base + j; rank++; }
 }
 
 // One wave per candidate block: reset voxels with w_depth <= maxWeight, flag the block when
@@ -92,7 +127,7 @@ __global__ __launch_bounds__(256) void k_decay_blocks(SceneP s, const int32_t *_
     const int ptr = s.table[t].ptr;
     if (ptr < 0) { if (lane == 0) freedFlag[i] = 0; continue; }
     uint8_t *blk = s.vba + (size_t)ptr * kBlockBytes;
-    // the weights decide everything: only lanes that reset a voxel touch the other three planes
+    // the weights decide everything: only lanes that reset a voxel touch the other two planes
     const uint2 wdRaw = *reinterpret_cast<const uint2 *>(blk + kOffWDepth + lane * 8);
     uint32_t wdW[2] = {wdRaw.x, wdRaw.y};
     uint32_t resetMask = 0;  // bit x: voxel x of this lane is reset
@@ -108,24 +143,20 @@ __global__ __launch_bounds__(256) void k_decay_blocks(SceneP s, const int32_t *_
       if (w == 0) empty++;
     }
     if (resetMask) {
-      // all four read-modify-writes of the lane are independent: loads first, then the stores
+      // the read-modify-writes of the lane are independent: loads first, then the stores
       const uint4 sdfRaw = *reinterpret_cast<const uint4 *>(blk + kOffSdf + lane * 16);
-      const uint2 wcRaw = *reinterpret_cast<const uint2 *>(blk + kOffWColor + lane * 8);
       const uint4 c0 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32);
       const uint4 c1 = *reinterpret_cast<const uint4 *>(blk + kOffClr + lane * 32 + 16);
       uint32_t sdfW[4] = {sdfRaw.x, sdfRaw.y, sdfRaw.z, sdfRaw.w};
-      uint32_t wcW[2] = {wcRaw.x, wcRaw.y};
       uint32_t clrW[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
       for (int x = 0; x < 8; ++x)
         if (resetMask & (1u << x)) {
           sdfW[x >> 1] = (sdfW[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (0x7fffu << ((x & 1) * 16));
-          wcW[x >> 2] &= ~(0xffu << ((x & 3) * 8));
-          clrW[x] = 0u;
+          clrW[x] = 0u;  // colour and w_color
         }
       *reinterpret_cast<uint4 *>(blk + kOffSdf + lane * 16) = make_uint4(sdfW[0], sdfW[1], sdfW[2], sdfW[3]);
       *reinterpret_cast<uint2 *>(blk + kOffWDepth + lane * 8) = make_uint2(wdW[0], wdW[1]);
-      *reinterpret_cast<uint2 *>(blk + kOffWColor + lane * 8) = make_uint2(wcW[0], wcW[1]);
       *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32) = make_uint4(clrW[0], clrW[1], clrW[2], clrW[3]);
       *reinterpret_cast<uint4 *>(blk + kOffClr + lane * 32 + 16) = make_uint4(clrW[4], clrW[5], clrW[6], clrW[7]);
     }

@@ -99,7 +99,18 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 // compile-time constants, their selects / the extra division disappear from the voxel loop and
 // the divisions by mu, 32767 and the new weight take the one-correction form.
 // OCC: waves per SIMD the register allocator must allow.
-template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
+// VAR: formulation of phases A1 / A2 (identical results, DESIGN.md "integrate variants"):
+//   0  the round-1 form: per-voxel select of the divisor and of the pixel index, four float
+//      compares for the image bounds, 64-bit addresses, colour list appended voxel by voxel;
+//   1  class-aware form (tools/ubench: compares, selects, conversions and anything with an SGPR
+//      operand issue at half the rate of plain fp32 / logic ops): no divisor select (lanes behind the
+//      camera plane are masked, what they compute is never used), image bounds as two unsigned
+//      compares on the float bits, depth gathers as RAW BUFFER loads (32-bit offsets; the hardware
+//      range check returns 0 = "no depth" for the lanes that are out of the image, so neither a
+//      clamped index nor a remembered in-bounds mask is needed), the (eta > mu) half of the colour
+//      gate dropped (implied by |eta/mu| > 0.25 for a correctly rounded quotient), colour list
+//      appended once per task from a per-lane bit mask.
+template <bool RGB_SAME, bool PLAIN, int VOX, int OCC, int VAR>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
                                                                          const int32_t *__restrict__ visibleIDs,
@@ -138,6 +149,11 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
+  // VAR 1: the depth image as a raw buffer (hardware range check) and the image bounds on float bits
+  const __amdgpu_buffer_rsrc_t depthRsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(depth), 0, (int)((uint32_t)p.W * (uint32_t)p.H * 4u), 0x00020000);
+  const int rowBytes = p.W * 4;
+  const uint32_t uLimBits = __float_as_uint(wLim) - 0x3f800000u, vLimBits = __float_as_uint(hLim) - 0x3f800000u;
 
   // ------------------------------------------------------------ colour pass
   // computeUpdatedVoxelColorInfo for `cnt` (<= 64) pending voxels starting at list position `base`,
@@ -166,10 +182,9 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       const float v = projr.y * pr.y / pr.z + projr.w;
       if (!((u < 1) || (u > wcLim) || (v < 1) || (v > hcLim))) {
         uint8_t *blk = s.vba + (size_t)bptr * kBlockBytes;
-        uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);
-        uint8_t *wcPtr = blk + kOffWColor + vox;
+        uint32_t *clrPtr = reinterpret_cast<uint32_t *>(blk + kOffClr + vox * 4);  // (r, g, b, w_color)
         const uint32_t cw = *clrPtr;
-        const int oldWcI = (int)*wcPtr;
+        const int oldWcI = (int)(cw >> 24);
         const float3 mm = bilinear_rgb(rgb, u, v, Wc);
         const float oldWc = (float)oldWcI;
         const float ocx = div_short((float)(cw & 0xffu), 255.0f, y255);
@@ -185,8 +200,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         newWc = (newWc < (float)p.maxW) ? newWc : (float)p.maxW;  // MIN(newW, maxW)
         const uint32_t r8 = (uint32_t)f2i(ncx * 255.0f) & 0xffu, g8 = (uint32_t)f2i(ncy * 255.0f) & 0xffu,
                        b8 = (uint32_t)f2i(ncz * 255.0f) & 0xffu;
-        *clrPtr = r8 | (g8 << 8) | (b8 << 16);
-        *wcPtr = (uint8_t)f2i(newWc);
+        *clrPtr = r8 | (g8 << 8) | (b8 << 16) | (((uint32_t)f2i(newWc) & 0xffu) << 24);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -238,6 +252,31 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     float pz[VOX], dm[VOX];
     bool inb[VOX];
     bool graze = false;
+    if constexpr (VAR == 1) {
+      bool allTame = true;
+#pragma unroll
+      for (int x = 0; x < VOX; ++x) {
+        const float mx = (float)(gx + x) * p.voxelSize;
+        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+        const bool tame = pc.z >= 1e-4f;
+        // lanes that are not tame (at or behind the camera plane) run the same arithmetic on whatever
+        // their z is — inf / NaN included — and are masked below
+        const float yz = rcp_refined(pc.z);
+        const float u = div_with_rcp(p.proj.x * pc.x, pc.z, yz) + p.proj.z;
+        const float v = div_with_rcp(p.proj.y * pc.y, pc.z, yz) + p.proj.w;
+        // 1 <= u <= W-2 on the bit patterns: for a finite u (tame lanes: finite operands, divisor >= 1e-4)
+        // bits(u) - bits(1.0f) as unsigned is <= bits(W-2) - bits(1.0f) exactly when u is in range
+        // (negative values and values below 1 wrap to something huge)
+        const bool in = tame && (__float_as_uint(u) - 0x3f800000u <= uLimBits) && (__float_as_uint(v) - 0x3f800000u <= vLimBits);
+        inb[x] = in;
+        const uint32_t off = in ? (uint32_t)(__mul24(f2i(v + 0.5f), rowBytes) + (f2i(u + 0.5f) << 2)) : 0xffffffffu;  // < 2^24 rows / bytes per row
+        // out of range -> the buffer load returns 0: "no depth", rejected by (dm <= 0) like an invalid pixel
+        dm[x] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(depthRsrc, (int)off, 0, 0));
+        pz[x] = pc.z;
+        allTame &= tame;
+      }
+      graze = !allTame;  // blocks touching the camera plane: decided exactly below
+    } else {
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
       const float mx = (float)(gx + x) * p.voxelSize;
@@ -254,6 +293,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       pz[x] = pc.z;
       graze |= pos && !tame;
     }
+    }
     if (__builtin_expect(__any(graze), 0)) {
       // voxels grazing the camera plane (0 < z < 1e-4): the divisor is not tame, redo them
       // with the plain IEEE divide
@@ -265,7 +305,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         const float u = p.proj.x * pc.x / pc.z + p.proj.z;
         const float v = p.proj.y * pc.y / pc.z + p.proj.w;
         inb[x] = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
-        dm[x] = depth[inb[x] ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0];
+        dm[x] = inb[x] ? depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W] : 0.0f;
       }
     }
 
@@ -276,7 +316,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     bool anyUpd = false;
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
-      ok[x] = inb[x] && !(dm[x] <= 0.0f);
+      ok[x] = (VAR == 1) ? !(dm[x] <= 0.0f) : (inb[x] && !(dm[x] <= 0.0f));  // VAR 1: out-of-image lanes read dm = 0
       eta[x] = dm[x] - pz[x];
       anyUpd |= ok[x] && !(eta[x] < -p.mu);
     }
@@ -289,6 +329,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     // compile-time flag of the loop so that the usual case carries no trace of it
     auto phaseA2 = [&](auto rejTag) {
       constexpr bool REJ = decltype(rejTag)::value;
+      uint32_t gateBits = 0;  // VAR 1: bit x = voxel x of this lane takes the colour update
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
         const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
@@ -312,15 +353,40 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         pl.wd[x >> 2] = upd ? ww : pl.wd[x >> 2];
         dirtyDepth |= upd;
         // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
-        //      voxels the depth step rejected carry eta = -1
-        const bool gateOk = !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
+        //      voxels the depth step rejected carry eta = -1.
+        //      VAR 1: q is the correctly rounded eta / mu and mu > 0, so eta > mu implies q >= 1 > 0.25:
+        //      the first comparison never decides (a NaN fails both in either form)
+        const bool gateOk = (VAR == 1) ? !(fabsf(q) > 0.25f) : !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
         const bool gate = REJ ? (!skip && (ok[x] ? gateOk : true)) : (okx && gateOk);
+        if constexpr (VAR == 1) {
+          gateBits |= gate ? (1u << x) : 0u;
+        } else {
         // append to the wave's pending colour list (ordered compaction across the 64 lanes)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
         if (gate)  // slot = number of gated lanes below this one (v_mbcnt)
           pend[nPend + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pendWord0 + (uint32_t)x;
         nPend += __popcll(m);
         statColour += (uint32_t)__popcll(m);
+        }
+      }
+      if constexpr (VAR == 1) {
+        // the task's colour voxels go to the pending list in one step: a wave prefix sum over the
+        // lanes' counts gives every lane its slots (the order inside the list is irrelevant: each
+        // entry is one independent voxel update)
+        if (__any(gateBits != 0u)) {
+          const int cnt = __popc(gateBits);
+          int inc = cnt;
+#pragma unroll
+          for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+          }
+          const int total = __builtin_amdgcn_readlane(inc, 63);
+          int slot = nPend + inc - cnt;
+          for (uint32_t b = gateBits; b; b &= b - 1u) pend[slot++] = pendWord0 + (uint32_t)(__ffs((int)b) - 1);
+          nPend += total;
+          statColour += (uint32_t)total;
+        }
       }
     };
     if (rejectedPassGate) phaseA2(std::true_type{});

@@ -148,11 +148,11 @@ __global__ __launch_bounds__(256) void k_swapin_combine(SceneP s, int maxW, cons
           }
         }
         {  // colour
-          int newW = dst[kOffWColor + v];
-          const int oldW = src[kOffWColor + v];
+          const uchar4 dc = *reinterpret_cast<const uchar4 *>(dst + kOffClr + v * 4);  // (r, g, b, w_color)
+          const uchar4 sc = *reinterpret_cast<const uchar4 *>(src + kOffClr + v * 4);
+          int newW = dc.w;
+          const int oldW = sc.w;
           if (oldW != 0) {
-            const uchar4 dc = *reinterpret_cast<const uchar4 *>(dst + kOffClr + v * 4);
-            const uchar4 sc = *reinterpret_cast<const uchar4 *>(src + kOffClr + v * 4);
             float nx = (float)dc.x / 255.0f, ny = (float)dc.y / 255.0f, nz = (float)dc.z / 255.0f;
             const float ox = (float)sc.x / 255.0f, oy = (float)sc.y / 255.0f, oz = (float)sc.z / 255.0f;
             nx = ox * (float)oldW + nx * (float)newW;
@@ -162,8 +162,7 @@ __global__ __launch_bounds__(256) void k_swapin_combine(SceneP s, int maxW, cons
             nx /= (float)newW; ny /= (float)newW; nz /= (float)newW;
             newW = newW < maxW ? newW : maxW;
             *reinterpret_cast<uchar4 *>(dst + kOffClr + v * 4) =
-                make_uchar4((uint8_t)f2i(nx * 255.0f), (uint8_t)f2i(ny * 255.0f), (uint8_t)f2i(nz * 255.0f), 0);
-            dst[kOffWColor + v] = (uint8_t)newW;
+                make_uchar4((uint8_t)f2i(nx * 255.0f), (uint8_t)f2i(ny * 255.0f), (uint8_t)f2i(nz * 255.0f), (uint8_t)newW);
           }
         }
       }

@@ -133,6 +133,14 @@ class EngineCore:
     def sync(self):
         self._check(self.api.sync(self._h))
 
+    def wait_for_stream(self, hip_stream):
+        """Engine work queued after this call starts when `hip_stream` (a hipStream_t as int) has drained."""
+        self._check(self.api.wait_for_stream(self._h, C.c_void_p(hip_stream)))
+
+    def stream_wait_for_engine(self, hip_stream):
+        """Work queued on `hip_stream` after this call starts when the engine's queued work has finished."""
+        self._check(self.api.stream_wait_for_engine(self._h, C.c_void_p(hip_stream)))
+
     def reset_scene(self):
         self._check(self.api.reset_scene(self._h))
 

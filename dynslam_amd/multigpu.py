@@ -82,6 +82,29 @@ class PreviewExchange:
                        if k in track_id_of_instance)
         return [l for _, l in items], [t for t, _ in items]
 
+    def composite_into(self, target_rgba, target_depth, track_id_of_instance, tint_strength=1.0, dim_background=True,
+                       host_api=None):
+        """composite() for tensors on either side: GPU tensors -> dsr_composite_instances_dev on torch's
+        current stream; CPU tensors (the gloo tests) -> `host_api.composite_instances` (the tests pass the
+        oracle's restatement; the product has no CPU composite)."""
+        if getattr(self.device, "type", "cpu") == "cuda":
+            return self.composite(target_rgba, target_depth, track_id_of_instance, tint_strength, dim_background)
+        api = host_api or getattr(self, "host_api", None)
+        if api is None:
+            raise RuntimeError("CPU tensors need host_api (tests only): there is no CPU fallback for the composite")
+        layers, tids = self.ordered_layers(track_id_of_instance)
+        if not layers:
+            return
+        lr = np.ascontiguousarray(self.all_rgba.numpy()[layers])
+        ld = np.ascontiguousarray(self.all_depth.numpy()[layers])
+        ids = np.asarray(tids, dtype=np.int32)
+        t_c, t_d = target_rgba.numpy(), target_depth.numpy()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        st = api.composite_instances(vp(t_c), vp(t_d), vp(lr), vp(ld), vp(ids), len(layers), self.P, float(tint_strength),
+                                     int(bool(dim_background)))
+        if st != 0:
+            raise RuntimeError("composite_instances failed")
+
     def composite(self, target_rgba, target_depth, track_id_of_instance, tint_strength=1.0, dim_background=True,
                   stream_ptr=None):
         """z-composite the gathered layers into target_* (torch tensors on this rank's GPU)
@@ -107,3 +130,121 @@ class PreviewExchange:
         if st != 0:
             raise RuntimeError(f"dsr_composite_instances_dev failed: {api.last_error().decode()}")
         self._keepalive = (lr, ld, ids)
+
+
+class ShardedScene:
+    """BASELINE configs[3] as one object per rank: the static map on rank 0, instance volume k on
+    rank 1 + (k mod (world-1)) (`volume_owner`), fused per frame by `step()`; `preview()` renders every
+    volume from the shared camera, ALL-GATHERS the instance layers (depth f32 + RGBA) and z-composites
+    them over the static map's render on rank 0 — DynSlam::GetStaticMapRaycastPreview +
+    InstanceReconstructor::CompositeInstances (DynSlam.h:96-132, InstanceReconstructor.cpp:911-990)
+    with the volumes on different GPUs.
+
+    `make_engine(kind)` returns an EngineCore-like object for kind in {"static", "instance", "view"}:
+    "view" is a volume-less holder of the full input frame on ranks that own instances but not the
+    static map (ProcessSilhouette reads the full frame: InstanceReconstructor.cpp:59-133).  Engines
+    on a GPU are driven through the "_dev" entry points and never synchronise with the host; with CPU
+    tensors (the gloo tests run the CPU oracle through this same class) the host-buffer entry points
+    are used.
+    """
+
+    def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None):
+        import torch
+        self.torch = torch
+        self.W, self.H, self.P = int(width), int(height), int(width) * int(height)
+        self.world, self.rank, self.device = int(world_size), int(rank), device
+        self.n_volumes = int(n_volumes)
+        self.on_gpu = getattr(device, "type", "cpu") == "cuda"
+        mine = volumes_of_rank(rank, n_volumes, world_size)
+        self.owns_static = 0 in mine
+        self.static = make_engine("static") if self.owns_static else None
+        self.instances = {v - 1: make_engine("instance") for v in mine if v > 0}
+        # the full frame the instance views are cut from
+        self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
+        self.exchange = PreviewExchange(self.P, n_volumes, world_size, rank, device, group)
+        self.target_rgba = torch.zeros((self.P, 4), dtype=torch.uint8, device=device)
+        self.target_depth = torch.zeros((self.P,), dtype=torch.float32, device=device)
+
+    def engines(self):
+        out = ([self.static] if self.static is not None else []) + list(self.instances.values())
+        if self.source is not None and self.source is not self.static:
+            out.append(self.source)
+        return out
+
+    def close(self):
+        for e in self.engines():
+            e.close()
+
+    def sync(self):
+        for e in self.engines():
+            e.sync()
+
+    # -- fusion -----------------------------------------------------------------------------
+    def step(self, rgba, depth_mm, static_pose, masks):
+        """One frame.  rgba / depth_mm: numpy arrays (host path) or device pointers (ints) of the full
+        frame, resident on this rank's GPU; static_pose: camera->world of the static map;
+        masks: [(instance k, x0, y0, bbox-local uint8 mask, camera->object pose of k)] for EVERY
+        instance (each rank picks its own).  Order per rank as on one GPU: cut the instance views out
+        of the full frame, blank them in the static view, fuse (InstanceReconstructor.cpp:238-263,569-700)."""
+        if self.source is not None:
+            if isinstance(rgba, int):
+                self.source.update_view_dev(rgba, depth_mm)
+            else:
+                self.source.update_view(rgba, depth_mm)
+        for k, x0, y0, mask, rel in masks:
+            ie = self.instances.get(k)
+            if ie is not None:
+                self.source.extract_silhouette(ie, mask, x0, y0)
+            if self.owns_static:
+                self.static.remove_silhouette(mask, x0, y0)
+            if ie is not None:
+                ie.set_pose_inv_m(rel)
+                ie.process_frame()
+                ie.prepare()
+        if self.owns_static:
+            self.static.set_pose_inv_m(static_pose)
+            self.static.process_frame()
+            self.static.prepare()
+
+    # -- fused preview ----------------------------------------------------------------------
+    def _render(self, eng, pose_m, rgba_t, depth_t):
+        from . import _capi
+        if self.on_gpu:
+            eng.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m, None, rgba_t.data_ptr(), None)
+            eng.get_image_dev(_capi.IMAGE_FREECAMERA_DEPTH, pose_m, None, None, depth_t.data_ptr())
+        else:
+            c, _ = eng.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=pose_m)
+            _, d = eng.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=pose_m, want_rgba=False, want_depth=True)
+            rgba_t.copy_(self.torch.from_numpy(c.reshape(self.P, 4)))
+            depth_t.copy_(self.torch.from_numpy(d.reshape(self.P)))
+
+    def preview(self, static_pose_m, instance_pose_m, track_id_of_instance, tint_strength=1.0, dim_background=True):
+        """static_pose_m: world->camera of the preview camera; instance_pose_m[k]: object k -> camera
+        (the model view composed with the instance pose, InstanceReconstructor.cpp:923,968).
+        Returns (rgba, depth) tensors of the composited preview on rank 0, (None, None) elsewhere.
+        Nothing here waits on the host: the engine streams, the collective and the composite are
+        ordered with events (dsr_stream_wait_for_engine)."""
+        torch = self.torch
+        ex = self.exchange
+        cur = torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else None
+        for slot, k in enumerate(ex.local_instances):
+            ie = self.instances[k]
+            if self.on_gpu:
+                ie.wait_for_stream(cur)  # the previous frame's all-gather has to be done with this slot
+            if k in instance_pose_m:
+                self._render(ie, instance_pose_m[k], ex.local_rgba[slot], ex.local_depth[slot])
+            else:  # not visible in this frame: an empty layer never wins a pixel
+                ex.local_depth[slot].zero_()
+            if self.on_gpu:
+                ie.stream_wait_for_engine(cur)  # the all-gather (torch's stream) reads what the engine stream writes
+        if self.owns_static:
+            if self.on_gpu:
+                self.static.wait_for_stream(cur)  # ... and the previous composite with the target
+            self._render(self.static, static_pose_m, self.target_rgba, self.target_depth)
+            if self.on_gpu:
+                self.static.stream_wait_for_engine(cur)
+        ex.gather()
+        if self.rank != 0:
+            return None, None
+        ex.composite_into(self.target_rgba, self.target_depth, track_id_of_instance, tint_strength, dim_background)
+        return self.target_rgba, self.target_depth

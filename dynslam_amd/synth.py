@@ -80,7 +80,9 @@ class StreetScene:
         T = np.eye(4)
         lane = -2.0 if (k % 2 == 0) else 2.0
         z0 = 8.0 + 3.5 * k
-        speed = (0.5 + 0.1 * k) * self.step_m  # slower than the camera: gets overtaken
+        # slower than the camera: gets overtaken; boxes 4.. (configs[3]: 7 instances) start beyond the 20 m
+        # depth clip and are slow enough to come into range within ~15 frames
+        speed = ((0.5 + 0.1 * k) if k < 4 else 0.3) * self.step_m
         T[:3, 3] = [lane, 1.65 - 0.75, z0 + speed * i]
         return T.astype(np.float32)
 

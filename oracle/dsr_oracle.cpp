@@ -713,6 +713,19 @@ static long long g_rc_stats[8];
 static bool g_rc_stats_on = false;
 static int *g_rc_steps = nullptr;  /* per-pixel step counts of the last raycast (orc_debug_raycast_steps) */
 static int g_rc_steps_w = 0;
+/* orc_debug_raycast_stats2: what-if counters for two march accelerations (oracle-only study):
+ * [0] found steps, [1] of those in blocks whose 512 sdf are all 32767 ("saturated block": the value is
+ * known from the entry alone), [2] found steps with sdf == 1 in other blocks, [3] miss steps,
+ * [4..6] miss steps inside a 2^3 / 4^3 / 8^3-block super-cell without ANY allocated block (the miss is
+ * known without a table read), [7] rays */
+static long long g_rc2[8];
+static bool g_rc2_on = false;
+static std::vector<uint8_t> g_rc2_blockSat;             /* per block index */
+static std::unordered_map<unsigned long long, uint8_t> g_rc2_super[3]; /* occupied super-cells, 2/4/8 blocks wide */
+static inline unsigned long long rc2_key(int bx, int by, int bz, int sh) {
+  return ((unsigned long long)(unsigned short)(bx >> sh)) | ((unsigned long long)(unsigned short)(by >> sh) << 16) |
+         ((unsigned long long)(unsigned short)(bz >> sh) << 32);
+}
 
 /* ITMVisualisationEngine.h castRay */
 static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 &invM, const V4f &invProj,
@@ -749,8 +762,21 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
   IndexCache cache;
 
   long long nMiss = 0, nFar = 0, nTri = 0, nSat = 0;
+  long long c2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   while (totalLength < totalLengthMax) {
     sdfValue = readFromSDF_float_uninterpolated(e, pt_result, hash_found, cache);
+    if (g_rc2_on) {
+      V3i vp = {f2i(ROUNDF(pt_result.x)), f2i(ROUNDF(pt_result.y)), f2i(ROUNDF(pt_result.z))}, bp;
+      pointToVoxelBlockPos(vp, bp);
+      if (!hash_found) {
+        c2[3]++;
+        for (int k = 0; k < 3; k++) if (!g_rc2_super[k].count(rc2_key(bp.x, bp.y, bp.z, k + 1))) c2[4 + k]++;
+      } else {
+        c2[0]++;
+        if (cache.blockPtr >= 0 && g_rc2_blockSat[(size_t)(cache.blockPtr / DSR_BLOCK_SIZE3)]) c2[1]++;
+        else if (sdfValue >= 1.0f) c2[2]++;
+      }
+    }
     if (!hash_found) {
       stepLength = DSR_BLOCK_SIZE;
       nMiss++;
@@ -774,6 +800,10 @@ static inline bool castRay(const Engine &e, V4f &pt_out, int x, int y, const M4 
     pt_found = true;
   } else pt_found = false;
 
+  if (g_rc2_on) {
+#pragma omp critical
+    { for (int k = 0; k < 7; k++) g_rc2[k] += c2[k]; g_rc2[7]++; }
+  }
   if (g_rc_stats_on) {
 #pragma omp critical
     {
@@ -1806,6 +1836,27 @@ int orc_debug_raycast_stats(int enable, int reset, long long out[8]) {
 
 /* oracle-only: record the number of march steps of every ray of the following raycasts into
  * out[W*H] (NULL stops recording) */
+int orc_debug_raycast_stats2(void *engine, int enable, long long out[8]) {
+  g_rc2_on = enable != 0;
+  if (out) memcpy(out, g_rc2, sizeof g_rc2);
+  memset(g_rc2, 0, sizeof g_rc2);
+  if (g_rc2_on && engine) { /* snapshot of the scene the NEXT raycast will march through */
+    Engine &e = reinterpret_cast<dsr_engine *>(engine)->e;
+    g_rc2_blockSat.assign((size_t)e.noBlocks, 0);
+    for (int k = 0; k < 3; k++) g_rc2_super[k].clear();
+    for (int t = 0; t < e.noTotalEntries; t++) {
+      const dsr_hash_entry &he = e.hashTable[t];
+      if (he.ptr < 0) continue;
+      const dsr_voxel *blk = &e.voxels[(size_t)he.ptr * DSR_BLOCK_SIZE3];
+      bool sat = true;
+      for (int v = 0; v < DSR_BLOCK_SIZE3 && sat; v++) sat = blk[v].sdf == 32767;
+      g_rc2_blockSat[(size_t)he.ptr] = sat;
+      for (int k = 0; k < 3; k++) g_rc2_super[k][rc2_key(he.pos[0], he.pos[1], he.pos[2], k + 1)] = 1;
+    }
+  }
+  return 0;
+}
+
 int orc_debug_raycast_steps(int *out, int width) {
   g_rc_steps = out; g_rc_steps_w = width;
   return DSR_OK;

@@ -25,3 +25,17 @@ def test_hip_matches_golden(hip_api, name):
     got = run_case(hip_factory, CASES[name])
     diff = {k: (got[k], GOLD[name][k]) for k in got if got[k] != GOLD[name][k]}
     assert not diff, f"fields differing from the golden fixture: {sorted(diff)}"
+
+
+def test_fullsize_fixture_covers_every_benched_case():
+    """tests/golden/fullsize_digests.json (made offline by make_golden_fullsize.py; replayed on the GPU by
+    tests/test_gpu_fullsize_golden.py) holds one per-frame record for every frame of every case."""
+    from tests.golden.make_golden_fullsize import CASES as FULL
+    doc = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize_digests.json")))["cases"]
+    for name, case in FULL.items():
+        assert name in doc and len(doc[name]["frames"]) == case["frames"]
+        last = doc[name]["frames"][-1]
+        assert "voxels_in_use" in last and "raycast_result" in last and len(last["hash_table"]) == 64
+    assert doc["cfg5_4mm_gc_swap"]["frames"][-1]["decayed_block_count"] > 0
+    assert doc["cfg5_4mm_gc_swap"]["frames"][-1]["swap_stored_count"] > 0
+    assert len(doc["cfg2_instances"]["frames"][-1]["instances"]) == 4

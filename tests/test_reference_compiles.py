@@ -132,7 +132,7 @@ def test_reference_driver_runs_on_the_hip_engine(hip_api, tmp_path):
     assert e.api.depth_m_to_mm(dep.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p), W * H) == 0
     assert e.api.rgba_to_bgr(col.ctypes.data_as(C.c_void_p), bgr.ctypes.data_as(C.c_void_p), W * H) == 0
     h = fnv(bgr.tobytes(), fnv(mm.tobytes(), fnv(vdepth.tobytes(), fnv(dep.tobytes(), fnv(col.tobytes())))))
-    assert (dep > 0).mean() > 0.3 and st.decayed_block_count > 0
+    assert (dep > 0).mean() > 0.05 and st.decayed_block_count > 0
     for exe in exes:
         out = subprocess.check_output([exe] + args).decode().strip()
         got = dict(kv.split("=") for kv in out.split())
