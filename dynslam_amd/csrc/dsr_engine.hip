@@ -134,7 +134,6 @@ struct dsr_engine {
   SceneP scene{};
   RenderStateDev live, freeview;
   int2 *tileSums = nullptr;
-  int integrateVar = 1;             // k_integrate formulation (k_integrate.h VAR); env DSR_INTEGRATE_VAR
   uint2 *integrateStats = nullptr;  // per wave of k_integrate: {lanes that stored depth planes, colour voxels}
   int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
   // free-view cache: DynSLAM renders several image types from ONE pose per redraw (GetImage colour +
@@ -420,18 +419,15 @@ int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
-#define LAUNCH_INTEGRATE(A, B, VOX, OCC, VAR)                                                                \
-  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, VAR>), dim3(e->gridIntegrate), dim3(256), p, e->scene,  \
+#define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
+  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
          (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs, e->integrateStats)
-#define LAUNCH_INTEGRATE_V(VOX, OCC, VAR)                                                                    \
+#define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
   do {                                                                                                       \
-    if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC, VAR); else LAUNCH_INTEGRATE(true, false, VOX, OCC, VAR); } \
-    else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC, VAR); else LAUNCH_INTEGRATE(false, false, VOX, OCC, VAR); }         \
+    if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
+    else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC); else LAUNCH_INTEGRATE(false, false, VOX, OCC); }         \
   } while (0)
-  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h); formulation 1 unless the
-  // image is too small for its bounds test on float bits (W - 2 >= 1 needed) or DSR_INTEGRATE_VAR=0
-  if (e->integrateVar == 1 && e->W >= 3 && e->H >= 3) LAUNCH_INTEGRATE_V(8, 7, 1);
-  else LAUNCH_INTEGRATE_V(8, 7, 0);
+  LAUNCH_INTEGRATE_V(8, 7);  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h)
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
@@ -669,7 +665,6 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
-  if (const char *iv = getenv("DSR_INTEGRATE_VAR")) e->integrateVar = atoi(iv);
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();

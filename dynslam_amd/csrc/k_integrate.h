@@ -99,18 +99,19 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 // compile-time constants, their selects / the extra division disappear from the voxel loop and
 // the divisions by mu, 32767 and the new weight take the one-correction form.
 // OCC: waves per SIMD the register allocator must allow.
-// VAR: formulation of phases A1 / A2 (identical results, DESIGN.md "integrate variants"):
-//   0  the round-1 form: per-voxel select of the divisor and of the pixel index, four float
-//      compares for the image bounds, 64-bit addresses, colour list appended voxel by voxel;
-//   1  class-aware form (tools/ubench: compares, selects, conversions and anything with an SGPR
-//      operand issue at half the rate of plain fp32 / logic ops): no divisor select (lanes behind the
-//      camera plane are masked, what they compute is never used), image bounds as two unsigned
-//      compares on the float bits, depth gathers as RAW BUFFER loads (32-bit offsets; the hardware
-//      range check returns 0 = "no depth" for the lanes that are out of the image, so neither a
-//      clamped index nor a remembered in-bounds mask is needed), the (eta > mu) half of the colour
-//      gate dropped (implied by |eta/mu| > 0.25 for a correctly rounded quotient), colour list
-//      appended once per task from a per-lane bit mask.
-template <bool RGB_SAME, bool PLAIN, int VOX, int OCC, int VAR>
+// Formulation notes (round 2; each measured alone and in combination on the bench workload with
+// tools/bench_variants.py, identical results in every case — DESIGN.md "integrate variants"):
+//   kept    depth gathers as RAW BUFFER loads (32-bit offsets; the hardware range check returns 0 =
+//           "no depth" for lanes that are out of the image, so neither a clamped index nor a remembered
+//           in-bounds mask is needed); the camera-plane fallback triggered by "some lane is not tame"
+//           instead of a per-voxel (z > 0) compare; the (eta > mu) half of the colour gate dropped
+//           (implied by |eta / mu| > 0.25 for a correctly rounded quotient): together 623 -> 587 us;
+//   dropped no select of the divisor for lanes behind the camera plane (709 us: inf / NaN operands in
+//           the division sequence are slow), image bounds as unsigned compares on the float bits
+//           (no change), colour list appended once per task from a per-lane bit mask + wave prefix
+//           sum (688 us: six dependent ds_bpermute), skipping x-slices without updates (no change),
+//           5 / 6 instead of 7 waves per SIMD (no change).
+template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
                                                                          const int32_t *__restrict__ visibleIDs,
@@ -149,11 +150,10 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const bool rejectedPassGate = !((-1.0f > p.mu) || (fabsf(-1.0f / p.mu) > 0.25f));
   const float wLim = (float)(p.W - 2), hLim = (float)(p.H - 2);
   const float wcLim = (float)(Wc - 2), hcLim = (float)(Hc - 2);
-  // VAR 1: the depth image as a raw buffer (hardware range check) and the image bounds on float bits
+  // the depth image as a raw buffer: 32-bit offsets, hardware range check (gfx9 descriptor word 3: 32-bit data format)
   const __amdgpu_buffer_rsrc_t depthRsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(depth), 0, (int)((uint32_t)p.W * (uint32_t)p.H * 4u), 0x00020000);
   const int rowBytes = p.W * 4;
-  const uint32_t uLimBits = __float_as_uint(wLim) - 0x3f800000u, vLimBits = __float_as_uint(hLim) - 0x3f800000u;
 
   // ------------------------------------------------------------ colour pass
   // computeUpdatedVoxelColorInfo for `cnt` (<= 64) pending voxels starting at list position `base`,
@@ -250,49 +250,27 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
     // ---------------------------------------------- phase A1: project, issue the depth gathers
     float pz[VOX], dm[VOX];
-    bool inb[VOX];
     bool graze = false;
-    if constexpr (VAR == 1) {
+    {
       bool allTame = true;
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
         const float mx = (float)(gx + x) * p.voxelSize;
         const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
         const bool tame = pc.z >= 1e-4f;
-        // lanes that are not tame (at or behind the camera plane) run the same arithmetic on whatever
-        // their z is — inf / NaN included — and are masked below
-        const float yz = rcp_refined(pc.z);
-        const float u = div_with_rcp(p.proj.x * pc.x, pc.z, yz) + p.proj.z;
-        const float v = div_with_rcp(p.proj.y * pc.y, pc.z, yz) + p.proj.w;
-        // 1 <= u <= W-2 on the bit patterns: for a finite u (tame lanes: finite operands, divisor >= 1e-4)
-        // bits(u) - bits(1.0f) as unsigned is <= bits(W-2) - bits(1.0f) exactly when u is in range
-        // (negative values and values below 1 wrap to something huge)
-        const bool in = tame && (__float_as_uint(u) - 0x3f800000u <= uLimBits) && (__float_as_uint(v) - 0x3f800000u <= vLimBits);
-        inb[x] = in;
-        const uint32_t off = in ? (uint32_t)(__mul24(f2i(v + 0.5f), rowBytes) + (f2i(u + 0.5f) << 2)) : 0xffffffffu;  // < 2^24 rows / bytes per row
-        // out of range -> the buffer load returns 0: "no depth", rejected by (dm <= 0) like an invalid pixel
+        const float zs = tame ? pc.z : 1.0f;
+        const float yz = rcp_refined(zs);
+        const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
+        const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
+        const bool in = tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+        // byte offset of the pixel (rows and bytes per row are < 2^24); out of the image -> out of the
+        // buffer's range -> the load returns 0: "no depth", rejected by (dm <= 0) like an invalid pixel
+        const uint32_t off = in ? (uint32_t)(__mul24(f2i(v + 0.5f), rowBytes) + (f2i(u + 0.5f) << 2)) : 0xffffffffu;
         dm[x] = __uint_as_float((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(depthRsrc, (int)off, 0, 0));
         pz[x] = pc.z;
         allTame &= tame;
       }
-      graze = !allTame;  // blocks touching the camera plane: decided exactly below
-    } else {
-#pragma unroll
-    for (int x = 0; x < VOX; ++x) {
-      const float mx = (float)(gx + x) * p.voxelSize;
-      const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
-      const bool pos = pc.z > 0;
-      const bool tame = pc.z >= 1e-4f;
-      const float zs = tame ? pc.z : 1.0f;
-      const float yz = rcp_refined(zs);
-      const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
-      const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
-      inb[x] = tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
-      const int pix = inb[x] ? (f2i(u + 0.5f) + f2i(v + 0.5f) * p.W) : 0;
-      dm[x] = depth[pix];
-      pz[x] = pc.z;
-      graze |= pos && !tame;
-    }
+      graze = !allTame;  // a block that touches the camera plane: decided exactly below
     }
     if (__builtin_expect(__any(graze), 0)) {
       // voxels grazing the camera plane (0 < z < 1e-4): the divisor is not tame, redo them
@@ -304,8 +282,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
         const float u = p.proj.x * pc.x / pc.z + p.proj.z;
         const float v = p.proj.y * pc.y / pc.z + p.proj.w;
-        inb[x] = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
-        dm[x] = inb[x] ? depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W] : 0.0f;
+        const bool in = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+        dm[x] = in ? depth[f2i(u + 0.5f) + f2i(v + 0.5f) * p.W] : 0.0f;
       }
     }
 
@@ -316,7 +294,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     bool anyUpd = false;
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
-      ok[x] = (VAR == 1) ? !(dm[x] <= 0.0f) : (inb[x] && !(dm[x] <= 0.0f));  // VAR 1: out-of-image lanes read dm = 0
+      ok[x] = !(dm[x] <= 0.0f);  // lanes out of the image read dm = 0
       eta[x] = dm[x] - pz[x];
       anyUpd |= ok[x] && !(eta[x] < -p.mu);
     }
@@ -329,15 +307,14 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     // compile-time flag of the loop so that the usual case carries no trace of it
     auto phaseA2 = [&](auto rejTag) {
       constexpr bool REJ = decltype(rejTag)::value;
-      uint32_t gateBits = 0;  // VAR 1: bit x = voxel x of this lane takes the colour update
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
         const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
         const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
         const bool skip = stopAtMaxW && wDepth == p.maxW;
         const bool okx = !skip && ok[x];
-        const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
         const bool upd = okx && !(eta[x] < -p.mu);
+        const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
         const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
                                  : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
         float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
@@ -352,41 +329,17 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         pl.sdf[x >> 1] = upd ? sw : pl.sdf[x >> 1];
         pl.wd[x >> 2] = upd ? ww : pl.wd[x >> 2];
         dirtyDepth |= upd;
-        // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25);
-        //      voxels the depth step rejected carry eta = -1.
-        //      VAR 1: q is the correctly rounded eta / mu and mu > 0, so eta > mu implies q >= 1 > 0.25:
-        //      the first comparison never decides (a NaN fails both in either form)
-        const bool gateOk = (VAR == 1) ? !(fabsf(q) > 0.25f) : !((eta[x] > p.mu) || (fabsf(q) > 0.25f));
+        // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25); voxels the
+        //      depth step rejected carry eta = -1.  q is the correctly rounded eta / mu and mu > 0, so
+        //      eta > mu implies q >= 1 > 0.25: the first comparison never decides (a NaN fails both)
+        const bool gateOk = !(fabsf(q) > 0.25f);
         const bool gate = REJ ? (!skip && (ok[x] ? gateOk : true)) : (okx && gateOk);
-        if constexpr (VAR == 1) {
-          gateBits |= gate ? (1u << x) : 0u;
-        } else {
         // append to the wave's pending colour list (ordered compaction across the 64 lanes)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
         if (gate)  // slot = number of gated lanes below this one (v_mbcnt)
           pend[nPend + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = pendWord0 + (uint32_t)x;
         nPend += __popcll(m);
         statColour += (uint32_t)__popcll(m);
-        }
-      }
-      if constexpr (VAR == 1) {
-        // the task's colour voxels go to the pending list in one step: a wave prefix sum over the
-        // lanes' counts gives every lane its slots (the order inside the list is irrelevant: each
-        // entry is one independent voxel update)
-        if (__any(gateBits != 0u)) {
-          const int cnt = __popc(gateBits);
-          int inc = cnt;
-#pragma unroll
-          for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-          }
-          const int total = __builtin_amdgcn_readlane(inc, 63);
-          int slot = nPend + inc - cnt;
-          for (uint32_t b = gateBits; b; b &= b - 1u) pend[slot++] = pendWord0 + (uint32_t)(__ffs((int)b) - 1);
-          nPend += total;
-          statColour += (uint32_t)total;
-        }
       }
     };
     if (rejectedPassGate) phaseA2(std::true_type{});

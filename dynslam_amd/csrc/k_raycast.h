@@ -429,7 +429,10 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         //  band of tile columns (workgroup i -> XCD i % 8), 533 vs 512 us; inside runs of misses
         //  prefetching the word of a 1 MB bucket-occupancy bitmap instead of the 16 B entry (a clear
         //  bit is a sure miss: no table read at all), 634 us; workgroups of 64 / 512 / 1024 threads
-        //  (1 / 8 / 16 neighbouring tiles) instead of 256: 601 / 536 / 519 vs 488 us.  Every variant
+        //  (1 / 8 / 16 neighbouring tiles) instead of 256: 601 / 536 / 519 vs 488 us; round 2: a per-wave
+        //  direct-mapped LDS cache of lookup OUTCOMES (found block / no block) shared by the 64 rays of a
+        //  tile, 572 vs 435 us — also when compiled for 7 or 6 waves per SIMD, which by themselves change
+        //  nothing (439 / 438 us).  Every variant
         //  that adds requests or iterations loses: the march is bound by gather-request
         //  throughput and by the per-wave chain of dependent round trips.)
       }
