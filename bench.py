@@ -210,7 +210,8 @@ def main_volumes(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun the process group (RCCL) is used for one rank too
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -247,7 +248,7 @@ def main_volumes(args):
         def barrier():
             scene.sync()
             torch.cuda.synchronize()
-            if nranks > 1:
+            if use_dist and nranks == world:
                 dist.barrier()
             scene.sync()
             torch.cuda.synchronize()
@@ -285,7 +286,7 @@ def main_volumes(args):
 
     sliced = None
     if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
-        one = ShardedScene(make_engine, W, H, V, 1, 0, dev)
+        one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True)
         t1 = run(one, 1)
         one.close()
         sliced = {"composited_frames_per_s": round(K / t1, 3), "ms_per_step": round(1e3 * t1 / K, 4),
@@ -315,7 +316,7 @@ def main_volumes(args):
             "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -18,6 +18,7 @@ DSR_E_DEVICE = 2
 DSR_E_OUT_OF_BLOCKS = 3
 DSR_E_NO_VIEW = 4
 DSR_E_NOMEM = 5
+DSR_E_IO = 6
 
 IMAGE_ORIGINAL_RGB = 0
 IMAGE_ORIGINAL_DEPTH = 1
@@ -110,6 +111,10 @@ SIGNATURES = {
     "get_image_dev": (C.c_int, [_H, C.c_int, _P, _P, _P, _P]),
     "depth_from_disparity": (C.c_int, [_P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "depth_from_disparity_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "read_depth_xml": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "read_pfm": (C.c_int, [C.c_char_p, _P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "clip_depth_mm": (C.c_int, [_P, C.c_int, C.c_float]),
+    "clip_depth_mm_dev": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_float]),
     "bgr_to_rgba": (C.c_int, [_P, _P, C.c_int]),
     "bgr_to_rgba_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int]),
     "rgba_to_bgr": (C.c_int, [_P, _P, C.c_int]),

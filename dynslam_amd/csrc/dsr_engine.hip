@@ -1108,6 +1108,135 @@ int dsr_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n) {
   return convert_host<decltype(&k_depth_m_to_mm), float, short>(k_depth_m_to_mm, depth_m, (size_t)n * 4, depth_mm_out, (size_t)n * 2, n);
 }
 
+// ---- precomputed depth / disparity maps on disk (PrecomputedDepthProvider.cpp:22-75) -------------------
+// Host-side parsing (disk I/O is not GPU work); the clamp and the disparity -> depth step that follow run on
+// the GPU (k_clip_depth_mm, k_depth_from_disparity).
+static short clip_limit_mm(float max_depth_m) {
+  // static_cast<int16_t>(round(GetMaxDepthMeters() * kMetersToMillimeters)) (:57-58)
+  const float f = roundf(max_depth_m * 1000.0f);
+  return (short)(f >= 32767.0f ? 32767 : (f <= -32768.0f ? -32768 : (int)f));
+}
+int dsr_clip_depth_mm_dev(int device, void *hip_stream, void *depth_mm_dev, int n, float max_depth_m) {
+  if (!depth_mm_dev || n <= 0) return fail(DSR_E_ARG, "bad clip arguments");
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(k_clip_depth_mm, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, (const short *)depth_mm_dev,
+                     (short *)depth_mm_dev, n, clip_limit_mm(max_depth_m));
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+int dsr_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m) {
+  if (!depth_mm || n <= 0) return fail(DSR_E_ARG, "bad clip arguments");
+  short *d = nullptr;
+  int st = dmalloc(&d, (size_t)n);
+  if (st) return st;
+  hipError_t err = hipMemcpy(d, depth_mm, (size_t)n * 2, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    st = dsr_clip_depth_mm_dev(-1, nullptr, d, n, max_depth_m);
+    if (st == DSR_OK) err = hipMemcpy(depth_mm, d, (size_t)n * 2, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d);
+  if (st) return st;
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, "clip copy failed");
+  return DSR_OK;
+}
+
+// the text between <tag ...> and </tag> of the first such element at or after `from` (FileStorage XML is
+// flat enough for this: the node "depth-frame" holds <rows>, <cols>, <dt>, <data>)
+static bool xml_element(const std::string &doc, const char *tag, size_t from, size_t *begin, size_t *end) {
+  const std::string open = std::string("<") + tag;
+  size_t p0 = doc.find(open, from);
+  while (p0 != std::string::npos) {
+    const char c = p0 + open.size() < doc.size() ? doc[p0 + open.size()] : 0;
+    if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
+    p0 = doc.find(open, p0 + 1);
+  }
+  if (p0 == std::string::npos) return false;
+  const size_t gt = doc.find('>', p0);
+  if (gt == std::string::npos) return false;
+  const size_t close = doc.find(std::string("</") + tag + ">", gt);
+  if (close == std::string::npos) return false;
+  *begin = gt + 1; *end = close;
+  return true;
+}
+static bool read_whole_file(const char *path, std::string *out) {
+  FILE *f = fopen(path, "rb");
+  if (!f) return false;
+  char buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
+  fclose(f);
+  return true;
+}
+
+int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
+  std::string doc;
+  if (!read_whole_file(path, &doc)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  size_t nb, ne, b, e2;
+  if (!xml_element(doc, "depth-frame", 0, &nb, &ne)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  const std::string node = doc.substr(nb, ne - nb);
+  int rows = 0, cols = 0;
+  if (!xml_element(node, "rows", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <rows>");
+  rows = atoi(node.substr(b, e2 - b).c_str());
+  if (!xml_element(node, "cols", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <cols>");
+  cols = atoi(node.substr(b, e2 - b).c_str());
+  if (!xml_element(node, "dt", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <dt>");
+  std::string dt = node.substr(b, e2 - b);
+  dt.erase(std::remove_if(dt.begin(), dt.end(), [](char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }), dt.end());
+  if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format.");  // :42-44: CV_16SC1 only
+  *width = cols; *height = rows;
+  if (rows <= 0 || cols <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map: empty matrix");
+  if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
+  if (!xml_element(node, "data", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <data>");
+  const char *p = node.c_str() + b, *end = node.c_str() + e2;
+  const long long n = (long long)rows * cols;
+  long long i = 0;
+  while (i < n) {
+    while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p;
+    if (p >= end) break;
+    char *next = nullptr;
+    const long v = strtol(p, &next, 10);
+    if (next == p) return fail(DSR_E_IO, "malformed <data> in depth-frame");
+    depth_mm_out[i++] = (int16_t)v;
+    p = next;
+  }
+  if (i != n) return fail(DSR_E_IO, "depth-frame <data> holds fewer values than rows x cols");
+  return DSR_OK;
+}
+
+int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
+  FILE *f = fopen(path, "rb");
+  if (!f) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  char magic[3] = {0, 0, 0};
+  int w = 0, h = 0;
+  float scale = 0.0f;
+  // "Pf" <ws> width <ws> height <ws> scale <single whitespace byte> raster
+  if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "Pf") != 0 || fscanf(f, "%d %d %f", &w, &h, &scale) != 3) {
+    fclose(f);
+    return fail(DSR_E_IO, "not a single-channel PFM (\"Pf\") file");
+  }
+  (void)fgetc(f);
+  *width = w; *height = h;
+  if (w <= 0 || h <= 0) { fclose(f); return fail(DSR_E_IO, "Could not read precomputed depth map: empty image"); }
+  if (!out || (long long)w * h > capacity) { fclose(f); return fail(DSR_E_ARG, "PFM image larger than the buffer"); }
+  const bool fileLittle = scale < 0.0f;
+  const uint16_t probe = 1;
+  const bool hostLittle = *reinterpret_cast<const uint8_t *>(&probe) == 1;
+  for (int r = h - 1; r >= 0; --r) {  // the file's first row is the image's bottom row
+    float *row = out + (size_t)r * w;
+    if (fread(row, 4, (size_t)w, f) != (size_t)w) { fclose(f); return fail(DSR_E_IO, "PFM raster shorter than width x height"); }
+    if (fileLittle != hostLittle)
+      for (int c = 0; c < w; ++c) {
+        uint32_t v; memcpy(&v, row + c, 4);
+        v = (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+        memcpy(row + c, &v, 4);
+      }
+  }
+  fclose(f);
+  return DSR_OK;
+}
+
 static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h) {
   const size_t n = (size_t)box_w * box_h;
   if (e->maskCap < n) {

@@ -72,4 +72,11 @@ __global__ __launch_bounds__(256) void k_remove_silhouette(uchar4 *__restrict__ 
   }
 }
 
+// PrecomputedDepthProvider::ReadPrecomputed, the input_is_depth_ clamp for int16 maps
+// (PrecomputedDepthProvider.cpp:55-74): depth > max_depth_mm_s -> 0
+__global__ __launch_bounds__(256) void k_clip_depth_mm(const short *__restrict__ in, short *__restrict__ out, int n, short maxMm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const short d = in[i]; out[i] = d > maxMm ? (short)0 : d; }
+}
+
 }  // namespace dsr

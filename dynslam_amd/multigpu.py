@@ -42,9 +42,10 @@ class PreviewExchange:
     `for track in GetActiveTracks()` loop composites in.
     """
 
-    def __init__(self, n_pixels, n_volumes, world_size, rank, device, group=None):
+    def __init__(self, n_pixels, n_volumes, world_size, rank, device, group=None, local_only=False):
         import torch
         self.torch = torch
+        self.local_only = bool(local_only)  # never touch the process group (a one-rank scene inside a larger job)
         self.P = int(n_pixels)
         self.world, self.rank = int(world_size), int(rank)
         self.group = group
@@ -68,10 +69,12 @@ class PreviewExchange:
 
     def gather(self):
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and (self.local_only or not (dist.is_available() and dist.is_initialized())):
             self.all_depth.copy_(self.local_depth)
             self.all_rgba.copy_(self.local_rgba)
             return
+        # (with a process group the collective runs for a single rank too: `torchrun --nproc-per-node 1` exercises
+        #  the RCCL path of the multi-GPU layout on a one-GPU box)
         dist.all_gather_into_tensor(self.all_depth, self.local_depth, group=self.group)
         dist.all_gather_into_tensor(self.all_rgba.view(self.world * self.slots, self.P * 4),
                                     self.local_rgba.view(self.slots, self.P * 4), group=self.group)
@@ -148,7 +151,7 @@ class ShardedScene:
     are used.
     """
 
-    def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None):
+    def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None, local_only=False):
         import torch
         self.torch = torch
         self.W, self.H, self.P = int(width), int(height), int(width) * int(height)
@@ -161,7 +164,7 @@ class ShardedScene:
         self.instances = {v - 1: make_engine("instance") for v in mine if v > 0}
         # the full frame the instance views are cut from
         self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
-        self.exchange = PreviewExchange(self.P, n_volumes, world_size, rank, device, group)
+        self.exchange = PreviewExchange(self.P, n_volumes, world_size, rank, device, group, local_only)
         self.target_rgba = torch.zeros((self.P, 4), dtype=torch.uint8, device=device)
         self.target_depth = torch.zeros((self.P,), dtype=torch.float32, device=device)
 

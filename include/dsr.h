@@ -55,7 +55,8 @@ typedef enum dsr_status {
                               fork throws std::runtime_error, caught at
                               InstanceReconstructor.cpp:662-671                */
   DSR_E_NO_VIEW = 4,       /* no frame given yet (InfiniTamDriver.cpp:168,185) */
-  DSR_E_NOMEM = 5
+  DSR_E_NOMEM = 5,
+  DSR_E_IO = 6             /* file missing or malformed (std::runtime_error at PrecomputedDepthProvider.cpp:40-52) */
 } dsr_status;
 
 /* ITMHashEntry (ITMLib/Objects/ITMVoxelBlockHash.h): 16 bytes.
@@ -265,6 +266,27 @@ int dsr_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int 
 int dsr_depth_from_disparity_dev(int device, void *hip_stream, const void *disparity_dev, void *depth_mm_out_dev,
                                  int n, float baseline_m, float focal_px, float scale, float min_depth_m,
                                  float max_depth_m);
+
+/* PrecomputedDepthProvider::ReadPrecomputed (src/DynSLAM/PrecomputedDepthProvider.cpp:22-75): the two on-disk
+ * formats of precomputed maps, read into caller-provided host buffers of `capacity` elements
+ * (*width / *height are set even when the map does not fit: DSR_E_ARG then; DSR_E_IO for a missing or
+ * malformed file — the reference throws std::runtime_error at :40,:43,:47-52).
+ *   dsr_read_depth_xml  OpenCV FileStorage XML dump of a CV_16SC1 matrix under the node "depth-frame"
+ *                       (:35-45; the ELAS depth maps, Input.h:71-78 "%04d.xml"): <rows>, <cols>, <dt>s</dt>,
+ *                       <data> as whitespace-separated decimals, row-major.  Any other <dt> is the
+ *                       reference's "wrong format" error.
+ *   dsr_read_pfm        single-channel PFM ("Pf" header, width height, scale; scale < 0 = little endian) as
+ *                       written by DispNet (:27-31, Input.h:112-118 "%06d.pfm"); PFM stores the BOTTOM row
+ *                       first, the map is returned top row first (what pfmLib's ReadFilePFM hands to OpenCV).
+ *                       pfmLib is an empty submodule of the reference: the public format is followed, the
+ *                       values are returned as stored (no multiplication by |scale|).
+ *   dsr_clip_depth_mm   the `input_is_depth_` clamp (:55-74) for int16 maps: depth > (int16)round(max_depth_m
+ *                       * 1000) -> 0, in place; the _dev variant works on an HBM buffer and enqueues on
+ *                       hip_stream. */
+int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height);
+int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *height);
+int dsr_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m);
+int dsr_clip_depth_mm_dev(int device, void *hip_stream, void *depth_mm_dev, int n, float max_depth_m);
 
 /* The host's layout shims at the boundary (InfiniTamDriver.cpp:81-144),
  * as kernels, so that frames and previews can stay in HBM in the host's own formats:

@@ -36,6 +36,8 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <fstream>
+#include <sstream>
 #include <vector>
 
 #ifdef _OPENMP
@@ -1505,6 +1507,90 @@ int orc_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int 
 int orc_depth_from_disparity_dev(int, void *, const void *d, void *o, int n, float b, float f, float s, float mn, float mx) {
   return orc_depth_from_disparity((const float *)d, (int16_t *)o, n, b, f, s, mn, mx);
 }
+
+/* PrecomputedDepthProvider::ReadPrecomputed (PrecomputedDepthProvider.cpp:22-75), restated with iostreams:
+ * the OpenCV FileStorage XML dump of a CV_16SC1 matrix (node "depth-frame": rows, cols, dt = "s", data) */
+int orc_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  std::stringstream ss; ss << in.rdbuf();
+  const std::string doc = ss.str();
+  auto element = [](const std::string &d, const std::string &tag, std::string &body) -> bool {
+    size_t p0 = 0;
+    while ((p0 = d.find("<" + tag, p0)) != std::string::npos) {
+      const char c = d[p0 + tag.size() + 1];
+      if (c == '>' || isspace((unsigned char)c)) break;
+      p0++;
+    }
+    if (p0 == std::string::npos) return false;
+    const size_t gt = d.find('>', p0), close = d.find("</" + tag + ">", p0);
+    if (gt == std::string::npos || close == std::string::npos || close < gt) return false;
+    body = d.substr(gt + 1, close - gt - 1);
+    return true;
+  };
+  std::string node, t;
+  if (!element(doc, "depth-frame", node)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  int rows = 0, cols = 0;
+  if (!element(node, "rows", t)) return fail(DSR_E_IO, "no rows");
+  rows = std::stoi(t);
+  if (!element(node, "cols", t)) return fail(DSR_E_IO, "no cols");
+  cols = std::stoi(t);
+  if (!element(node, "dt", t)) return fail(DSR_E_IO, "no dt");
+  std::string dt; for (char c : t) if (!isspace((unsigned char)c)) dt += c;
+  if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format."); /* out.type() != CV_16SC1 */
+  *width = cols; *height = rows;
+  if (rows == 0 || cols == 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
+  if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
+  if (!element(node, "data", t)) return fail(DSR_E_IO, "no data");
+  std::istringstream data(t);
+  long long i = 0, n = (long long)rows * cols;
+  long v;
+  while (i < n && (data >> v)) depth_mm_out[i++] = (int16_t)v;
+  if (i != n) return fail(DSR_E_IO, "depth-frame <data> holds fewer values than rows x cols");
+  return DSR_OK;
+}
+/* single-channel PFM: "Pf", width height, scale (< 0: little endian), raster bottom row first; returned
+ * top row first (what ReadFilePFM of the reference's pfmLib submodule — absent — hands to OpenCV) */
+int orc_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
+  std::ifstream in(path, std::ios::binary);
+  if (!in) return fail(DSR_E_IO, "Could not read precomputed depth map.");
+  std::string magic; int w = 0, h = 0; double scale = 0;
+  in >> magic >> w >> h >> scale;
+  if (!in || magic != "Pf") return fail(DSR_E_IO, "not a single-channel PFM file");
+  in.get();
+  *width = w; *height = h;
+  if (w <= 0 || h <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
+  if (!out || (long long)w * h > capacity) return fail(DSR_E_ARG, "PFM image larger than the buffer");
+  std::vector<unsigned char> row((size_t)w * 4);
+  for (int r = 0; r < h; r++) {
+    in.read(reinterpret_cast<char *>(row.data()), (std::streamsize)row.size());
+    if (!in) return fail(DSR_E_IO, "PFM raster shorter than width x height");
+    for (int c = 0; c < w; c++) {
+      const unsigned char *b = &row[(size_t)c * 4];
+      uint32_t bits = scale < 0 ? ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24))
+                                : ((uint32_t)b[3] | ((uint32_t)b[2] << 8) | ((uint32_t)b[1] << 16) | ((uint32_t)b[0] << 24));
+      float f; memcpy(&f, &bits, 4);
+      out[(size_t)(h - 1 - r) * w + c] = f;
+    }
+  }
+  return DSR_OK;
+}
+/* the input_is_depth_ clamp, int16 branch (PrecomputedDepthProvider.cpp:55-74) */
+int orc_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m) {
+  if (!depth_mm || n <= 0) return fail(DSR_E_ARG, "bad clip arguments");
+  const float kMetersToMillimeters = 1000.0f;
+  float max_depth_mm_f = max_depth_m * kMetersToMillimeters;
+  float r = roundf(max_depth_mm_f);
+  int16_t max_depth_mm_s = (int16_t)(r >= 32767.0f ? 32767 : (r <= -32768.0f ? -32768 : (int)r)); /* saturating, like f2i */
+  for (int i = 0; i < n; i++) {
+    int16_t depth = depth_mm[i];
+    if (depth > max_depth_mm_s) depth_mm[i] = 0;
+  }
+  return DSR_OK;
+}
+int orc_clip_depth_mm_dev(int, void *, void *d, int n, float m) { return orc_clip_depth_mm((int16_t *)d, n, m); }
 
 /* InfiniTamDriver.cpp:81-100 CvToItm(cv::Mat3b) */
 int orc_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n) {

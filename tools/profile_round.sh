@@ -6,9 +6,9 @@ export TMPDIR=/tmp
 TAG=${1:-r02a}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
-B="python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-profile"
-python bench.py > $O/bench_line.json 2> $O/bench.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline > $O/kt.log 2>&1
+B="timeout 200 python bench.py --steps 45 --warmup 5 --no-cpu-baseline --no-through-shim --no-profile"
+timeout 300 python bench.py > $O/bench_line.json 2> $O/bench.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py --no-cpu-baseline --no-through-shim > $O/kt.log 2>&1
 grep '^{"metric"' $O/kt.log > $O/bench_line_under_rocprof.json
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- $B > $O/fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- $B > $O/write.log 2>&1
@@ -19,7 +19,7 @@ python tools/profile_summary.py stats $O/kt 45 > $O/kernel_stats.json
 python tools/profile_summary.py traffic $O/fetch $O/write 45 $O/bench_line.json > $O/pmc_traffic.json
 python tools/profile_summary.py pmc $O/inst $O/cyc $O/cyc2 > $O/pmc_sq.json
 cp $O/kt/*/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || cp $O/kt/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null
-python bench.py --profile-all --no-cpu-baseline > $O/bench_line_profile_all.json 2>> $O/bench.err
+timeout 200 python bench.py --profile-all --no-cpu-baseline --no-through-shim > $O/bench_line_profile_all.json 2>> $O/bench.err
 find $O -name "*.csv" -size +1M -delete
 rm -rf $O/kt $O/fetch $O/write $O/inst $O/cyc $O/cyc2
 ls -la $O
