@@ -66,6 +66,8 @@ def _gen_frame(args):
 
 def make_frames(w, h, n, n_inst=0):
     procs = min(n, max(1, (os.cpu_count() or 2) - 1), 16)
+    if os.environ.get("DSR_BENCH_NO_POOL"):  # under rocprofv3 the forked pool sometimes never returns on this pool of boxes
+        procs = 1
     if procs <= 1:
         return [_gen_frame((w, h, i, n_inst)) for i in range(n)]
     with Pool(procs) as pool:

@@ -51,6 +51,14 @@ __device__ __forceinline__ float read_sdf_raw(const SceneP &s, const FrameP &p, 
   return (float)*reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf + lin * 2);
 }
 
+// two neighbouring shorts of an sdf plane with ONE load (the address is only 2-byte aligned: unaligned dword
+// access is supported for global memory on gfx9 and the compiler emits a single global_load_dword)
+__device__ __forceinline__ uint32_t load_pair(const short *p) {
+  uint32_t w;
+  __builtin_memcpy(&w, p, 4);
+  return w;
+}
+
 __device__ __forceinline__ float roundf_itm(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }  // ROUND()
 
 __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
@@ -76,10 +84,14 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = 32767.0f;
     if (ptr >= 0) {
+      // the two corners of a cell that differ in x are neighbouring shorts of the sdf plane: FOUR (possibly
+      // 2-byte aligned) dword loads fetch the 8 corners — half the gather instructions of 8 short loads
       const short *b = reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf) + lin;
-      const short s0 = b[0], s1 = b[1], s2 = b[8], s3 = b[9], s4 = b[64], s5 = b[65], s6 = b[72], s7 = b[73];
-      v[0] = (float)s0; v[1] = (float)s1; v[2] = (float)s2; v[3] = (float)s3;
-      v[4] = (float)s4; v[5] = (float)s5; v[6] = (float)s6; v[7] = (float)s7;
+      const uint32_t w0 = load_pair(b), w1 = load_pair(b + 8), w2 = load_pair(b + 64), w3 = load_pair(b + 72);
+      v[0] = (float)(short)(w0 & 0xffffu); v[1] = (float)(short)(w0 >> 16);
+      v[2] = (float)(short)(w1 & 0xffffu); v[3] = (float)(short)(w1 >> 16);
+      v[4] = (float)(short)(w2 & 0xffffu); v[5] = (float)(short)(w2 >> 16);
+      v[6] = (float)(short)(w3 & 0xffffu); v[7] = (float)(short)(w3 >> 16);
     }
     res1 = (1.0f - cx) * v[0] + cx * v[1];
     res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
@@ -117,6 +129,20 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
       if (p1 == -2) { p1 = resolve(h1, b1x, b1y, b1z); cache2.bx = b1x; cache2.by = b1y; cache2.bz = b1z; cache2.ptr = p1; }
       const uint8_t *vb = s.vba + kOffSdf;
       float v[8];
+      if (!fx) {
+        // the straddle is in y or z: the x-pairs of corners stay inside one block each -> four dword loads
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const int dy = (k >> 1) & 1, dz = k >> 2;
+          const int ptr = ((fy && dy) || (fz && dz)) ? p1 : p0;
+          const int lin = (ix & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
+          v[k] = 32767.0f; v[k + 1] = 32767.0f;
+          if (ptr >= 0) {
+            const uint32_t w = load_pair(reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes) + lin);
+            v[k] = (float)(short)(w & 0xffffu); v[k + 1] = (float)(short)(w >> 16);
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
@@ -125,6 +151,7 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
         const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
         v[k] = 32767.0f;
         if (ptr >= 0) v[k] = (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + lin * 2);
+      }
       }
       res1 = (1.0f - cx) * v[0] + cx * v[1];
       res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);

@@ -137,6 +137,28 @@ def test_decay_and_reap(hip_api):
     assert_render_equal(g, o)
 
 
+def test_decay_fifo_grows_and_drains(hip_api):
+    """The GC FIFO is a ring of bit planes (one bit per hash entry per queued frame): raising min_age
+    mid-sequence re-allocates the ring with the queued lists in order, lowering it (DecayCatchup:
+    min_age 0, InfiniTamDriver.h:210-226) drains one list per call, a reset empties it."""
+    sc, g, o = make_pair(scene_kw=dict(noise_px=0.6))
+    ages = [2, 2, 2, 6, 6, 6, 6, 6, 1, 0, 0, 0, 0]
+    for i, age in enumerate(ages):
+        feed((g, o), sc, min(i, 7))
+        for e in (g, o):
+            e.decay(1, age, False)
+        assert_scene_equal(g, o, voxels=False)
+    assert o.get_stats().decayed_block_count > 0
+    assert_scene_equal(g, o)
+    for e in (g, o):
+        e.reset_scene()
+    for i in range(3):
+        feed((g, o), sc, i)
+        for e in (g, o):
+            e.decay(1, 1, False)
+    assert_scene_equal(g, o)
+
+
 def test_reset_scene(hip_api):
     sc, g, o = make_pair()
     feed((g, o), sc, 0)
