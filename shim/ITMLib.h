@@ -38,6 +38,8 @@ template <class T> struct Vector2 {
   union { struct { T x, y; }; struct { T width, height; }; T v[2]; };
   Vector2() : x(0), y(0) {}
   Vector2(T a, T b) : x(a), y(b) {}
+  const T *getValues() const { return v; }
+  T *getValues() { return v; }
   T &operator[](int i) { return v[i]; }
   const T &operator[](int i) const { return v[i]; }
   bool operator==(const Vector2 &o) const { return x == o.x && y == o.y; }
@@ -46,11 +48,19 @@ template <class T> struct Vector3 {
   union { struct { T x, y, z; }; struct { T r, g, b; }; T v[3]; };
   Vector3() : x(0), y(0), z(0) {}
   Vector3(T a, T b_, T c) : x(a), y(b_), z(c) {}
+  const T *getValues() const { return v; }
+  T *getValues() { return v; }
+  T &operator[](int i) { return v[i]; }
+  const T &operator[](int i) const { return v[i]; }
 };
 template <class T> struct Vector4 {
   union { struct { T x, y, z, w; }; struct { T r, g, b, a; }; T v[4]; };
   Vector4() : x(0), y(0), z(0), w(0) {}
   Vector4(T a_, T b_, T c, T d) : x(a_), y(b_), z(c), w(d) {}
+  const T *getValues() const { return v; }  // DynSlam.h:102,118
+  T *getValues() { return v; }
+  T &operator[](int i) { return v[i]; }
+  const T &operator[](int i) const { return v[i]; }
 };
 
 // column-major 4x4, m[col*4 + row] (InfiniTamDriver.cpp:146-163)

@@ -1,6 +1,9 @@
 // Stand-in for <opencv2/opencv.hpp>: see tests/stubs/README.md.  cv::Mat / Mat_<T> / Vec / Size_ / Rect_ only.
 #pragma once
+#include <algorithm>
 #include <cassert>
+#include <iostream>
+#include <sstream>
 #include <cstdint>
 #include <cstring>
 #include <memory>

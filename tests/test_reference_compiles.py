@@ -2,9 +2,11 @@
 
 CPU (here, where /root/reference exists):
   * the unmodified src/DynSLAM/InfiniTamDriver.cpp (which pulls InfiniTamDriver.h, Input.h, Utils.h,
-    DepthProvider.h, Defines.h, PreviewType.h, VoxelDecayParams.h) and Utils.cpp compile against
-    shim/ITMLib.h through the forwarding headers under shim/InfiniTAM/ — the only other headers are the
-    functional stand-ins for OpenCV / Eigen / Pangolin / gflags under tests/stubs/ (none is installed);
+    DepthProvider.h, Defines.h, PreviewType.h, VoxelDecayParams.h), InstRecLib/InstanceReconstructor.cpp (which
+    pulls DynSlam.h, InstanceTracker.h, Track.h, InstanceView.h, ...), InstanceTracker.cpp, Track.cpp, InstanceView.cpp
+    and the host units around them (REFERENCE_UNITS: 12 translation units) compile against shim/ITMLib.h through
+    the forwarding headers under shim/InfiniTAM/ — the only other headers are the functional stand-ins for
+    OpenCV / Eigen / Pangolin / gflags / libviso2 under tests/stubs/ (none is installed or vendored);
   * they LINK with shim/host_bench.cpp (-DDSR_HOST_REFERENCE_DRIVER) and libdsr_hip.so into
     tests/refhost/_build/ref_driver_host: every ITMLib symbol the reference's driver needs resolves.
 GPU (the prebuilt binary travels with the snapshot; /root/reference does not exist there):
@@ -24,7 +26,20 @@ LIB_DIR = os.path.join(ROOT, "dynslam_amd", "csrc")
 REF_EXE = os.path.join(ROOT, "tests", "refhost", "_build", "ref_driver_host")
 SHIM_EXE = os.path.join(ROOT, "shim", "host_bench")
 LINK = ["-L", LIB_DIR, "-ldsr_hip", f"-Wl,-rpath,{LIB_DIR}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
-REF_INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "shim", "DynSLAM"), "-I", REF]
+REF_INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "tests", "stubs", "DynSLAM", "InstRecLib"),
+           "-I", os.path.join(ROOT, "shim", "DynSLAM"), "-I", os.path.join(ROOT, "shim", "DynSLAM", "InstRecLib"),
+           "-I", REF, "-I", os.path.join(REF, "InstRecLib")]
+# every translation unit of the reference that reaches the engines (ITMLib names) — plus the host-side units around
+# them that need nothing beyond the stand-in third-party headers.  Not in the list: DynSlam.cpp / DynSLAMGUI.cpp /
+# Evaluation/*.cpp (pull the evaluation subsystem: dynamic Eigen matrices, Pangolin GUI), Input.cpp / Mask.cpp
+# (OpenCV image I/O and imgproc), PrecomputedDepthProvider.cpp (pfmLib, cv::FileStorage), VisoSparseSFProvider.cpp.
+REFERENCE_UNITS = [
+    "InfiniTamDriver.cpp", "Utils.cpp",
+    "InstRecLib/InstanceReconstructor.cpp",  # ITMView, SetView, GetScene, ITMMeshingEngine / ITMMesh, GetImage per instance
+    "InstRecLib/InstanceTracker.cpp", "InstRecLib/Track.cpp", "InstRecLib/InstanceView.cpp",
+    "InstRecLib/InstanceSegmentationResult.cpp", "InstRecLib/SegmentationDataset.cpp", "InstRecLib/SparseSFProvider.cpp",
+    "InstRecLib/Utils/BoundingBox.cpp", "Evaluation/CsvWriter.cpp", "Evaluation/Tracklets.cpp",
+]
 
 have_ref = os.path.isdir(REF)
 
@@ -44,7 +59,7 @@ def build_ref_host():
 
 
 @pytest.mark.skipif(not have_ref, reason="/root/reference is not on this machine")
-@pytest.mark.parametrize("src", ["InfiniTamDriver.cpp", "Utils.cpp"])
+@pytest.mark.parametrize("src", REFERENCE_UNITS)
 def test_reference_sources_compile_unmodified_against_the_shim(src):
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wno-unused-variable"] + REF_INC + [os.path.join(REF, src)],
                        capture_output=True, text=True)
