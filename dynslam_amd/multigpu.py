@@ -198,8 +198,10 @@ class ShardedScene:
             ie = self.instances.get(k)
             if ie is not None:
                 self.source.extract_silhouette(ie, mask, x0, y0)
-            if self.owns_static:
-                self.static.remove_silhouette(mask, x0, y0)
+            if self.source is not None:
+                # every rank that holds the frame blanks every silhouette, in order, like the one main view of the
+                # reference: a later instance's cut-out must not see pixels an earlier (overlapping) mask removed
+                self.source.remove_silhouette(mask, x0, y0)
             if ie is not None:
                 ie.set_pose_inv_m(rel)
                 ie.process_frame()

@@ -32,7 +32,7 @@ def main():
         e = EngineCore(default_settings(**settings_kwargs("5mm"), device=0, sync_status=0), make_calib(*sc.intrinsics(), 1242, 375))
         for i in range(n):
             if i == warm:
-                e.sync(); e.profile_enable(2); e.profile_reset()
+                e.sync(); e.profile_enable(1 if os.environ.get("DSR_VARIANTS_PROFILE_ALL") else 2); e.profile_reset()
             e.update_view_dev(rgb[i].data_ptr(), dep[i].data_ptr())
             e.set_pose_inv_m(frames[i][2])
             e.process_frame()
@@ -40,8 +40,11 @@ def main():
         e.sync()
         prof = {r["name"]: round(1e3 * r["total_ms"] / max(1, r["launches"]), 1) for r in e.profile_get()}
         st = e.get_stats()
-        print(json.dumps({"variant": spec, "integrate_us": prof.get("integrate"), "raycast_us": prof.get("raycast"),
-                          "visible": st.no_visible_blocks, "status": st.sticky_status}), flush=True)
+        rec = {"variant": spec, "integrate_us": prof.get("integrate"), "raycast_us": prof.get("raycast"),
+               "visible": st.no_visible_blocks, "status": st.sticky_status}
+        if os.environ.get("DSR_VARIANTS_PROFILE_ALL"):
+            rec["all_us"] = prof
+        print(json.dumps(rec), flush=True)
         e.close()
 
 
