@@ -11,6 +11,8 @@ Cases
                  re-tests over ~600 k entries, weights > 1, colour running means.
   cfg5_4mm_gc_swap   the `4mm` preset (mu = 0.016: its own short_division_exact outcome,
                  BASELINE configs[4]) with voxel GC (max_weight 1, min_age 3) + host swapping.
+  seq06_5cm_50frames  configs[0]/[1] at the reference's own settings: 1226x370 (seq 06), 50 frames, 5 cm voxels,
+                 upstream's default table sizes, voxel GC (1, 20).
   cfg2_instances BASELINE configs[2]: static 5 mm map + 4 instance volumes (0.035 m, mu 1.0,
                  7142 blocks: InstanceReconstructor.cpp:372-379), masks split on the device
                  (ProcessSilhouette / RemoveSilhouette), 3 frames.
@@ -43,6 +45,12 @@ CASES = {
     "cfg5_4mm_gc_swap": dict(frames=12, instances=0, decay=(1, 3), render_every=4,
                              settings=dict(voxel_size=0.004, mu=0.016, sdf_local_block_num=1 << 22, hash_bucket_num=1 << 24,
                                            excess_list_size=1 << 22, use_swapping=1, **COMMON)),
+    # BASELINE configs[0] / configs[1] at the reference's own settings: KITTI-odometry seq 06's image size
+    # (1226x370), 50 frames, static map only, 5 cm voxels (the reference's experiments),
+    # upstream's default table sizes, voxel GC as the GUI runs it scaled to the sequence (max_weight 1, min_age 20)
+    "seq06_5cm_50frames": dict(frames=50, instances=0, decay=(1, 20), render_every=10, width=1226, height=370,
+                               settings=dict(voxel_size=0.05, mu=0.2, sdf_local_block_num=0x40000, hash_bucket_num=0x100000,
+                                             excess_list_size=0x20000, **COMMON)),
     "cfg2_instances": dict(frames=3, instances=4, decay=None, render_every=1,
                            settings=dict(voxel_size=0.005, mu=0.02, sdf_local_block_num=1 << 21, hash_bucket_num=1 << 22,
                                          excess_list_size=1 << 20, **COMMON)),
@@ -98,8 +106,9 @@ def run_case(make_engine, case, frames, log=None):
     from dynslam_amd import _capi
     from dynslam_amd.engine import OutOfBlocksError
     from dynslam_amd.synth import StreetScene
-    sc = StreetScene(W, H, n_instances=case["instances"])
-    calib_args = (*sc.intrinsics(), W, H)
+    cw, ch = case.get("width", W), case.get("height", H)
+    sc = StreetScene(cw, ch, n_instances=case["instances"])
+    calib_args = (*sc.intrinsics(), cw, ch)
     e = make_engine(case["settings"], calib_args)
     inst = [make_engine(INSTANCE, calib_args) for _ in range(case["instances"])]
     swapping = bool(case["settings"].get("use_swapping"))
@@ -153,7 +162,7 @@ def run_case(make_engine, case, frames, log=None):
 def case_frames(case):
     sys.path.insert(0, ROOT)
     from bench import make_frames
-    return make_frames(W, H, case["frames"], case["instances"])
+    return make_frames(case.get("width", W), case.get("height", H), case["frames"], case["instances"])
 
 
 def oracle_factory(settings, calib_args):

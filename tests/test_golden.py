@@ -39,3 +39,4 @@ def test_fullsize_fixture_covers_every_benched_case():
     assert doc["cfg5_4mm_gc_swap"]["frames"][-1]["decayed_block_count"] > 0
     assert doc["cfg5_4mm_gc_swap"]["frames"][-1]["swap_stored_count"] > 0
     assert len(doc["cfg2_instances"]["frames"][-1]["instances"]) == 4
+    assert doc["seq06_5cm_50frames"]["frames"][-1]["decayed_block_count"] > 0
