@@ -15,6 +15,11 @@
  * CMakeLists.txt:106 would build) plus the fork deltas visible from DynSLAM's
  * call sites (cited as /root/reference paths).  Function-level comments name the
  * upstream function that is restated and the DynSLAM call site that reaches it.
+ * EXCEPTION — pinned by the reference's own code: the host loops at the edges of the
+ * path (silhouette split, compositing, disparity -> depth, layout conversions) exist in
+ * /root/reference; they are compiled from where they lie into oracle/_ref/ (ref_edges.cpp,
+ * Makefile target _ref) and tests/test_reference_edges.py checks the restatements
+ * below against them.
  *
  * Floating point: every expression is written in the upstream evaluation order;
  * build with -ffp-contract=off so that no FMA contraction happens (x86-64 gcc
