@@ -262,7 +262,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         const float yz = rcp_refined(zs);
         const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
         const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
-        const bool in = tame && !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
+        const bool in = tame & !((u < 1) | (u > wLim) | (v < 1) | (v > hLim));  // bitwise: no short-circuit branches
         // byte offset of the pixel (rows and bytes per row are < 2^24); out of the image -> out of the
         // buffer's range -> the load returns 0: "no depth", rejected by (dm <= 0) like an invalid pixel
         const uint32_t off = in ? (uint32_t)(__mul24(f2i(v + 0.5f), rowBytes) + (f2i(u + 0.5f) << 2)) : 0xffffffffu;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     for (int x = 0; x < VOX; ++x) {
       ok[x] = !(dm[x] <= 0.0f);  // lanes out of the image read dm = 0
       eta[x] = dm[x] - pz[x];
-      anyUpd |= ok[x] && !(eta[x] < -p.mu);
+      anyUpd |= ok[x] & !(eta[x] < -p.mu);
     }
     if (!rejectedPassGate && !__any(anyUpd)) continue;
 
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       for (int x = 0; x < VOX; ++x) {
         const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
         const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
-        const bool skip = stopAtMaxW && wDepth == p.maxW;
-        const bool okx = !skip && ok[x];
-        const bool upd = okx && !(eta[x] < -p.mu);
+        const bool skip = stopAtMaxW & (wDepth == p.maxW);
+        const bool okx = !skip & ok[x];  // (bitwise: the compiler turns && / || chains into exec-mask branches)
+        const bool upd = okx & !(eta[x] < -p.mu);
         const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
         const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
                                  : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         //      depth step rejected carry eta = -1.  q is the correctly rounded eta / mu and mu > 0, so
         //      eta > mu implies q >= 1 > 0.25: the first comparison never decides (a NaN fails both)
         const bool gateOk = !(fabsf(q) > 0.25f);
-        const bool gate = REJ ? (!skip && (ok[x] ? gateOk : true)) : (okx && gateOk);
+        const bool gate = REJ ? (!skip & (ok[x] ? gateOk : true)) : (okx & gateOk);
         // append to the wave's pending colour list (ordered compaction across the 64 lanes)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
         if (gate)  // slot = number of gated lanes below this one (v_mbcnt)

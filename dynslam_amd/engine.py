@@ -23,7 +23,7 @@ VOXEL_DTYPE = np.dtype([("sdf", "<i2"), ("w_depth", "u1"), ("clr", "u1", (3,)), 
 assert HASH_ENTRY_DTYPE.itemsize == 16 and VOXEL_DTYPE.itemsize == 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libdsr_hip.so")
+HIP_LIB_PATH = os.environ.get("DSR_HIP_LIB") or os.path.join(_HERE, "csrc", "libdsr_hip.so")  # (override: kernel experiments, tools/bench_variants.py)
 
 _hip_api = None
 
