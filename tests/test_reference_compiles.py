@@ -108,6 +108,76 @@ KW = dict(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum
           sdf_local_block_num=20000, hash_bucket_num=0x8000, excess_list_size=0x2000)
 
 
+def _host_args(path, sc, n, W, H):
+    fx, fy, cx, cy = sc.intrinsics()
+    return [str(path), str(W), str(H), repr(fx), repr(fy), repr(cx), repr(cy), str(n), "1", repr(KW["voxel_size"]), repr(KW["mu"]),
+            str(KW["sdf_local_block_num"]), str(KW["hash_bucket_num"]), str(KW["excess_list_size"]), "1", "1"]
+
+
+def _mirror_digest(make_engine, api, sc, n, W, H, M):
+    """The host_bench call sequence through the Python mirror -> (stats, FNV digest of what host_bench digests)."""
+    import ctypes as C
+    from dynslam_amd import _capi
+    fx, fy, cx, cy = sc.intrinsics()
+    e = make_engine()
+    for i in range(n):
+        rgba, d, T, _ = sc.frame(i)
+        rgba = rgba.copy(); rgba[..., 3] = 255  # CvToItm sets alpha to 255 (InfiniTamDriver.cpp:94)
+        e.update_view(rgba, d)
+        e.set_pose_inv_m(T)
+        e.process_frame()
+        e.prepare()
+        e.decay(1, 1, False)
+    st = e.get_stats()
+    col, _ = e.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, intrinsics=[fx, fy, cx, cy])
+    _, dep = e.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=M, intrinsics=[fx, fy, cx, cy], want_rgba=False, want_depth=True)
+    vdepth = e.get_view()[1]
+    mm = np.empty(W * H, np.int16)
+    bgr = np.empty((W * H, 3), np.uint8)
+    assert api.depth_m_to_mm(dep.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p), W * H) == 0
+    assert api.rgba_to_bgr(col.ctypes.data_as(C.c_void_p), bgr.ctypes.data_as(C.c_void_p), W * H) == 0
+    h = fnv(bgr.tobytes(), fnv(mm.tobytes(), fnv(vdepth.tobytes(), fnv(dep.tobytes(), fnv(col.tobytes())))))
+    e.close()
+    return st, h, dep
+
+
+@pytest.mark.parametrize("driver", ["reference", "shim"])
+def test_cpp_drivers_run_on_the_cpu_oracle(oracle_lib, tmp_path, driver):
+    """The same host — the reference's unmodified InfiniTamDriver over shim/ITMLib.h — with every dsr_* entry point
+    renamed to the CPU oracle's orc_* at compile time (a generated -include header: TEST-ONLY, the shipped shim binds
+    libdsr_hip.so): the reference's driver logic and the shim run in the CPU suite too, and must reproduce what the
+    oracle gives when driven directly."""
+    from dynslam_amd import _capi
+    from dynslam_amd.engine import make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import LIB_PATH, OracleEngine, oracle_settings
+    if driver == "reference" and not have_ref:
+        pytest.skip("/root/reference is not on this machine")
+    rename = tmp_path / "dsr_to_orc.h"
+    rename.write_text("".join(f"#define dsr_{name} orc_{name}\n" for name in _capi.SIGNATURES))
+    exe = tmp_path / "ref_driver_host_cpu"
+    odir = os.path.dirname(LIB_PATH)
+    if driver == "reference":
+        subprocess.check_call(["g++", "-std=c++14", "-O2", "-DNDEBUG", "-DDSR_HOST_REFERENCE_DRIVER", "-include", str(rename)] + REF_INC +
+                              [os.path.join(ROOT, "shim", "host_bench.cpp"), os.path.join(REF, "InfiniTamDriver.cpp"),
+                               os.path.join(REF, "Utils.cpp"), "-o", str(exe), "-L", odir, "-loracle", f"-Wl,-rpath,{odir}"])
+    else:  # our own HostDriver (shim/host_bench.cpp) — the host of bench.py's through_shim leg
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-include", str(rename), "-I", os.path.join(ROOT, "shim"),
+                               os.path.join(ROOT, "shim", "host_bench.cpp"), "-o", str(exe), "-L", odir, "-loracle", f"-Wl,-rpath,{odir}"])
+    W, H, n = 128, 48, 4
+    sc = StreetScene(W, H)
+    path = tmp_path / "frames.bin"
+    M = write_frames_file(path, sc, n)
+    fx, fy, cx, cy = sc.intrinsics()
+    st, h, dep = _mirror_digest(lambda: OracleEngine(oracle_settings(**KW), make_calib(fx, fy, cx, cy, W, H)), oracle_lib, sc, n, W, H, M)
+    out = subprocess.check_output([str(exe)] + _host_args(path, sc, n, W, H)).decode().strip()
+    got = dict(kv.split("=") for kv in out.split())
+    assert got["driver"] == driver and (dep > 0).mean() > 0.05
+    assert int(got["used_bytes"]) == 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id), out
+    assert int(got["saved_bytes"]) == st.decayed_block_count * 4096, out
+    assert got["hash"] == f"{h:016x}", out
+
+
 @pytest.mark.gpu
 def test_reference_driver_runs_on_the_hip_engine(hip_api, tmp_path):
     import ctypes as C
