@@ -11,6 +11,7 @@
 #include "InstRecLib/InstanceReconstructor.cpp"  // -I /root/reference/src/DynSLAM
 
 #include "DepthProvider.h"
+#include "PrecomputedDepthProvider.h"
 
 namespace {
 using instreclib::utils::BoundingBox;
@@ -82,6 +83,26 @@ int ref_depth_from_disparity(const float *disparity, short *depth_mm_out, int W,
   p.DepthFromDisparityMap<float>(disp, calib, out, scale);
   std::memcpy(depth_mm_out, out.data, (size_t)W * H * 2);
   return 0;
+}
+// PrecomputedDepthProvider::GetDepth (PrecomputedDepthProvider.h:46-68, .cpp:22-75): the reference's own
+// ReadPrecomputed + clamp / disparity conversion; only the two file parsers underneath (cv::FileStorage, pfmLib's
+// ReadFilePFM — both absent) are the stand-ins of tests/stubs/, which call dsr_read_depth_xml / dsr_read_pfm.
+// -> 0 ok, 1 std::runtime_error (message in err)
+int ref_precomputed_get_depth(const char *folder, const char *fname_format, int input_is_depth, float min_depth_m, float max_depth_m,
+                              int frame_idx, float baseline_m, float focal_px, float scale, short *depth_mm_out, int W, int H,
+                              char *err, int err_cap) {
+  try {
+    dynslam::PrecomputedDepthProvider p(nullptr, folder, fname_format, input_is_depth != 0, 0, min_depth_m, max_depth_m);
+    dynslam::StereoCalibration calib(baseline_m, focal_px);
+    cv::Mat1s out(H, W);
+    p.GetDepth(frame_idx, calib, out, scale);
+    if (out.rows != H || out.cols != W) { snprintf(err, err_cap, "size %dx%d", out.cols, out.rows); return 1; }
+    std::memcpy(depth_mm_out, out.data, (size_t)W * H * 2);
+    return 0;
+  } catch (const std::exception &ex) {
+    snprintf(err, err_cap, "%s", ex.what());
+    return 1;
+  }
 }
 // InfiniTamDriver.cpp:81-100, :108-120, :128-139
 int ref_cv_to_itm(const unsigned char *bgr, unsigned char *rgba_out, int W, int H) {

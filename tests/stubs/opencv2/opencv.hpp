@@ -5,8 +5,10 @@
 #include <iostream>
 #include <sstream>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 typedef unsigned char uchar;
@@ -101,5 +103,32 @@ typedef Mat_<uchar> Mat1b;
 typedef Mat_<short> Mat1s;
 typedef Mat_<float> Mat1f;
 typedef Mat_<Vec3b> Mat3b;
+
+// cv::FileStorage, read side only, for `fs["depth-frame"] >> mat` (PrecomputedDepthProvider.cpp:37-41): the node
+// reader is the library under test (dsr_read_depth_xml: the OpenCV FileStorage XML dump of a CV_16SC1 matrix)
+extern "C" int dsr_read_depth_xml(const char *path, int16_t *out, int capacity, int *width, int *height);
+class FileStorage {
+ public:
+  enum Mode { READ = 0 };
+  struct Node {
+    std::string path, name;
+    void operator>>(Mat &out) const {
+      int w = 0, h = 0;
+      out = Mat();
+      if (name != "depth-frame") return;
+      dsr_read_depth_xml(path.c_str(), nullptr, 0, &w, &h);  // size query
+      if (w <= 0 || h <= 0) return;
+      Mat m(h, w, CV_16SC1);
+      if (dsr_read_depth_xml(path.c_str(), reinterpret_cast<int16_t *>(m.data), w * h, &w, &h) == 0) out = m;
+    }
+  };
+  FileStorage(const std::string &path, int) : path_(path) { FILE *f = fopen(path.c_str(), "rb"); opened_ = f != nullptr; if (f) fclose(f); }
+  bool isOpened() const { return opened_; }
+  Node operator[](const char *name) const { return Node{path_, name}; }
+
+ private:
+  std::string path_;
+  bool opened_ = false;
+};
 
 }  // namespace cv

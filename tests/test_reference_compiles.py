@@ -26,19 +26,21 @@ LIB_DIR = os.path.join(ROOT, "dynslam_amd", "csrc")
 REF_EXE = os.path.join(ROOT, "tests", "refhost", "_build", "ref_driver_host")
 SHIM_EXE = os.path.join(ROOT, "shim", "host_bench")
 LINK = ["-L", LIB_DIR, "-ldsr_hip", f"-Wl,-rpath,{LIB_DIR}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
-REF_INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "tests", "stubs", "DynSLAM", "InstRecLib"),
+REF_INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "tests", "stubs", "DynSLAM"),
+           "-I", os.path.join(ROOT, "tests", "stubs", "DynSLAM", "InstRecLib"),
            "-I", os.path.join(ROOT, "shim", "DynSLAM"), "-I", os.path.join(ROOT, "shim", "DynSLAM", "InstRecLib"),
            "-I", REF, "-I", os.path.join(REF, "InstRecLib")]
 # every translation unit of the reference that reaches the engines (ITMLib names) — plus the host-side units around
 # them that need nothing beyond the stand-in third-party headers.  Not in the list: DynSlam.cpp / DynSLAMGUI.cpp /
 # Evaluation/*.cpp (pull the evaluation subsystem: dynamic Eigen matrices, Pangolin GUI), Input.cpp / Mask.cpp
-# (OpenCV image I/O and imgproc), PrecomputedDepthProvider.cpp (pfmLib, cv::FileStorage), VisoSparseSFProvider.cpp.
+# (OpenCV image I/O and imgproc), VisoSparseSFProvider.cpp.
 REFERENCE_UNITS = [
     "InfiniTamDriver.cpp", "Utils.cpp",
     "InstRecLib/InstanceReconstructor.cpp",  # ITMView, SetView, GetScene, ITMMeshingEngine / ITMMesh, GetImage per instance
     "InstRecLib/InstanceTracker.cpp", "InstRecLib/Track.cpp", "InstRecLib/InstanceView.cpp",
     "InstRecLib/InstanceSegmentationResult.cpp", "InstRecLib/SegmentationDataset.cpp", "InstRecLib/SparseSFProvider.cpp",
     "InstRecLib/Utils/BoundingBox.cpp", "Evaluation/CsvWriter.cpp", "Evaluation/Tracklets.cpp",
+    "PrecomputedDepthProvider.cpp",  # cv::FileStorage / pfmLib ReadFilePFM stand-ins call dsr_read_depth_xml / dsr_read_pfm
 ]
 
 have_ref = os.path.isdir(REF)

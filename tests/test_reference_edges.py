@@ -128,6 +128,44 @@ def check_disparity_and_conversions(api, ref):
     assert np.array_equal(mm, wmm)
 
 
+def check_precomputed_provider(api, ref, tmp_path):
+    """The reference's PrecomputedDepthProvider::GetDepth (its own ReadPrecomputed logic, clamp and disparity loops; the
+    absent cv::FileStorage / pfmLib underneath replaced by stand-ins over dsr_read_depth_xml / dsr_read_pfm) == the
+    Python mirror dynslam_amd/depth_io.py over `api`."""
+    from dynslam_amd.depth_io import DepthIOError, PrecomputedDepthProvider
+    from tests.test_depth_io import write_cv_xml, write_pfm
+    rng = np.random.default_rng(11)
+    depth = rng.integers(0, 32767, (H, W)).astype(np.int16)
+    depth[rng.random((H, W)) < 0.1] = 0
+    write_cv_xml(tmp_path / "0007.xml", depth)
+    disp = rng.uniform(0.0, 120.0, (H, W)).astype(np.float32)
+    disp[rng.random((H, W)) < 0.05] = 0.0
+    write_pfm(tmp_path / "000007.pfm", disp, little=False)
+    err = C.create_string_buffer(256)
+    for fmt, is_depth in (("%04d.xml", 1), ("%06d.pfm", 0)):
+        want = np.empty((H, W), np.int16)
+        st = ref.ref_precomputed_get_depth(str(tmp_path).encode(), fmt.encode(), is_depth, C.c_float(0.5), C.c_float(20.0), 7,
+                                           C.c_float(0.537150654273), C.c_float(707.0912), C.c_float(1.0), vp(want), W, H, err, 256)
+        assert st == 0, err.value
+        got = PrecomputedDepthProvider(tmp_path, fmt, bool(is_depth), 0.5, 20.0, api=api).GetDepth(7, 0.537150654273, 707.0912)
+        assert np.array_equal(got, want) and (got > 0).mean() > 0.3, fmt
+    # a missing file: std::runtime_error in the reference, DepthIOError in the mirror
+    assert ref.ref_precomputed_get_depth(str(tmp_path).encode(), b"%04d.xml", 1, C.c_float(0.5), C.c_float(20.0), 8, C.c_float(0.5),
+                                         C.c_float(700.0), C.c_float(1.0), vp(np.empty((H, W), np.int16)), W, H, err, 256) == 1
+    assert b"precomputed depth" in err.value
+    with pytest.raises(DepthIOError):
+        PrecomputedDepthProvider(tmp_path, "%04d.xml", True, 0.5, 20.0, api=api).GetDepth(8, 0.5, 700.0)
+
+
+def test_oracle_precomputed_depth_provider_equals_reference_code(oracle_lib, ref, tmp_path):
+    check_precomputed_provider(oracle_lib, ref, tmp_path)
+
+
+@pytest.mark.gpu
+def test_hip_precomputed_depth_provider_equals_reference_code(hip_api, ref, tmp_path):
+    check_precomputed_provider(hip_api, ref, tmp_path)
+
+
 def test_oracle_silhouettes_equal_reference_code(oracle_lib, ref):
     check_silhouettes(oracle_lib, ref)
 
