@@ -13,6 +13,11 @@
 //     runs on the HIP engines unchanged.
 //
 // usage: host_bench frames.bin W H fx fy cx cy n_frames warmup voxel mu blocks buckets excess [decay_max_w decay_min_age]
+//        [--masks masks.bin n_instances]   (our HostDriver only) BASELINE configs[2]: every frame's instance silhouettes are
+//        cut out of the static view ON THE GPU (dsr_view_extract_silhouette / dsr_view_remove_silhouette — what replaces
+//        ProcessSilhouette_CPU / RemoveSilhouette_CPU and their D2H/H2D round trip, InstanceReconstructor.cpp:59-197) and fused
+//        into their own volumes (0.035 m, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379) by further HostDrivers.
+//   masks.bin: per frame int32 n; per mask int32 k, x0, y0, bw, bh; float rel[16] (camera->object, ROW-major); u8 mask[bw*bh]
 //   frames.bin: per frame  BGR u8[H*W*3], depth int16[H*W] (mm), pose float[16] (camera->world, ROW-major);
 //               then float[16]: model-view matrix (world->camera, row-major) of the final free-view render
 // prints one line: key=value ... (frames_per_s over the frames after `warmup`, FNV-1a digest of the
@@ -21,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #ifdef DSR_HOST_REFERENCE_DRIVER
@@ -64,6 +70,13 @@ class HostDriver : public ITMMainEngine {
     }
   }
   void Decay() { if (decay_) denseMapper->Decay(scene, renderState_live, decayMaxW_, decayMinAge_, false); }  // .h:201-206
+  // the engine's device view has just been written by dsr_view_extract_silhouette: give the host-side ITMView that
+  // names it (InstanceReconstructor.cpp:580 SetView) without uploading stale host buffers over it
+  void AdoptDeviceView() {
+    if (!view) view = new ITMView(viewBuilder->GetCalib(), rgb_.noDims, rawDepth_.noDims, true);
+    view->owner = GetDsrEngine();
+    view->deviceStale = false;
+  }
   size_t GetUsedMemoryBytes() const {                                                                       // .h:241-244
     return sizeof(ITMVoxel) * SDF_BLOCK_SIZE3 * (size_t)(scene->index.getNumAllocatedVoxelBlocks() - scene->localVBA.lastFreeBlockId);
   }
@@ -96,6 +109,10 @@ int main(int argc, char **argv) {
   const char *path = argv[1];
   const int W = atoi(argv[2]), H = atoi(argv[3]), nFrames = atoi(argv[8]), warmup = atoi(argv[9]);
   const float fx = (float)atof(argv[4]), fy = (float)atof(argv[5]), cx = (float)atof(argv[6]), cy = (float)atof(argv[7]);
+  const char *masksPath = nullptr;
+  int nInstances = 0;
+  for (int a = 15; a + 2 < argc + 0; a++)
+    if (strcmp(argv[a], "--masks") == 0) { masksPath = argv[a + 1]; nInstances = atoi(argv[a + 2]); argc = a; break; }
   const bool decay = argc > 16;
   const int decayMaxW = decay ? atoi(argv[15]) : 0, decayMinAge = decay ? atoi(argv[16]) : 0;
   const size_t P = (size_t)W * H;
@@ -120,6 +137,29 @@ int main(int argc, char **argv) {
   float renderM[16];  // trailer: the model-view matrix (world->camera, row-major) of the final free-view render
   if (fread(renderM, 4, 16, f) != 16) { fprintf(stderr, "%s: render pose missing\n", path); return 2; }
   fclose(f);
+  struct MaskRec { int k, x0, y0, bw, bh; float rel[16]; std::vector<unsigned char> bits; };
+  std::vector<std::vector<MaskRec>> masks(nFrames);
+  if (masksPath) {
+#ifdef DSR_HOST_REFERENCE_DRIVER
+    fprintf(stderr, "--masks needs the HostDriver build (the reference's driver splits views on the CPU)\n");
+    return 2;
+#endif
+    FILE *mf = fopen(masksPath, "rb");
+    if (!mf) { perror(masksPath); return 2; }
+    for (int i = 0; i < nFrames; i++) {
+      int n = 0;
+      if (fread(&n, 4, 1, mf) != 1) { fprintf(stderr, "%s: short read\n", masksPath); return 2; }
+      masks[i].resize(n);
+      for (auto &m : masks[i]) {
+        int hdr[5];
+        if (fread(hdr, 4, 5, mf) != 5 || fread(m.rel, 4, 16, mf) != 16) { fprintf(stderr, "%s: short read\n", masksPath); return 2; }
+        m.k = hdr[0]; m.x0 = hdr[1]; m.y0 = hdr[2]; m.bw = hdr[3]; m.bh = hdr[4];
+        m.bits.resize((size_t)m.bw * m.bh);
+        if (fread(m.bits.data(), 1, m.bits.size(), mf) != m.bits.size()) { fprintf(stderr, "%s: short read\n", masksPath); return 2; }
+      }
+    }
+    fclose(mf);
+  }
 
   try {
 #ifdef DSR_HOST_REFERENCE_DRIVER
@@ -137,6 +177,12 @@ int main(int argc, char **argv) {
     calib->trafo_rgb_to_depth.SetFrom(identity);
     calib->disparityCalib.SetFrom(1.0f / 1000.0f, 0.0f, ITMDisparityCalib::TRAFO_AFFINE);
     HostDriver drv(&settings, calib, Vector2i(W, H), decay, decayMaxW, decayMinAge);
+    // one volume per tracked instance (InstanceReconstructor.cpp:363-389)
+    ITMLibSettings instSettings = settings;
+    instSettings.sceneParams.voxelSize = 0.035f; instSettings.sceneParams.mu = 1.0f;
+    instSettings.sdfLocalBlockNum = 7142; instSettings.hashBucketNum = 0x100000; instSettings.excessListSize = 0x20000;
+    std::vector<std::unique_ptr<HostDriver>> inst;
+    for (int k = 0; k < nInstances; k++) inst.emplace_back(new HostDriver(&instSettings, calib, Vector2i(W, H), false, 0, 0));
 #endif
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < nFrames; i++) {
@@ -153,6 +199,17 @@ int main(int argc, char **argv) {
       Matrix4f invM;
       for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) invM.at(c, r) = T[r * 4 + c];
       drv.UpdateView(bgr[i].data(), dep[i].data());
+      for (const auto &m : masks[i]) {  // the view split of InstanceReconstructor::ProcessFrame (:238-263), on the GPU
+        HostDriver &id = *inst[m.k];
+        ITMLib::Engine::dsr_throw(dsr_view_extract_silhouette(drv.GetDsrEngine(), id.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh));
+        ITMLib::Engine::dsr_throw(dsr_view_remove_silhouette(drv.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh));
+        Matrix4f rel;
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) rel.at(c, r) = m.rel[r * 4 + c];
+        id.AdoptDeviceView();
+        id.SetPose(rel);
+        id.Integrate();
+        id.PrepareNextStep();
+      }
       drv.SetPose(invM);
 #endif
       drv.Integrate();
@@ -160,6 +217,10 @@ int main(int argc, char **argv) {
       drv.Decay();
     }
     // GetUsedMemoryBytes reads the free-list head from the device: it also drains the stream
+    size_t instUsed = 0;
+#ifndef DSR_HOST_REFERENCE_DRIVER
+    for (auto &id : inst) instUsed += id->GetUsedMemoryBytes();
+#endif
     const size_t used = drv.GetUsedMemoryBytes();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
@@ -196,14 +257,14 @@ int main(int argc, char **argv) {
 #endif
     h = fnv(mm.data(), P * 2, h);
     h = fnv(pbgr.data(), P * 3, h);
-    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu hash=%016llx\n",
+    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu instances=%d inst_used_bytes=%zu hash=%016llx\n",
 #ifdef DSR_HOST_REFERENCE_DRIVER
            "reference",
 #else
            "shim",
 #endif
            nFrames, nFrames - warmup, (nFrames - warmup) / secs, 1e3 * secs / (nFrames - warmup), used, drv.GetSavedDecayMemoryBytes(),
-           (unsigned long long)h);
+           nInstances, instUsed, (unsigned long long)h);
   } catch (const std::exception &ex) {
     fprintf(stderr, "error: %s\n", ex.what());
     return 1;

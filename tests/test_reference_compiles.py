@@ -180,6 +180,116 @@ def test_cpp_drivers_run_on_the_cpu_oracle(oracle_lib, tmp_path, driver):
     assert got["hash"] == f"{h:016x}", out
 
 
+def write_masks_file(path, frames):
+    """masks.bin of shim/host_bench.cpp --masks: per frame n, then (k, x0, y0, bw, bh, rel[16] row-major, mask bytes)."""
+    import struct
+    with open(path, "wb") as f:
+        for _, _, _, masks in frames:
+            f.write(struct.pack("<i", len(masks)))
+            for k, x0, y0, mask, rel in masks:
+                f.write(struct.pack("<5i", k, x0, y0, mask.shape[1], mask.shape[0]))
+                f.write(np.ascontiguousarray(rel, np.float32).tobytes())
+                f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+
+
+INST_KW = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+               sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
+
+
+def _instances_case(tmp_path, W, H, n, n_inst):
+    from bench import _gen_frame
+    from dynslam_amd.synth import StreetScene
+    sc = StreetScene(W, H, n_instances=n_inst)
+    frames = [_gen_frame((W, H, i, n_inst)) for i in range(n)]
+    path, mpath = tmp_path / "frames.bin", tmp_path / "masks.bin"
+    M = np.linalg.inv(np.asarray(frames[-1][2], np.float64)).astype(np.float32)
+    with open(path, "wb") as f:
+        for rgba, d, T, _ in frames:
+            f.write(np.ascontiguousarray(rgba[..., 2::-1]).tobytes())
+            f.write(np.ascontiguousarray(d, np.int16).tobytes())
+            f.write(np.ascontiguousarray(T, np.float32).tobytes())
+        f.write(M.tobytes())
+    write_masks_file(mpath, frames)
+    return sc, frames, path, mpath, M
+
+
+def _instances_mirror(make_engine, api, sc, frames, W, H, M, n_inst):
+    """configs[2] through the Python mirror: bench.py's step (GPU view split + one volume per instance)."""
+    import ctypes as C
+    from dynslam_amd import _capi
+    fx, fy, cx, cy = sc.intrinsics()
+    e = make_engine(KW)
+    inst = [make_engine(INST_KW) for _ in range(n_inst)]
+    for rgba, d, T, masks in frames:
+        rgba = rgba.copy(); rgba[..., 3] = 255
+        e.update_view(rgba, d)
+        for k, x0, y0, mask, rel in masks:
+            e.extract_silhouette(inst[k], mask, x0, y0)
+            e.remove_silhouette(mask, x0, y0)
+            inst[k].set_pose_inv_m(rel)
+            inst[k].process_frame()
+            inst[k].prepare()
+        e.set_pose_inv_m(T)
+        e.process_frame()
+        e.prepare()
+    col, _ = e.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, intrinsics=[fx, fy, cx, cy])
+    _, dep = e.get_image(_capi.IMAGE_FREECAMERA_DEPTH, pose_m=M, intrinsics=[fx, fy, cx, cy], want_rgba=False, want_depth=True)
+    vdepth = e.get_view()[1]
+    mm = np.empty(W * H, np.int16)
+    bgr = np.empty((W * H, 3), np.uint8)
+    assert api.depth_m_to_mm(dep.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p), W * H) == 0
+    assert api.rgba_to_bgr(col.ctypes.data_as(C.c_void_p), bgr.ctypes.data_as(C.c_void_p), W * H) == 0
+    h = fnv(bgr.tobytes(), fnv(mm.tobytes(), fnv(vdepth.tobytes(), fnv(dep.tobytes(), fnv(col.tobytes())))))
+    inst_used = 0
+    for ie in inst:
+        st = ie.get_stats()
+        inst_used += 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id)
+        ie.close()
+    st = e.get_stats()
+    e.close()
+    return st, h, inst_used
+
+
+def _instances_args(path, mpath, sc, n, W, H, n_inst):
+    return _host_args(path, sc, n, W, H)[:14] + ["--masks", str(mpath), str(n_inst)]
+
+
+def test_cpp_host_with_instance_volumes_runs_on_the_cpu_oracle(oracle_lib, tmp_path):
+    """configs[2] through the C++ host (shim/host_bench.cpp --masks: GPU view split + one HostDriver per instance
+    volume), oracle-backed like the test above: same digest and the same instance-volume sizes as the Python mirror."""
+    from dynslam_amd import _capi
+    from dynslam_amd.engine import make_calib
+    from oracle.oracle import LIB_PATH, OracleEngine, oracle_settings
+    rename = tmp_path / "dsr_to_orc.h"
+    rename.write_text("".join(f"#define dsr_{name} orc_{name}\n" for name in _capi.SIGNATURES))
+    exe = tmp_path / "host_bench_cpu"
+    odir = os.path.dirname(LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-include", str(rename), "-I", os.path.join(ROOT, "shim"),
+                           os.path.join(ROOT, "shim", "host_bench.cpp"), "-o", str(exe), "-L", odir, "-loracle", f"-Wl,-rpath,{odir}"])
+    W, H, n, n_inst = 160, 56, 3, 2
+    sc, frames, path, mpath, M = _instances_case(tmp_path, W, H, n, n_inst)
+    assert sum(len(f[3]) for f in frames) >= n  # the silhouettes are really there
+    calib = make_calib(*sc.intrinsics(), W, H)
+    st, h, inst_used = _instances_mirror(lambda kw: OracleEngine(oracle_settings(**kw), calib), oracle_lib, sc, frames, W, H, M, n_inst)
+    out = subprocess.check_output([str(exe)] + _instances_args(path, mpath, sc, n, W, H, n_inst)).decode().strip()
+    got = dict(kv.split("=") for kv in out.split())
+    assert int(got["instances"]) == n_inst and int(got["inst_used_bytes"]) == inst_used > 2 * 4096, out
+    assert int(got["used_bytes"]) == 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id), out
+    assert got["hash"] == f"{h:016x}", out
+
+
+@pytest.mark.gpu
+def test_cpp_host_with_instance_volumes_on_the_hip_engine(hip_api, tmp_path):
+    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+    W, H, n, n_inst = 160, 56, 3, 2
+    sc, frames, path, mpath, M = _instances_case(tmp_path, W, H, n, n_inst)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    st, h, inst_used = _instances_mirror(lambda kw: EngineCore(default_settings(**kw), calib), hip_api, sc, frames, W, H, M, n_inst)
+    out = subprocess.check_output([build_shim_host()] + _instances_args(path, mpath, sc, n, W, H, n_inst)).decode().strip()
+    got = dict(kv.split("=") for kv in out.split())
+    assert int(got["inst_used_bytes"]) == inst_used > 2 * 4096 and got["hash"] == f"{h:016x}", out
+
+
 @pytest.mark.gpu
 def test_reference_driver_runs_on_the_hip_engine(hip_api, tmp_path):
     import ctypes as C

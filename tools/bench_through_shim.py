@@ -26,7 +26,19 @@ def write_frames(path, frames, render_pose_m):
         f.write(np.ascontiguousarray(render_pose_m, np.float32).tobytes())
 
 
-def run(exe, frames, W, H, intr, preset_kw, warmup, decay=None, tmpdir=None):
+def write_masks(path, frames):
+    import struct
+    with open(path, "wb") as f:
+        for fr in frames:
+            masks = fr[3]
+            f.write(struct.pack("<i", len(masks)))
+            for k, x0, y0, mask, rel in masks:
+                f.write(struct.pack("<5i", k, x0, y0, mask.shape[1], mask.shape[0]))
+                f.write(np.ascontiguousarray(rel, np.float32).tobytes())
+                f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+
+
+def run(exe, frames, W, H, intr, preset_kw, warmup, decay=None, tmpdir=None, instances=0):
     tmpdir = tmpdir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
     path = os.path.join(tmpdir, f"dsr_frames_{os.getpid()}.bin")
     M = np.linalg.inv(np.asarray(frames[-1][2], np.float64)).astype(np.float32)
@@ -37,9 +49,14 @@ def run(exe, frames, W, H, intr, preset_kw, warmup, decay=None, tmpdir=None):
                 str(preset_kw["hash_bucket_num"]), str(preset_kw["excess_list_size"])]
         if decay:
             args += [str(decay[0]), str(decay[1])]
+        if instances:  # configs[2]: silhouettes split on the GPU, one volume per instance (shim/host_bench.cpp --masks)
+            write_masks(path + ".masks", frames)
+            args += ["--masks", path + ".masks", str(instances)]
         out = subprocess.check_output(args, timeout=600).decode().strip()
     finally:
         os.unlink(path)
+        if os.path.exists(path + ".masks"):
+            os.unlink(path + ".masks")
     return dict(kv.split("=") for kv in out.split())
 
 
@@ -52,11 +69,12 @@ if __name__ == "__main__":
     ap.add_argument("--height", type=int, default=375)
     ap.add_argument("--reference", action="store_true")
     ap.add_argument("--decay", action="store_true")
+    ap.add_argument("--instances", type=int, default=0, help="configs[2]: this many instance volumes, views split on the GPU")
     a = ap.parse_args()
     from bench import PRESETS, make_frames
     from dynslam_amd.synth import StreetScene
-    frames = make_frames(a.width, a.height, a.warmup + a.steps)
+    frames = make_frames(a.width, a.height, a.warmup + a.steps, a.instances)
     exe = os.path.join(ROOT, "tests", "refhost", "_build", "ref_driver_host") if a.reference else os.path.join(ROOT, "shim", "host_bench")
     r = run(exe, frames, a.width, a.height, StreetScene(a.width, a.height).intrinsics(), PRESETS[a.preset], a.warmup,
-            (1, 200) if a.decay else None)
+            (1, 200) if a.decay else None, instances=a.instances)
     print(r)
