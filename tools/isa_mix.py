@@ -73,12 +73,16 @@ def main():
             weights[id(b)] = 0.5
     tot = {k: 0.0 for k in RATE}
     salu = 0.0
+    half_ops = {}
     for grp, w in ((hot, None), (pend, 0.35 * 0.5), (colour, 10.2 / 64.0)):
         for b in grp:
             ww = weights.get(id(b), 1.0) if w is None else w
             for ins in b[1]:
                 if ins.startswith("v_"):
-                    tot[classify(ins)] += ww
+                    k = classify(ins)
+                    tot[k] += ww
+                    if k == "half":
+                        half_ops[ins.split()[0]] = half_ops.get(ins.split()[0], 0.0) + ww
                 elif ins.startswith("s_") and not ins.startswith(("s_waitcnt", "s_nop")):
                     salu += ww
     n = sum(tot.values())
@@ -89,6 +93,17 @@ def main():
         print(f"  {k:10s} {tot[k]:7.1f} instructions/task  x {RATE[k]:4.2f} cycles = {tot[k] * RATE[k]:7.0f}")
     print(f"  VALU total {n:7.1f} per task (SQ_INSTS_VALU / visible blocks measured: 614), weighted mean {cyc / n:.2f} cycles/instruction")
     print(f"  SALU       {salu:7.1f} per task x 4.6 cycles = {salu * 4.6:.0f} (own issue port: overlaps VALU of other waves)")
+    groups = {"compares": ("v_cmp",), "selects": ("v_cndmask",), "conversions": ("v_cvt",), "SGPR spills to VGPR lanes": ("v_readlane", "v_writelane"),
+              "shifts / bit-field / permute": ("v_lsh", "v_bf", "v_perm", "v_and_or", "v_or3"), "min / max": ("v_min", "v_max", "v_med3"),
+              "integer multiply-add": ("v_mad", "v_mul_lo", "v_mul_u32", "v_mul_i32"), "lane counting (colour list)": ("v_mbcnt", "v_readfirstlane")}
+    print("  half-rate instructions by kind (per task):")
+    rest = dict(half_ops)
+    for g, pre in groups.items():
+        n_g = sum(v for k, v in half_ops.items() if k.startswith(pre))
+        for k in [k for k in rest if k.startswith(pre)]:
+            rest.pop(k)
+        print(f"    {g:32s} {n_g:6.1f}  = {n_g * RATE['half']:5.0f} cycles")
+    print(f"    {'other':32s} {sum(rest.values()):6.1f}")
     measured = 608e-6 * 2.3e9 * 1024 / 616948
     print(f"  VALU issue {cyc:.0f} cycles per task vs {measured:.0f} SIMD-cycles per task measured (608 us x 2.3 GHz x 1024 SIMDs / 616948 "
           f"tasks): {100 * cyc / measured:.0f} %")
