@@ -91,6 +91,7 @@ SIGNATURES = {
     "engine_destroy": (None, [_H]),
     "reset_scene": (C.c_int, [_H]),
     "sync": (C.c_int, [_H]),
+    "device_synchronize": (C.c_int, []),
     "wait_for_stream": (C.c_int, [_H, _P]),
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "update_view": (C.c_int, [_H, _P, _P]),

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +36,7 @@ using namespace dsr;
 namespace {
 
 thread_local std::string g_err;
+std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 #define HIP_TRY(expr)                                                                              \
@@ -647,6 +649,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (s.device >= 0) e->device = s.device;
   else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
   if (e->device >= nDev) { delete e; return fail(DSR_E_ARG, "device ordinal out of range"); }
+  if (e->device < 64) g_devMask.fetch_or(1ull << e->device);
   e->W = calib->depth.width; e->H = calib->depth.height; e->Wr = calib->rgb.width; e->Hr = calib->rgb.height;
   e->P = e->W * e->H;
   e->noBuckets = s.hash_bucket_num; e->noExcess = s.excess_list_size; e->E = e->noBuckets + e->noExcess;
@@ -756,6 +759,22 @@ int dsr_sync(dsr_engine *e) {
   CHECK_E(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
   return DSR_OK;
+}
+
+int dsr_device_synchronize(void) {
+  int prev = 0;
+  const bool havePrev = hipGetDevice(&prev) == hipSuccess;
+  const unsigned long long mask = g_devMask.load();
+  int rc = DSR_OK;
+  for (int d = 0; d < 64; d++) {
+    if (!((mask >> d) & 1ull)) continue;
+    hipError_t err = hipSetDevice(d);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err != hipSuccess) rc = fail(DSR_E_DEVICE, std::string("device ") + std::to_string(d) + ": " + hipGetErrorString(err));
+  }
+  if (havePrev) (void)hipSetDevice(prev);
+  return rc;
 }
 
 // ---- stream ordering without host synchronisation (dsr.h)

@@ -173,9 +173,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
 void dsr_engine_destroy(dsr_engine *e);
 /* denseMapper->ResetScene(scene) (InfiniTamDriver.h:282-284). */
 int dsr_reset_scene(dsr_engine *e);
-/* Blocks until all work queued on the engine's stream is done
- * (cudaDeviceSynchronize at DynSlam.cpp:165-172). */
+/* Blocks until all work queued on the engine's stream is done. */
 int dsr_sync(dsr_engine *e);
+/* Blocks until all work of EVERY engine of this process is done, on every device an engine was
+ * created on (the host's per-frame "final sanity check": ITMSafeCall(cudaDeviceSynchronize()) +
+ * cudaGetLastError(), DynSlam.cpp:163-172).  Returns DSR_E_DEVICE if a device reports an error. */
+int dsr_device_synchronize(void);
 
 /* Stream ordering for the "_dev" entry points, WITHOUT host synchronisation.  Every engine
  * enqueues on its own private HIP stream and "_dev" calls return before the work has run, so a

@@ -1356,6 +1356,7 @@ void orc_engine_destroy(dsr_engine *h) { delete h; }
 
 int orc_reset_scene(dsr_engine *h) { if (!h) return fail(DSR_E_ARG, "null"); reset_scene(E); return DSR_OK; }
 int orc_sync(dsr_engine *h) { return h ? DSR_OK : fail(DSR_E_ARG, "null"); }
+int orc_device_synchronize(void) { return DSR_OK; }  // the CPU restatement runs synchronously
 
 int orc_update_view(dsr_engine *h, const uint8_t *rgba, const int16_t *depth_mm) {
   if (!h || !rgba || !depth_mm) return fail(DSR_E_ARG, "null");

@@ -148,7 +148,18 @@ struct ITMVoxel { short sdf; uchar w_depth; uchar clr[3]; uchar w_color; uchar _
 struct ITMVoxelIndex {};
 static_assert(sizeof(ITMVoxel) == sizeof(dsr_voxel), "voxel size");
 
-#define ITMSafeCall(x) (x)
+// ITMSafeCall(err) (ITMLib/Utils/ITMCUDAUtils.h: print + exit on a CUDA error; DynSlam.cpp:165,171) and the two CUDA
+// runtime names DynSLAM's host calls directly after every frame (DynSlam.cpp:165-166: device-wide sync + error
+// poll; upstream they arrive through ITMLib's headers).  They map onto the library's device-wide sync; errors of
+// individual engine calls are already raised as exceptions where they happen.
+typedef int cudaError_t;
+enum { cudaSuccess = 0 };
+inline cudaError_t cudaDeviceSynchronize() { return dsr_device_synchronize(); }
+inline cudaError_t cudaGetLastError() { return cudaSuccess; }
+inline void ITMSafeCallImpl(int err, const char *file, int line) {
+  if (err != 0) throw std::runtime_error(std::string(file) + ":" + std::to_string(line) + ": " + dsr_last_error());
+}
+#define ITMSafeCall(x) ITMSafeCallImpl((x), __FILE__, __LINE__)
 
 namespace ITMLib {
 namespace Objects {

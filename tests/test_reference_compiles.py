@@ -4,7 +4,7 @@ CPU (here, where /root/reference exists):
   * the unmodified src/DynSLAM/InfiniTamDriver.cpp (which pulls InfiniTamDriver.h, Input.h, Utils.h,
     DepthProvider.h, Defines.h, PreviewType.h, VoxelDecayParams.h), InstRecLib/InstanceReconstructor.cpp (which
     pulls DynSlam.h, InstanceTracker.h, Track.h, InstanceView.h, ...), InstanceTracker.cpp, Track.cpp, InstanceView.cpp
-    and the host units around them (REFERENCE_UNITS: 12 translation units) compile against shim/ITMLib.h through
+    and the host units around them (REFERENCE_UNITS: 24 translation units) compile against shim/ITMLib.h through
     the forwarding headers under shim/InfiniTAM/ — the only other headers are the functional stand-ins for
     OpenCV / Eigen / Pangolin / gflags / libviso2 under tests/stubs/ (none is installed or vendored);
   * they LINK with shim/host_bench.cpp (-DDSR_HOST_REFERENCE_DRIVER) and libdsr_hip.so into
@@ -31,9 +31,9 @@ REF_INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, 
            "-I", os.path.join(ROOT, "shim", "DynSLAM"), "-I", os.path.join(ROOT, "shim", "DynSLAM", "InstRecLib"),
            "-I", REF, "-I", os.path.join(REF, "InstRecLib")]
 # every translation unit of the reference that reaches the engines (ITMLib names) — plus the host-side units around
-# them that need nothing beyond the stand-in third-party headers.  Not in the list: DynSlam.cpp / DynSLAMGUI.cpp /
-# Evaluation/*.cpp (pull the evaluation subsystem: dynamic Eigen matrices, Pangolin GUI), Input.cpp / Mask.cpp
-# (OpenCV image I/O and imgproc), VisoSparseSFProvider.cpp.
+# them that need nothing beyond the stand-in third-party headers.  Not in the list: DynSLAMGUI.cpp, DSHandler3D.cpp and
+# Evaluation/ErrorVisualizationCallback.cpp (Pangolin GUI / OpenGL), the Direct/ image-alignment library (unused:
+# InstanceReconstructor.cpp:590-606 throws "Deprecated").
 REFERENCE_UNITS = [
     "InfiniTamDriver.cpp", "Utils.cpp",
     "InstRecLib/InstanceReconstructor.cpp",  # ITMView, SetView, GetScene, ITMMeshingEngine / ITMMesh, GetImage per instance
@@ -41,6 +41,11 @@ REFERENCE_UNITS = [
     "InstRecLib/InstanceSegmentationResult.cpp", "InstRecLib/SegmentationDataset.cpp", "InstRecLib/SparseSFProvider.cpp",
     "InstRecLib/Utils/BoundingBox.cpp", "Evaluation/CsvWriter.cpp", "Evaluation/Tracklets.cpp",
     "PrecomputedDepthProvider.cpp",  # cv::FileStorage / pfmLib ReadFilePFM stand-ins call dsr_read_depth_xml / dsr_read_pfm
+    "DynSlam.cpp",  # the per-frame orchestrator: ITMSafeCall(cudaDeviceSynchronize()) -> dsr_device_synchronize
+    "Input.cpp", "InstRecLib/Utils/Mask.cpp", "InstRecLib/PrecomputedSegmentationProvider.cpp",
+    "InstRecLib/VisoSparseSFProvider.cpp",
+    "Evaluation/Evaluation.cpp", "Evaluation/VelodyneIO.cpp", "Evaluation/EvaluationCallback.cpp",  # readers of the a14 depth renders
+    "Evaluation/SegmentedCallback.cpp", "Evaluation/SegmentedEvaluationCallback.cpp", "Evaluation/SegmentedVisualizationCallback.cpp",
 ]
 
 have_ref = os.path.isdir(REF)
