@@ -160,6 +160,12 @@ class StreetScene:
     def frame(self, i, with_instances=True):
         """-> rgba uint8 [H,W,4], depth int16 mm [H,W], inv_m float32 4x4, inst_id int64 [H,W]."""
         z, rgb, _, inst_id = self.render(i, with_instances)
+        rgba, depth_mm = self.quantise(i, z, rgb)
+        return rgba, depth_mm, self.pose(i), inst_id
+
+    def quantise(self, i, z, rgb):
+        """Exact depth + float colour of frame i -> what a stereo matcher hands over: depth through a noisy
+        disparity on a 1/16 px grid, clipped to [0.5, 20] m, int16 mm (0 = invalid); RGBA uint8."""
         rng = np.random.default_rng([self.seed, int(i)])
         fb = self.fx * KITTI_BASELINE_M
         with np.errstate(divide="ignore", invalid="ignore"):
@@ -174,7 +180,7 @@ class StreetScene:
         rgba = np.empty((self.height, self.width, 4), dtype=np.uint8)
         rgba[..., :3] = rgb.astype(np.uint8)
         rgba[..., 3] = 255
-        return rgba, depth_mm, self.pose(i), inst_id
+        return rgba, depth_mm
 
     def intrinsics(self):
         return self.fx, self.fy, self.cx, self.cy
