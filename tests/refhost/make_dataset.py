@@ -7,6 +7,8 @@ reference's whole per-frame pipeline can run on it (tests/refhost/ref_dynslam_ho
   seg_image_2/mnc/cls_%06d.png              segmentation preview (PPM content)
   seg_image_2/mnc/%06d.png.%04d.result.txt  "[x0 y0 x1 y1 0], probability, class" per detection
   seg_image_2/mnc/%06d.png.%04d.mask.txt    numpy text dump of the bbox-local 0/1 mask
+  velodyne/%06d.bin                         "LIDAR" returns, float32 x y z reflectance in the camera frame (the host passes an
+                                            identity velo-to-camera matrix): every 3rd pixel's EXACT surface point
   viso/%06d.bin                             what the scripted libviso2 stand-in "computes" for frame k >= 1: ego-motion,
                                             raw matches (object id in p_match::i1c), per-object motion vectors
   synthetic.txt                             W H fx fy cx cy baseline
@@ -80,7 +82,7 @@ def write_dataset(root, n_frames, width=1242, height=375, min_area=45 * 45):
     sc = PipelineScene(width, height)
     fx, fy, cx, cy = sc.intrinsics()
     seg = os.path.join(root, "seg_image_2", "mnc")
-    for d in ("image_2", "image_3", "precomputed-depth-dispnet", "viso", "csv"):
+    for d in ("image_2", "image_3", "precomputed-depth-dispnet", "viso", "csv", "velodyne"):
         os.makedirs(os.path.join(root, d), exist_ok=True)
     os.makedirs(seg, exist_ok=True)
     with open(os.path.join(root, "synthetic.txt"), "w") as f:
@@ -99,6 +101,11 @@ def write_dataset(root, n_frames, width=1242, height=375, min_area=45 * 45):
             disp = np.where(depth_mm > 0, fx * KITTI_BASELINE_M / (depth_mm.astype(np.float64) / 1000.0), 0.0)
         _write_pfm(os.path.join(root, "precomputed-depth-dispnet", "%06d.pfm" % i), disp.astype(np.float32))
         _write_ppm(os.path.join(seg, "cls_%06d.png" % i), (rgba[..., :3] // 2))
+        vv, uu = np.mgrid[1:height:3, 1:width:3]
+        zz = z[vv, uu]
+        keep = np.isfinite(zz) & (zz > 0.5) & (zz < 20.0)
+        pts = np.stack([(uu[keep] - cx) / fx * zz[keep], (vv[keep] - cy) / fy * zz[keep], zz[keep], np.full(keep.sum(), 0.5)], axis=1)
+        pts.astype("<f4").tofile(os.path.join(root, "velodyne", "%06d.bin" % i))
 
         # detections: the moving boxes, then the parked cars (prim ids 5..8 of the street)
         objects = [(k, inst_id == k, k) for k in range(sc.n_instances)]

@@ -13,7 +13,8 @@
 // Only this file is ours: it builds the objects like BuildDynSlamKittiOdometry does (DynSLAMGUI.cpp:1100-1270, a GUI unit
 // that is not compiled), installs the odometry script, runs N frames and dumps what the engines hold.
 //
-// usage: ref_dynslam_host <dataset_root> <n_frames> <out.bin> [voxel_size] [decay: 0|1]
+// usage: ref_dynslam_host <dataset_root> <n_frames> <out.bin> [voxel_size] [decay: 0|1] [evaluate: 0|1]
+//   evaluate = 1: Evaluation::EvaluateFrame after every frame (DynSlam.cpp:153-159) against <dataset_root>/velodyne/%06d.bin
 //   <dataset_root>/synthetic.txt : W H fx fy cx cy baseline
 //   <dataset_root>/viso/%06d.bin : the script of frame k >= 1 (tests/refhost/make_dataset.py)
 // stdout (last line): key=value ...   out.bin: the renders listed in that line, raw, in order.
@@ -94,6 +95,7 @@ int main(int argc, char **argv) {
   const char *outPath = argv[3];
   const float voxel = argc > 4 ? (float)atof(argv[4]) : 0.05f;
   const bool decay = argc > 5 && atoi(argv[5]) != 0;
+  const bool evaluate = argc > 6 && atoi(argv[6]) != 0;
 
   int W = 0, H = 0;
   double fx = 0, fy = 0, cx = 0, cy = 0, baseline = 0;
@@ -134,8 +136,9 @@ int main(int argc, char **argv) {
     sfParams.calib.cu = cx; sfParams.calib.cv = cy; sfParams.calib.f = fx;
     auto *sparseSF = new instreclib::VisoSparseSFProvider(sfParams);
 
-    auto *evaluation = new eval::Evaluation(root, input, veloToCam, proj, projRight, (float)baseline, W, H, voxel, false, true, false, false);
-    FLAGS_enable_evaluation = false;  // no LIDAR in the synthetic dataset; LogMemoryUse still runs every frame
+    auto *evaluation = new eval::Evaluation(root, input, veloToCam, proj, projRight, (float)baseline, W, H, voxel, false, true, false,
+                                            /* separate static / dynamic: the only mode Evaluation.cpp:153 supports */ true);
+    FLAGS_enable_evaluation = evaluate;  // LogMemoryUse runs every frame either way
     Vector2i inputShape(W, H);
     DynSlam *dynSlam = new DynSlam(driver, segmentation, sparseSF, evaluation, inputShape, proj.cast<float>(), projRight.cast<float>(),
                                    (float)baseline, false, /* dynamic_mode */ true, FLAGS_fusion_every);

@@ -30,9 +30,9 @@ N_FRAMES = 8
 W, H = 1242, 375
 
 
-def run_host(exe, root, out_bin, decay=0):
+def run_host(exe, root, out_bin, decay=0, evaluate=0):
     env = dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1)))
-    r = subprocess.run([exe, root, str(N_FRAMES), out_bin, "0.05", str(decay)], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, root, str(N_FRAMES), out_bin, "0.05", str(decay), str(evaluate)], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = r.stdout.strip().splitlines()[-1]
     kv = dict(tok.split("=", 1) for tok in line.split())
@@ -165,6 +165,52 @@ def test_pipeline_is_deterministic_and_decay_runs(oracle_run, oracle_host, datas
     assert kv3["tracks"] == "4"
 
 
+def read_depth_csv(root, which):
+    """-> {frame: {(leg, delta): {"total", "error", "missing", "correct"}}} from the reference's <...>-<which>-depth-result.csv."""
+    import csv
+    path = [f for f in os.listdir(os.path.join(root, "csv")) if f.endswith(f"-{which}-depth-result.csv")]
+    assert len(path) == 1
+    out = {}
+    with open(os.path.join(root, "csv", path[0])) as f:
+        for row in csv.DictReader(f):
+            rec = {}
+            for k, v in row.items():
+                parts = (k or "").split("-")
+                if parts[0] in ("fusion", "input") and parts[1] in ("total", "error", "missing", "correct") and len(parts) == 3:
+                    rec.setdefault((parts[0], parts[2]), {})[parts[1]] = int(v)
+            out[int(row["frame"])] = rec
+    return out
+
+
+def test_reference_evaluation_scores_the_engine_renders_against_lidar(oracle_host, dataset, tmp_path):
+    """FLAGS_enable_evaluation: after every frame Evaluation::EvaluateFrame (DynSlam.cpp:153-159, Evaluation.cpp:35-150) raycasts
+    the map from the frame's pose (GetStaticMapRaycastDepthPreview: the fork's FREECAMERA_DEPTH render + CompositeInstanceDepthMaps),
+    projects the LIDAR returns and scores fused and input depth in disparity space — the accuracy metric of the reference's
+    experiments, computed by its own code on this engine's renders.  The synthetic LIDAR is the exact surface."""
+    kv, log = run_host(oracle_host, dataset, str(tmp_path / "eval.bin"), evaluate=1)
+    assert kv["tracks"] == "4" and log.count("Starting evaluation of frame") == N_FRAMES - 1
+    static, dynamic = read_depth_csv(dataset, "static"), read_depth_csv(dataset, "dynamic")
+    assert sorted(static) == list(range(1, N_FRAMES))
+    for frame, rec in static.items():
+        for delta, floor in (("1.00", 0.965), ("2.00", 0.985), ("3.00", 0.99)):
+            fu, inp = rec[("fusion", delta)], rec[("input", delta)]
+            assert fu["total"] == inp["total"] > 30000
+            acc = fu["correct"] / (fu["correct"] + fu["error"])
+            assert acc > floor, (frame, delta, acc)
+            assert inp["correct"] / (inp["correct"] + inp["error"]) > 0.999  # the input is the truth + 0.25 px of noise
+        # what the map has seen it reproduces: few LIDAR points without a rendered depth once a few frames are fused
+        if frame >= 3:
+            assert rec[("fusion", "1.00")]["missing"] < 0.15 * rec[("fusion", "1.00")]["total"]
+    # fusing frames beats a single frame at the half-pixel level from the third frame on (the point of the paper's figure)
+    for frame in range(3, N_FRAMES):
+        fu, inp = static[frame][("fusion", "0.50")], static[frame][("input", "0.50")]
+        assert fu["correct"] / (fu["correct"] + fu["error"]) > inp["correct"] / (inp["correct"] + inp["error"]) - 0.01
+    # LIDAR points on reconstructed dynamic objects are scored against the composited instance renders
+    last = dynamic[N_FRAMES - 1]
+    assert last[("fusion", "12.00")]["correct"] > 3000
+    assert last[("fusion", "12.00")]["correct"] / (last[("fusion", "12.00")]["correct"] + last[("fusion", "12.00")]["error"]) > 0.95
+
+
 # --- GPU ---------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -178,7 +224,7 @@ def test_reference_pipeline_on_the_hip_engine_matches_the_oracle(tmp_path):
     os.makedirs(root)
     write_dataset(root, N_FRAMES, W, H)
     for decay in (0, 1):
-        got, _ = run_host(hip, root, str(tmp_path / f"hip{decay}.bin"), decay)
-        want, _ = run_host(orc, root, str(tmp_path / f"orc{decay}.bin"), decay)
+        got, _ = run_host(hip, root, str(tmp_path / f"hip{decay}.bin"), decay, evaluate=decay)
+        want, _ = run_host(orc, root, str(tmp_path / f"orc{decay}.bin"), decay, evaluate=decay)
         assert got == want, {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
         assert open(tmp_path / f"hip{decay}.bin", "rb").read() == open(tmp_path / f"orc{decay}.bin", "rb").read()
