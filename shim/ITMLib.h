@@ -188,9 +188,14 @@ struct ITMRGBDCalib {
   ITMDisparityCalib disparityCalib;
 };
 
+// Defaults: DynSLAM's GUI never sets the scene parameters (DynSLAMGUI.cpp:1214-1219), it runs on the FORK's
+// ITMLibSettings defaults, which are not in the reference tree.  What the tree does pin: the experiment artefacts are
+// named after `driver_settings->sceneParams.voxelSize` and read "voxelsize-0.0500" (Evaluation.h:66-72,
+// notebooks/DepthAnalysis.ipynb:47-51), and depth is fused up to 20 m (Input.h:71-72) — so the fork's defaults are
+// 5 cm voxels and an outdoor frustum, not upstream's indoor 5 mm / 3 m.  mu keeps upstream's 4 voxels.
 struct ITMSceneParams {
-  float mu = 0.02f; int maxW = 100; float voxelSize = 0.005f;
-  float viewFrustum_min = 0.2f, viewFrustum_max = 3.0f; bool stopIntegratingAtMaxW = false;
+  float mu = 0.2f; int maxW = 100; float voxelSize = 0.05f;
+  float viewFrustum_min = 0.2f, viewFrustum_max = 30.0f; bool stopIntegratingAtMaxW = false;
 };
 struct ITMLibSettings {
   enum DeviceType { DEVICE_CPU, DEVICE_CUDA, DEVICE_METAL };

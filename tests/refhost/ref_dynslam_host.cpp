@@ -122,10 +122,9 @@ int main(int argc, char **argv) {
                                                         cfg.min_depth_m, cfg.max_depth_m);
     input->SetDepthProvider(depth);
 
-    ITMLibSettings *settings = new ITMLibSettings();
-    settings->sceneParams.voxelSize = voxel;
+    ITMLibSettings *settings = new ITMLibSettings();  // like the GUI: the defaults (shim/ITMLib.h: 5 cm voxels, outdoor frustum) ...
+    settings->sceneParams.voxelSize = voxel;          // ... unless the test asks for another voxel size
     settings->sceneParams.mu = 4.0f * voxel;
-    settings->sceneParams.viewFrustum_max = 30.0f;  // the GUI relies on the fork's defaults (unknown: SURVEY.md F1); upstream's 3 m is indoor
     drivers::InfiniTamDriver *driver = new drivers::InfiniTamDriver(
         settings, drivers::CreateItmCalib(proj, frameSize), drivers::ToItmVec(input->GetRgbSize()), drivers::ToItmVec(input->GetDepthSize()),
         decayParams, false);
