@@ -251,6 +251,12 @@ int main(int argc, char **argv) {
       engine_digest(tracker.GetTrack(reconstructed[0]).GetReconstruction()->GetDsrEngine(), &ist);
       line += Format("object%d_used_after_reap=%d ", reconstructed[0], ist.num_allocated_voxel_blocks - 1 - ist.last_free_block_id);
     }
+    // end of sequence (DynSLAMGUI.cpp's "decay catch-up" button): GC of every queued visible list, then wait for mesh jobs
+    dynSlam->StaticMapDecayCatchup();
+    dynSlam->WaitForJobs();
+    dsr_get_stats(driver->GetDsrEngine(), &st);
+    line += Format("static_decayed_after_catchup=%lld static_saved_decay_bytes=%zu ", (long long)st.decayed_block_count,
+                   dynSlam->GetStaticMapSavedDecayMemoryBytes());
     printf("%s\n", line.c_str());
     fflush(stdout);
     delete dynSlam;

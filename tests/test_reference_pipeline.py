@@ -163,6 +163,10 @@ def test_pipeline_is_deterministic_and_decay_runs(oracle_run, oracle_host, datas
     kv3, _ = run_host(oracle_host, dataset, str(tmp_path / "decay.bin"), decay=1)  # VoxelDecayParams(enabled, min age 3, max weight 1)
     assert int(kv3["static_decayed"]) > 0 and int(kv3["static_used_blocks"]) < int(kv["static_used_blocks"])
     assert kv3["tracks"] == "4"
+    # DecayCatchup (InfiniTamDriver.h:210-225) drains the visible lists still queued; without decay it does nothing
+    assert int(kv3["static_decayed_after_catchup"]) > int(kv3["static_decayed"])
+    assert int(kv3["static_saved_decay_bytes"]) == int(kv3["static_decayed_after_catchup"]) * 4096
+    assert kv["static_decayed_after_catchup"] == "0"
 
 
 def read_depth_csv(root, which):
