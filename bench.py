@@ -222,38 +222,67 @@ def main_volumes(args):
     dev = torch.device("cuda", local_rank)
 
     from dynslam_amd.engine import EngineCore, default_settings, make_calib
-    from dynslam_amd.multigpu import ShardedScene, volumes_of_rank
     from dynslam_amd.synth import StreetScene
     sc = StreetScene(W, H, n_instances=V - 1)
     calib = make_calib(*sc.intrinsics(), W, H)
-    kw = settings_kwargs(args.preset)
-    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
-                   sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
-    view_kw = dict(kw, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
-    kinds = {"static": kw, "instance": inst_kw, "view": view_kw}
+    kinds = volume_settings(args.preset)
 
     def make_engine(kind):
         return EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib)
 
-    rgb_dev = [torch.from_numpy(f[0]).to(dev) for f in frames]
-    dep_dev = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    out = run_volumes(args, frames, make_engine, dev, world, rank, use_dist)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def volume_settings(preset):
+    """Engine settings of the three kinds of engine a rank of the configs[3] job may hold."""
+    kw = settings_kwargs(preset)
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                   sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
+    view_kw = dict(kw, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
+    return {"static": kw, "instance": inst_kw, "view": view_kw}
+
+
+def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None):
+    """The timed part of the configs[3] job, after the process group and the device are set up: returns the bench line
+    (a dict) on rank 0, None elsewhere.  `dev` is this rank's torch device; with a CPU device (tests/test_bench_contract.py
+    drives this function at world size 2 over gloo with the CPU oracle as `make_engine`) the frames are handed over as host
+    arrays and `host_api` composites; on a GPU everything stays on the device."""
+    import torch
+    import torch.distributed as dist
+    from dynslam_amd.multigpu import ShardedScene, volumes_of_rank
+    V = args.volumes
+    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
+    on_gpu = dev.type == "cuda"
+    if on_gpu:
+        rgb_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
+        dep_in = [torch.from_numpy(f[1]).to(dev) for f in frames]
+        torch.cuda.synchronize()
     track_ids = {k: 1 + k for k in range(V - 1)}
     pose_m = [np.linalg.inv(np.asarray(f[2], np.float64)).astype(np.float32) for f in frames]
     inst_m = [{k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in f[3]} for f in frames]
-    torch.cuda.synchronize()
 
     def run(scene, nranks):
         def step(i):
-            scene.step(rgb_dev[i].data_ptr(), dep_dev[i].data_ptr(), frames[i][2], frames[i][3])
+            if on_gpu:
+                scene.step(rgb_in[i].data_ptr(), dep_in[i].data_ptr(), frames[i][2], frames[i][3])
+            else:
+                scene.step(frames[i][0], frames[i][1], frames[i][2], frames[i][3])
             scene.preview(pose_m[i], inst_m[i], track_ids)
 
         def barrier():
             scene.sync()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
             if use_dist and nranks == world:
                 dist.barrier()
             scene.sync()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
         for i in range(Wm):
             step(i)
         if getattr(scene, "after_warmup", None):
@@ -266,8 +295,10 @@ def main_volumes(args):
         return time.perf_counter() - t0
 
     scene = ShardedScene(make_engine, W, H, V, world, rank, dev)
+    scene.exchange.host_api = host_api
     prof = []
-    if scene.owns_static and not args.no_profile:  # HIP events around the static map's integrate + raycast
+    profiled = scene.owns_static and not args.no_profile and on_gpu
+    if profiled:  # HIP events around the static map's integrate + raycast
         scene.static.profile_enable(2)
 
         def _reset():
@@ -275,7 +306,7 @@ def main_volumes(args):
             scene.static.profile_reset()
         scene.after_warmup = _reset
     elapsed = run(scene, world)
-    if scene.owns_static and not args.no_profile:
+    if profiled:
         prof = scene.static.profile_get()
         scene.static.profile_enable(False)
     stats = scene.static.get_stats() if scene.owns_static else None
@@ -289,38 +320,35 @@ def main_volumes(args):
     sliced = None
     if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
         one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True)
+        one.exchange.host_api = host_api
         t1 = run(one, 1)
         one.close()
         sliced = {"composited_frames_per_s": round(K / t1, 3), "ms_per_step": round(1e3 * t1 / K, 4),
                   "note": f"the same {V} volumes fused + previewed sequentially on rank 0's GPU, same frames"}
-
-    if rank == 0:
-        roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's static map: the dominant kernel of the job
-        out = {
-            "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
-            "value": round(V * K / elapsed, 3) if world > 1 else round(K / elapsed, 3),
-            "unit": "volume-frames/s" if world > 1 else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[3]: static map (preset {args.preset}) + {V - 1} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
-                                   f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1)), synthetic "
-                                   f"KITTI-like street {W}x{H} with {V - 1} moving boxes, frames {Wm}..{Wm + K - 1}; every step = silhouette "
-                                   f"split + fusion (allocate, integrate, raycast) of every volume + fused preview: colour and depth raycast "
-                                   f"of every volume from the frame's camera, RCCL all-gather of the {V - 1} instance layers "
-                                   f"({(V - 1) * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
-                       "volumes": V, "volumes_per_rank": [len(volumes_of_rank(r, V, world)) for r in range(world)],
-                       "composited_frames_per_s": round(K / elapsed, 3),
-                       "preview_hit_fraction": round(hit, 4),
-                       "static_visible_blocks_last_frame": stats.no_visible_blocks if stats else None,
-                       "status": stats.sticky_status if stats else None},
-            "time_sliced_1gpu": sliced,
-            "speedup_vs_time_sliced_1gpu": round((K / elapsed) / sliced["composited_frames_per_s"], 3) if sliced else None,
-            "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
-        }
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's static map: the dominant kernel of the job
+    return {
+        "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
+        "value": round(V * K / elapsed, 3) if world > 1 else round(K / elapsed, 3),
+        "unit": "volume-frames/s" if world > 1 else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3]: static map (preset {args.preset}) + {V - 1} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
+                               f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1)), synthetic "
+                               f"KITTI-like street {W}x{H} with {V - 1} moving boxes, frames {Wm}..{Wm + K - 1}; every step = silhouette "
+                               f"split + fusion (allocate, integrate, raycast) of every volume + fused preview: colour and depth raycast "
+                               f"of every volume from the frame's camera, RCCL all-gather of the {V - 1} instance layers "
+                               f"({(V - 1) * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
+                   "volumes": V, "volumes_per_rank": [len(volumes_of_rank(r, V, world)) for r in range(world)],
+                   "composited_frames_per_s": round(K / elapsed, 3),
+                   "preview_hit_fraction": round(hit, 4),
+                   "static_visible_blocks_last_frame": stats.no_visible_blocks if stats else None,
+                   "status": stats.sticky_status if stats else None},
+        "time_sliced_1gpu": sliced,
+        "speedup_vs_time_sliced_1gpu": round((K / elapsed) / sliced["composited_frames_per_s"], 3) if sliced else None,
+        "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+    }
 
 
 def main():

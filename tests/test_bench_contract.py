@@ -60,3 +60,57 @@ def test_presets_match_the_baseline_configs():
     assert bench.PRESETS["5mm"]["voxel_size"] == 0.005 and bench.PRESETS["4mm"]["voxel_size"] == 0.004
     kw = bench.settings_kwargs("5mm")
     assert kw["mu"] == 0.02 and kw["max_w"] == 100 and kw["view_frustum_max"] == 30.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# `bench.py --gpus N` (N > 1): the timed part of the configs[3] job — bench.run_volumes, what every rank runs after the
+# process group is up — at world size 2 over gloo with the CPU oracle as the engine.  Checks the line the driver will
+# record (value = V*K/t in volume-frames/s, max over ranks, the time-sliced one-GPU leg on rank 0 while the other
+# ranks wait) and that no rank deadlocks on a collective the others do not enter.
+
+def _volumes_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dynslam_amd.engine import make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, load_api, oracle_settings
+    W, H, V = 256, 80, world
+    args = argparse.Namespace(volumes=V, width=W, height=H, steps=3, warmup=1, preset="5cm", no_profile=False, no_time_sliced=False,
+                              decay=False, swap=False, instances=0)
+    frames = [bench._gen_frame((W, H, i, V - 1)) for i in range(args.steps + args.warmup)]
+    calib = make_calib(*StreetScene(W, H, n_instances=V - 1).intrinsics(), W, H)
+    kinds = bench.volume_settings(args.preset)
+    line = bench.run_volumes(args, frames, lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib), torch.device("cpu"), world, rank,
+                             True, host_api=load_api())
+    assert (line is not None) == (rank == 0)
+    if rank == 0:
+        with open(os.path.join(out_dir, "line.json"), "w") as f:
+            json.dump(line, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_configs3_bench_line_at_world_size_2(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_volumes_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    line = json.load(open(tmp_path / "line.json"))
+    assert line["n_gpus"] == 2 and line["unit"] == "volume-frames/s" and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
+    assert line["metric"].startswith("frames/sec TSDF integrate+raycast") and line["higher_is_better"] is True and line["vs_baseline"] is None
+    cfg = line["config"]
+    assert cfg["volumes"] == 2 and cfg["volumes_per_rank"] == [1, 1] and cfg["workload"].startswith("configs[3]")
+    # value = whole-job volume-frames per second = V * K / (max-over-ranks time)
+    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
+    assert abs(cfg["composited_frames_per_s"] * 2 - line["value"]) / line["value"] < 1e-3
+    assert cfg["preview_hit_fraction"] > 0.3 and cfg["status"] == 0 and cfg["static_visible_blocks_last_frame"] > 100
+    ts = line["time_sliced_1gpu"]
+    assert ts and ts["composited_frames_per_s"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0
+    assert line["roofline"] is None and line["cpu_baseline"] is None  # no HIP events on a CPU device; N = 1 item
