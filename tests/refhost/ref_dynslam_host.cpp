@@ -201,6 +201,18 @@ int main(int argc, char **argv) {
                    (unsigned long long)fnv(colourStatic.data(), P * 4), (unsigned long long)fnv(depthStatic.data(), P * 4),
                    (unsigned long long)fnv(colourFused.data(), P * 4), (unsigned long long)fnv(depthFused.data(), P * 4));
 
+    // every preview type the GUI cycles through (PreviewType.h; InfiniTamDriver.cpp:16-34 maps them onto GetImage types)
+    {
+      const PreviewType types[] = {PreviewType::kGray, PreviewType::kNormal, PreviewType::kWeight, PreviewType::kLatestRaycast, PreviewType::kDepth};
+      const char *names[] = {"gray", "normal", "weight", "latest_raycast", "depth_as_colour"};
+      for (int k = 0; k < 5; k++) {
+        const unsigned char *img = dynSlam->GetStaticMapRaycastPreview(mv, types[k], k % 2 == 0);
+        size_t lit = 0;
+        for (size_t q = 0; q < P; q++) lit += (img[q * 4] | img[q * 4 + 1] | img[q * 4 + 2]) != 0;
+        line += Format("preview_%s=%016llx:lit%zu ", names[k], (unsigned long long)fnv(img, P * 4), lit);
+      }
+    }
+
     auto &tracker = dynSlam->GetInstanceReconstructor()->GetInstanceTracker();
     line += Format("tracks=%d ", tracker.GetActiveTrackCount());
     std::vector<int> reconstructed;

@@ -142,6 +142,10 @@ def test_composite_preview_meshes_and_memory_log(oracle_run, dataset):
     # background dimmed by 10 % (InstanceReconstructor.cpp:945-954)
     cs, cf = d["colour_static"][far][:, :3].astype(np.int32), d["colour_fused"][far][:, :3].astype(np.int32)
     assert np.array_equal(cf, (cs * (1.0 - float(np.float32(0.10)))).astype(np.int32))  # `1.0 - dim_factor` with a float 0.10f
+    # every preview type of the GUI renders something (kDepth through GetImage has no RGBA output: stays empty)
+    for name in ("gray", "normal", "weight", "latest_raycast"):
+        assert int(kv[f"preview_{name}"].split(":lit")[1]) > 0.3 * W * H, name
+    assert len({kv[f"preview_{n}"].split(":")[0] for n in ("gray", "normal", "weight", "latest_raycast")}) == 4
     mesh_dir = os.path.join(dataset, "mesh_out", "synthetic")
     objs = [os.path.join(dp, f) for dp, _, fs in os.walk(mesh_dir) for f in fs if f.endswith(".obj")]
     names = sorted(os.path.basename(p) for p in objs)
