@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Offline study input: per-ray march step counts of the bench workload's steady state, from the CPU oracle
+"""Offline study input (uses the CPU oracle, hence under tests/): per-ray march step counts of the bench workload's steady state, from the CPU oracle
 (oracle/dsr_oracle.cpp orc_debug_raycast_steps).  Fuses frames 0..N-1 of bench.py's default workload (1242x375, preset 5mm,
 the bench's table sizes) and writes the step count of every ray of the LAST frame's Prepare() raycast to an .npy file,
 for tools/raycast_divergence_model.py.
 
-usage: python tools/raycast_steps_dump.py [--frames 8] [--preset 5mm] [--out /tmp/raycast_steps.npy]
+usage: python tests/study/raycast_steps_dump.py [--frames 8] [--preset 5mm] [--out /tmp/raycast_steps.npy]
 """
 import argparse
 import ctypes as C
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Offline model of k_raycast's lane divergence (no GPU needed): given the per-ray march step counts of a frame
-(tools/raycast_steps_dump.py), how many WAVE-ITERATIONS does a mapping of rays to wavefronts cost?  A wave iterates as long
+(tests/study/raycast_steps_dump.py), how many WAVE-ITERATIONS does a mapping of rays to wavefronts cost?  A wave iterates as long
 as its longest ray, so cost(mapping) = sum over waves of max(steps of its 64 rays); the kernel is bound by the per-wave
 chain of dependent round trips with every wave resident, so launch time is roughly proportional to it.
 
