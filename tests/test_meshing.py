@@ -37,6 +37,36 @@ def test_tables_are_the_generators_and_valid(tmp_path):
         assert open(os.path.join(ROOT, copy)).read() == out.read_text(), f"{copy} is not the generator's output"
 
 
+# rows 0..15 of the classic (Lorensen & Cline / Bourke) triangle table, the cases with all negative corners on the bottom
+# face — written down from the published table, NOT produced by the generator
+CLASSIC_ROWS_0_15 = [[], [0, 8, 3], [0, 1, 9], [1, 8, 3, 9, 8, 1], [1, 2, 10], [0, 8, 3, 1, 2, 10], [9, 2, 10, 0, 2, 9],
+                     [2, 8, 3, 2, 10, 8, 10, 9, 8], [3, 11, 2], [0, 11, 2, 8, 11, 0], [1, 9, 0, 2, 3, 11], [1, 11, 2, 1, 9, 11, 9, 8, 11],
+                     [3, 10, 1, 11, 10, 3], [0, 10, 1, 0, 8, 10, 8, 11, 10], [3, 9, 0, 3, 11, 9, 11, 10, 9], [9, 8, 10, 10, 8, 11]]
+
+
+def test_generated_table_cuts_the_classic_polygons():
+    """Independent of the generator: for the 16 cases whose published rows are at hand, the generated triangles cover the
+    same ORIENTED polygons as the classic table (same cube numbering, same winding, and on the ambiguous bottom face —
+    cases 5 and 10 — the same choice: every negative corner cut off on its own).  The triangulation INSIDE a polygon may
+    differ, which moves no surface point."""
+    et, tt, _ = _generator().tables()
+
+    def boundary(tris):
+        d = {}
+        for t in tris:
+            for i in range(3):
+                d[(t[i], t[(i + 1) % 3])] = 1
+        return {e for e in d if (e[1], e[0]) not in d}
+    same_triangles = 0
+    for case, row in enumerate(CLASSIC_ROWS_0_15):
+        classic = [tuple(row[i:i + 3]) for i in range(0, len(row), 3)]
+        assert boundary(tt[case]) == boundary(classic), case
+        assert len(tt[case]) == len(classic)
+        norm = lambda t: min((t[i], t[(i + 1) % 3], t[(i + 2) % 3]) for i in range(3))  # noqa: E731
+        same_triangles += {norm(t) for t in tt[case]} == {norm(t) for t in classic}
+    assert same_triangles >= 8  # every single-triangle case at least
+
+
 def _plane_engine(api_engine_cls=None):
     """An oracle engine that fused a fronto-parallel wall at z = 2 m from 3 identical frames."""
     from oracle.oracle import OracleEngine, oracle_settings
