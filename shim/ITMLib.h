@@ -19,6 +19,7 @@
 #include <future>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../include/dsr.h"
@@ -250,21 +251,42 @@ class ITMView {
   ITMRGBDCalib *calib;
   ITMUChar4Image *rgb;
   ITMFloatImage *depth;
-  dsr_engine *owner = nullptr;  // engine whose device view mirrors this host view (may be null)
+  dsr_engine *owner = nullptr;  // engine whose device view mirrors this host view (may be null): set with bind()
   bool deviceStale = true;      // host buffers are newer than the engine's copy
   // takes ownership of calib (InstanceReconstructor.cpp:782-785)
   ITMView(const ITMRGBDCalib *c, Vector2i imgSize_rgb, Vector2i imgSize_d, bool /*useGPU*/)
       : calib(new ITMRGBDCalib(*c)), rgb(new ITMUChar4Image(imgSize_rgb, true, true)), depth(new ITMFloatImage(imgSize_d, true, true)) {
-    for (auto *hook : {(void *)rgb, (void *)depth}) (void)hook;
     rgb->ctx = depth->ctx = this;
     rgb->toHost = depth->toHost = [](void *v) { static_cast<ITMView *>(v)->pull(); };
     rgb->toDevice = depth->toDevice = [](void *v) { static_cast<ITMView *>(v)->deviceStale = true; };
   }
-  ~ITMView() { delete calib; delete rgb; delete depth; }
+  ~ITMView() { bind(nullptr); delete calib; delete rgb; delete depth; }
   void pull() {
     if (owner && !deviceStale)
       dsr_get_view(owner, reinterpret_cast<uint8_t *>(rgb->GetData(MEMORYDEVICE_CPU)), depth->GetData(MEMORYDEVICE_CPU));
   }
+  // Views outlive engines in the host (a track keeps the views of its frames, InstanceView.h, while its InfiniTamDriver is
+  // reaped or pruned): the engine a view mirrors is tracked here so that a dying engine can detach its views instead
+  // of leaving them with a dangling handle.
+  void bind(dsr_engine *e) {
+    if (owner == e) return;
+    auto &reg = registry();
+    if (owner) {
+      auto range = reg.equal_range(owner);
+      for (auto it = range.first; it != range.second; ++it) if (it->second == this) { reg.erase(it); break; }
+    }
+    owner = e;
+    if (e) reg.emplace(e, this);
+  }
+  static void detach_all(dsr_engine *e) {  // called by the engine's destructor
+    auto &reg = registry();
+    auto range = reg.equal_range(e);
+    for (auto it = range.first; it != range.second; ++it) { it->second->owner = nullptr; it->second->deviceStale = true; }
+    reg.erase(range.first, range.second);
+  }
+
+ private:
+  static std::unordered_multimap<dsr_engine *, ITMView *> &registry() { static std::unordered_multimap<dsr_engine *, ITMView *> r; return r; }
 };
 
 }  // namespace Objects
@@ -376,7 +398,7 @@ template <class TVoxel, class TIndex> class ITMDenseMapper {
     if (view->owner != e_ || view->deviceStale) {
       ITMLib::Engine::dsr_throw(dsr_set_view_float(e_, reinterpret_cast<const uint8_t *>(view->rgb->GetData(MEMORYDEVICE_CPU)),
                                                    view->depth->GetData(MEMORYDEVICE_CPU)));
-      view->owner = e_; view->deviceStale = false;
+      view->bind(e_); view->deviceStale = false;
     }
   }
  private:
@@ -404,7 +426,7 @@ class ITMViewBuilder {
   void UpdateView(ITMView **view, ITMUChar4Image *rgb, ITMShortImage *rawDepth, bool /*useBilateral*/, bool /*modelSensorNoise*/ = false) {
     if (*view == nullptr) *view = new ITMView(calib_, rgb->noDims, rawDepth->noDims, true);
     ITMLib::Engine::dsr_throw(dsr_update_view(e_, reinterpret_cast<const uint8_t *>(rgb->GetData(MEMORYDEVICE_CPU)), rawDepth->GetData(MEMORYDEVICE_CPU)));
-    (*view)->owner = e_; (*view)->deviceStale = false;
+    (*view)->bind(e_); (*view)->deviceStale = false;
     // keep the host colour copy current; the converted depth is fetched on UpdateHostFromDevice()
     (*view)->rgb->SetFrom(rgb, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
   }
@@ -457,6 +479,7 @@ class ITMMainEngine {
     delete view;  // the host nulls it first when it does not own it (InstanceTracker.cpp:44-50)
     delete scene; delete denseMapper; delete trackingController; delete viewBuilder; delete trackingState;
     delete renderState_live; delete visualisationEngine;
+    ITMView::detach_all(engine_);  // views kept by the host (track frames) must not keep the dead handle
     dsr_engine_destroy(engine_);
   }
 

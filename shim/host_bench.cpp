@@ -74,7 +74,7 @@ class HostDriver : public ITMMainEngine {
   // names it (InstanceReconstructor.cpp:580 SetView) without uploading stale host buffers over it
   void AdoptDeviceView() {
     if (!view) view = new ITMView(viewBuilder->GetCalib(), rgb_.noDims, rawDepth_.noDims, true);
-    view->owner = GetDsrEngine();
+    view->bind(GetDsrEngine());
     view->deviceStale = false;
   }
   size_t GetUsedMemoryBytes() const {                                                                       // .h:241-244

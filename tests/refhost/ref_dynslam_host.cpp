@@ -263,6 +263,18 @@ int main(int argc, char **argv) {
       engine_digest(tracker.GetTrack(reconstructed[0]).GetReconstruction()->GetDsrEngine(), &ist);
       line += Format("object%d_used_after_reap=%d ", reconstructed[0], ist.num_allocated_voxel_blocks - 1 - ist.last_free_block_id);
     }
+    // what InstanceTracker::PruneTracks does when a track expires after 50 frames without a detection
+    // (InstanceTracker.cpp:37-58): the track's engine dies, the host keeps (and may still sync) the views of its frames
+    if (!reconstructed.empty()) {
+      instreclib::reconstruction::Track &t = tracker.GetTrack(reconstructed.back());
+      ITMView *lastView = t.GetLastFrame().instance_view.GetView();
+      t.GetReconstruction()->SetView(nullptr);
+      t.GetReconstruction().reset();  // ~InfiniTamDriver -> ~ITMMainEngine -> dsr_engine_destroy
+      lastView->rgb->UpdateHostFromDevice();  // must not reach the dead engine
+      lastView->depth->UpdateHostFromDevice();
+      line += Format("pruned_track=%d pruned_view_detached=%d pruned_has_reconstruction=%d ", reconstructed.back(), lastView->owner == nullptr ? 1 : 0,
+                     t.HasReconstruction() ? 1 : 0);
+    }
     // end of sequence (DynSLAMGUI.cpp's "decay catch-up" button): GC of every queued visible list, then wait for mesh jobs
     dynSlam->StaticMapDecayCatchup();
     dynSlam->WaitForJobs();

@@ -94,6 +94,8 @@ def test_tracker_classifies_the_objects_and_starts_their_reconstructions(oracle_
     assert recon == [1, 2, 3]  # the uncertain one is cut away and never fused (InstanceReconstructor.cpp:238-246)
     for i in recon:
         assert int(kv[f"track{i}"].split(":used")[1].split(":")[0]) > 100  # blocks in its own volume
+    # an expiring track takes its engine with it; the views the host keeps are detached, not left with a dead handle
+    assert kv["pruned_track"] == "3" and kv["pruned_view_detached"] == "1" and kv["pruned_has_reconstruction"] == "0"
     assert "Unknown motion for possibly dynamic object of class car; cutting away!" in log
     assert "Reaping track with max weight" in log  # ForceDynamicObjectCleanup -> Track::ReapReconstruction -> Decay(force)
     # GetUsedMemoryBytes = (allocated - lastFreeBlockId) blocks: one more than the blocks in use (InfiniTamDriver.h:241-244)
