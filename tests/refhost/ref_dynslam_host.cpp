@@ -13,7 +13,7 @@
 // Only this file is ours: it builds the objects like BuildDynSlamKittiOdometry does (DynSLAMGUI.cpp:1100-1270, a GUI unit
 // that is not compiled), installs the odometry script, runs N frames and dumps what the engines hold.
 //
-// usage: ref_dynslam_host <dataset_root> <n_frames> <out.bin> [voxel_size] [decay: 0|1] [evaluate: 0|1]
+// usage: ref_dynslam_host <dataset_root> <n_frames> <out.bin> [voxel_size] [decay: 0|1] [evaluate: 0|1] [blocks buckets excess]
 //   evaluate = 1: Evaluation::EvaluateFrame after every frame (DynSlam.cpp:153-159) against <dataset_root>/velodyne/%06d.bin
 //   <dataset_root>/synthetic.txt : W H fx fy cx cy baseline
 //   <dataset_root>/viso/%06d.bin : the script of frame k >= 1 (tests/refhost/make_dataset.py)
@@ -96,6 +96,8 @@ int main(int argc, char **argv) {
   const float voxel = argc > 4 ? (float)atof(argv[4]) : 0.05f;
   const bool decay = argc > 5 && atoi(argv[5]) != 0;
   const bool evaluate = argc > 6 && atoi(argv[6]) != 0;
+  const long blocks = argc > 9 ? atol(argv[7]) : 0;  // table sizes for small voxels (default: upstream's constants)
+  const int buckets = argc > 9 ? atoi(argv[8]) : 0, excess = argc > 9 ? atoi(argv[9]) : 0;
 
   int W = 0, H = 0;
   double fx = 0, fy = 0, cx = 0, cy = 0, baseline = 0;
@@ -125,6 +127,7 @@ int main(int argc, char **argv) {
     ITMLibSettings *settings = new ITMLibSettings();  // like the GUI: the defaults (shim/ITMLib.h: 5 cm voxels, outdoor frustum) ...
     settings->sceneParams.voxelSize = voxel;          // ... unless the test asks for another voxel size
     settings->sceneParams.mu = 4.0f * voxel;
+    if (blocks > 0) { settings->sdfLocalBlockNum = blocks; settings->hashBucketNum = buckets; settings->excessListSize = excess; }
     drivers::InfiniTamDriver *driver = new drivers::InfiniTamDriver(
         settings, drivers::CreateItmCalib(proj, frameSize), drivers::ToItmVec(input->GetRgbSize()), drivers::ToItmVec(input->GetDepthSize()),
         decayParams, false);
