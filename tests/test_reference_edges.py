@@ -54,6 +54,9 @@ def boxes(seed):
     out = []
     for x0, y0, bw, bh in [(10, 5, 30, 20), (-7, -3, 25, 15), (80, 30, 40, 25), (0, 0, W, H), (50, 10, 1, 1)]:
         out.append((x0, y0, (rng.random((bh, bw)) < 0.6).astype(np.uint8)))
+    # boxes entirely outside the frame / much taller than it, and masks holding values other than 0 / 1 (only 1 selects)
+    for x0, y0, bw, bh in [(-50, -50, 20, 20), (200, 5, 10, 10), (5, -100, 10, 300), (20, 8, 40, 20)]:
+        out.append((x0, y0, rng.choice(np.array([0, 1, 2, 255], np.uint8), (bh, bw))))
     return out
 
 
@@ -191,3 +194,47 @@ def test_hip_composite_equals_reference_code(hip_api, ref):
 @pytest.mark.gpu
 def test_hip_disparity_and_conversions_equal_reference_code(hip_api, ref):
     check_disparity_and_conversions(hip_api, ref)
+
+
+# --- special values: NaN, infinities, signed zeros, denormals, exact ties -----------------------------------------------------
+
+_SPECIAL_DEPTH = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, -1.0, 1e-40, -1e-40, 3.0, 3.0000002, 1e30], np.float32)
+_SPECIAL_DISP = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-5, 9.9e-6, -9.9e-6, 1e-6, -3.0, 0.5, 19.0, 37.98, 759.0, 1e-38, 1e20], np.float32)
+
+
+def check_special_values(api, ref, trials):
+    """Compositing and disparity conversion on buffers drawn from the awkward floats: the reference's comparisons
+    (`s != 0 && (t == 0 || t > s)`, `abs(disp) < 1e-5`, the int casts) decide every case, bit for bit."""
+    P = W * H
+    rng = np.random.default_rng(21)
+    for _ in range(trials):
+        bg_c = rng.integers(0, 256, (P, 4)).astype(np.uint8)
+        bg_d = rng.choice(_SPECIAL_DEPTH, P).astype(np.float32)
+        L = 3
+        lc = rng.integers(0, 256, (L, P, 4)).astype(np.uint8)
+        ld = rng.choice(_SPECIAL_DEPTH, (L, P)).astype(np.float32)
+        ids = np.sort(rng.choice(60, L, replace=False)).astype(np.int32)
+        ts = float(rng.choice([0.0, 0.3, 0.5, 1.0]))
+        t_c, t_d = bg_c.copy(), bg_d.copy()
+        assert api.composite_instances(vp(t_c), vp(t_d), vp(lc), vp(ld), vp(ids), L, P, ts, 0) == 0
+        w_c, w_d = bg_c.copy(), bg_d.copy()
+        for k in range(L):
+            assert ref.ref_composite_color(vp(w_c), vp(w_d), vp(lc[k]), vp(ld[k]), W, H, int(ids[k]), C.c_float(ts)) == 0
+        assert np.array_equal(t_d.view(np.uint32), w_d.view(np.uint32)) and np.array_equal(t_c, w_c)
+        disp = rng.choice(_SPECIAL_DISP, P).astype(np.float32)
+        scale, lo, hi = float(rng.choice([1.0, 0.75, 0.5])), float(rng.choice([0.0, 0.5])), float(rng.choice([20.0, 32.0]))
+        got, want = np.empty(P, np.int16), np.empty(P, np.int16)
+        assert api.depth_from_disparity(vp(disp), vp(got), P, 0.537150654273, 707.0912, scale, lo, hi) == 0
+        assert ref.ref_depth_from_disparity(vp(disp), vp(want), W, H, C.c_float(0.537150654273), C.c_float(707.0912), C.c_float(scale),
+                                            C.c_float(lo), C.c_float(hi)) == 0
+        assert np.array_equal(got, want), (scale, lo, hi)
+
+
+def test_oracle_edges_equal_reference_code_on_special_values(oracle_lib, ref):
+    check_special_values(oracle_lib, ref, 60)
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=False, reason="written after round 2's GPU minutes were spent: first GPU run pending (remove this marker once it has passed)")
+def test_hip_edges_equal_reference_code_on_special_values(hip_api, ref):
+    check_special_values(hip_api, ref, 20)
