@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 from . import _capi
-from ._capi import (BLOCK_SIZE3, DSR_E_OUT_OF_BLOCKS, DSR_OK, Calib, Intrinsics, KernelTime,
+from ._capi import (BLOCK_SIZE3, DSR_E_OUT_OF_BLOCKS, DSR_OK, Calib, KernelTime,
                     Settings, Stats)
 
 HASH_ENTRY_DTYPE = np.dtype([("pos", "<i2", (3,)), ("pad", "<i2"), ("offset", "<i4"), ("ptr", "<i4")])

@@ -3,7 +3,6 @@
 CPU: the library's and the oracle's parsers (host code, no GPU needed) against files written here in the two
 formats and against each other, error behaviour included.  GPU: clamp + disparity conversion == oracle."""
 import ctypes as C
-import struct
 
 import numpy as np
 import pytest
