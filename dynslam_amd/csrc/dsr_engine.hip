@@ -1187,7 +1187,7 @@ static bool read_whole_file(const char *path, std::string *out) {
   return true;
 }
 
-int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
   if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
   std::string doc;
   if (!read_whole_file(path, &doc)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
@@ -1223,7 +1223,7 @@ int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, in
   return DSR_OK;
 }
 
-int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+static int read_pfm_impl(const char *path, float *out, int capacity, int *width, int *height) {
   if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
   FILE *f = fopen(path, "rb");
   if (!f) return fail(DSR_E_IO, "Could not read precomputed depth map.");
@@ -1254,6 +1254,19 @@ int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *he
   }
   fclose(f);
   return DSR_OK;
+}
+
+// The size is reported whenever the header could be read (DSR_OK, and DSR_E_ARG for a buffer that is too small: the
+// size query of a caller that allocates afterwards); after DSR_E_IO it is 0 x 0, never a half-parsed value.
+int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+  const int st = read_depth_xml_impl(path, depth_mm_out, capacity, width, height);
+  if (st == DSR_E_IO && width && height) *width = *height = 0;
+  return st;
+}
+int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+  const int st = read_pfm_impl(path, out, capacity, width, height);
+  if (st == DSR_E_IO && width && height) *width = *height = 0;
+  return st;
 }
 
 static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h) {

@@ -272,8 +272,9 @@ int dsr_depth_from_disparity_dev(int device, void *hip_stream, const void *dispa
 
 /* PrecomputedDepthProvider::ReadPrecomputed (src/DynSLAM/PrecomputedDepthProvider.cpp:22-75): the two on-disk
  * formats of precomputed maps, read into caller-provided host buffers of `capacity` elements
- * (*width / *height are set even when the map does not fit: DSR_E_ARG then; DSR_E_IO for a missing or
- * malformed file — the reference throws std::runtime_error at :40,:43,:47-52).
+ * (*width / *height are set even when the map does not fit: DSR_E_ARG then — call with capacity 0 to
+ * query the size; DSR_E_IO for a missing or malformed file — the reference throws std::runtime_error at
+ * :40,:43,:47-52 — leaves them 0 x 0.  Nothing is ever written past `capacity` elements.)
  *   dsr_read_depth_xml  OpenCV FileStorage XML dump of a CV_16SC1 matrix under the node "depth-frame"
  *                       (:35-45; the ELAS depth maps, Input.h:71-78 "%04d.xml"): <rows>, <cols>, <dt>s</dt>,
  *                       <data> as whitespace-separated decimals, row-major.  Any other <dt> is the

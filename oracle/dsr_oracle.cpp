@@ -1516,7 +1516,7 @@ int orc_depth_from_disparity_dev(int, void *, const void *d, void *o, int n, flo
 
 /* PrecomputedDepthProvider::ReadPrecomputed (PrecomputedDepthProvider.cpp:22-75), restated with iostreams:
  * the OpenCV FileStorage XML dump of a CV_16SC1 matrix (node "depth-frame": rows, cols, dt = "s", data) */
-int orc_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
   if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
   std::ifstream in(path, std::ios::binary);
   if (!in) return fail(DSR_E_IO, "Could not read precomputed depth map.");
@@ -1539,14 +1539,14 @@ int orc_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, in
   if (!element(doc, "depth-frame", node)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
   int rows = 0, cols = 0;
   if (!element(node, "rows", t)) return fail(DSR_E_IO, "no rows");
-  rows = std::stoi(t);
+  rows = atoi(t.c_str());  /* no exceptions across the C ABI: garbage reads as 0 -> "empty matrix" below */
   if (!element(node, "cols", t)) return fail(DSR_E_IO, "no cols");
-  cols = std::stoi(t);
+  cols = atoi(t.c_str());
   if (!element(node, "dt", t)) return fail(DSR_E_IO, "no dt");
   std::string dt; for (char c : t) if (!isspace((unsigned char)c)) dt += c;
   if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format."); /* out.type() != CV_16SC1 */
   *width = cols; *height = rows;
-  if (rows == 0 || cols == 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
+  if (rows <= 0 || cols <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
   if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
   if (!element(node, "data", t)) return fail(DSR_E_IO, "no data");
   std::istringstream data(t);
@@ -1558,7 +1558,7 @@ int orc_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, in
 }
 /* single-channel PFM: "Pf", width height, scale (< 0: little endian), raster bottom row first; returned
  * top row first (what ReadFilePFM of the reference's pfmLib submodule — absent — hands to OpenCV) */
-int orc_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+static int read_pfm_impl(const char *path, float *out, int capacity, int *width, int *height) {
   if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
   std::ifstream in(path, std::ios::binary);
   if (!in) return fail(DSR_E_IO, "Could not read precomputed depth map.");
@@ -1582,6 +1582,17 @@ int orc_read_pfm(const char *path, float *out, int capacity, int *width, int *he
     }
   }
   return DSR_OK;
+}
+/* size reported with DSR_OK and DSR_E_ARG (buffer too small: the size query), 0 x 0 after DSR_E_IO */
+int orc_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
+  const int st = read_depth_xml_impl(path, depth_mm_out, capacity, width, height);
+  if (st == DSR_E_IO && width && height) *width = *height = 0;
+  return st;
+}
+int orc_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
+  const int st = read_pfm_impl(path, out, capacity, width, height);
+  if (st == DSR_E_IO && width && height) *width = *height = 0;
+  return st;
 }
 /* the input_is_depth_ clamp, int16 branch (PrecomputedDepthProvider.cpp:55-74) */
 int orc_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m) {

@@ -132,3 +132,68 @@ def test_precomputed_depth_provider_matches_reference_loops(tmp_path, hip_api, o
     torch.cuda.synchronize()
     w2 = depth.copy(); assert oracle_lib.clip_depth_mm(vp(w2), w2.size, 7.3) == 0
     assert np.array_equal(t.cpu().numpy(), w2)
+
+
+# --- malformed files: the two parsers are host code in the product library; a broken file must produce an error code, never a
+# crash or a write past the caller's buffer.  Runs in a child process so that a crash is a test failure, not a dead pytest.
+
+_FUZZ_CHILD = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from dynslam_amd.engine import load_hip_api
+from oracle.oracle import load_api
+from tests.test_depth_io import write_cv_xml, write_pfm
+tmp = sys.argv[2]
+rng = np.random.default_rng(5)
+H, W = 12, 17
+depth = rng.integers(0, 32767, (H, W)).astype(np.int16)
+disp = rng.uniform(0, 100, (H, W)).astype(np.float32)
+write_cv_xml(os.path.join(tmp, "good.xml"), depth)
+write_pfm(os.path.join(tmp, "good.pfm"), disp)
+good = {"xml": open(os.path.join(tmp, "good.xml"), "rb").read(), "pfm": open(os.path.join(tmp, "good.pfm"), "rb").read()}
+apis = [("hip", load_hip_api()), ("oracle", load_api())]
+GUARD = 64
+def call(api, kind, path, cap):
+    w, h = C.c_int(-1), C.c_int(-1)
+    if kind == "xml":
+        buf = np.full(cap + GUARD, -12345, np.int16)
+        st = api.read_depth_xml(path.encode(), buf.ctypes.data_as(C.c_void_p), cap, C.byref(w), C.byref(h))
+    else:
+        buf = np.full(cap + GUARD, -12345.0, np.float32)
+        st = api.read_pfm(path.encode(), buf.ctypes.data_as(C.c_void_p), cap, C.byref(w), C.byref(h))
+    assert (buf[cap:] == -12345).all(), "write past the buffer"
+    return st, w.value, h.value, buf[:cap].tobytes() if st == 0 else b""
+n = 0
+for kind in ("xml", "pfm"):
+    base = good[kind]
+    cases = [base[:k] for k in range(0, len(base), max(1, len(base) // 97))]
+    for _ in range(1500):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 6))):
+            op = int(rng.integers(0, 4))
+            pos = int(rng.integers(0, len(b)))
+            if op == 0: b[pos] = int(rng.integers(0, 256))
+            elif op == 1: del b[pos:pos + int(rng.integers(1, 40))]
+            elif op == 2: b[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 20))).astype(np.uint8))
+            else: b[pos:pos] = rng.choice([b"99999999999", b"-1", b"<rows>", b"</data>", b"Pf\n", b"\x00", b"2147483647 2147483647"])
+        cases.append(bytes(b))
+    for i, data in enumerate(cases):
+        path = os.path.join(tmp, "case." + kind)
+        open(path, "wb").write(data)
+        for cap in (H * W, 5, 0):
+            res = [call(api, kind, path, cap) for _, api in apis]
+            assert res[0] == res[1], (kind, i, cap, res[0][:3], res[1][:3])
+            assert res[0][0] in (0, 1, 6), res[0][0]   # DSR_OK, DSR_E_ARG, DSR_E_IO
+            n += 1
+print("ok", n)
+'''
+
+
+def test_parsers_survive_malformed_files(tmp_path, oracle_lib):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FUZZ_CHILD, root, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
