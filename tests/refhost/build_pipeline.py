@@ -38,12 +38,13 @@ def inputs():
     return [HOST, os.path.join(ROOT, "shim", "ITMLib.h"), os.path.join(ROOT, "include", "dsr.h")]
 
 
-def build(kind, exe, workdir):
-    """-> exe.  `workdir` receives the object files (and the rename header for kind "oracle")."""
+def build(kind, exe, workdir, extra_flags=(), oracle_dir=None):
+    """-> exe.  `workdir` receives the object files (and the rename header for kind "oracle").  extra_flags: e.g. sanitizer
+    options (compile and link); oracle_dir: where liboracle.so is taken from (a sanitised build for those)."""
     assert kind in ("hip", "oracle")
     os.makedirs(workdir, exist_ok=True)
     os.makedirs(os.path.dirname(exe), exist_ok=True)
-    flags = ["-std=c++14", "-O1", "-DNDEBUG"]
+    flags = ["-std=c++14", "-O1", "-DNDEBUG"] + list(extra_flags)
     if kind == "oracle":
         import sys
         sys.path.insert(0, ROOT)
@@ -52,8 +53,8 @@ def build(kind, exe, workdir):
         with open(rename, "w") as f:
             f.write("".join(f"#define dsr_{name} orc_{name}\n" for name in _capi.SIGNATURES))
         flags += ["-include", rename]
-        lib_dir = os.path.join(ROOT, "oracle")
-        link = ["-L", lib_dir, "-loracle", f"-Wl,-rpath,{lib_dir}", "-fopenmp"]
+        lib_dir = oracle_dir or os.path.join(ROOT, "oracle")
+        link = ["-L", lib_dir, "-loracle", f"-Wl,-rpath,{lib_dir}", "-fopenmp"] + list(extra_flags)
     else:
         lib_dir = os.path.join(ROOT, "dynslam_amd", "csrc")
         link = ["-L", lib_dir, "-ldsr_hip", f"-Wl,-rpath,{lib_dir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
