@@ -92,6 +92,7 @@ SIGNATURES = {
     "reset_scene": (C.c_int, [_H]),
     "sync": (C.c_int, [_H]),
     "device_synchronize": (C.c_int, []),
+    "device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "wait_for_stream": (C.c_int, [_H, _P]),
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "update_view": (C.c_int, [_H, _P, _P]),

@@ -777,6 +777,19 @@ int dsr_device_synchronize(void) {
   return rc;
 }
 
+int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (!free_bytes || !total_bytes) return fail(DSR_E_ARG, "null argument");
+  int prev = 0;
+  const bool havePrev = hipGetDevice(&prev) == hipSuccess;
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  size_t f = 0, t = 0;
+  const hipError_t err = hipMemGetInfo(&f, &t);
+  if (device >= 0 && havePrev) (void)hipSetDevice(prev);
+  if (err != hipSuccess) return fail(DSR_E_DEVICE, std::string("hipMemGetInfo: ") + hipGetErrorString(err));
+  *free_bytes = f; *total_bytes = t;
+  return DSR_OK;
+}
+
 // ---- stream ordering without host synchronisation (dsr.h)
 
 int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {

@@ -179,6 +179,9 @@ int dsr_sync(dsr_engine *e);
  * created on (the host's per-frame "final sanity check": ITMSafeCall(cudaDeviceSynchronize()) +
  * cudaGetLastError(), DynSlam.cpp:163-172).  Returns DSR_E_DEVICE if a device reports an error. */
 int dsr_device_synchronize(void);
+/* Free / total memory of a device in bytes (device < 0: the calling thread's current device): the GUI's memory read-out,
+ * cudaMemGetInfo at DynSLAMGUI.cpp:912. */
+int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
 /* Stream ordering for the "_dev" entry points, WITHOUT host synchronisation.  Every engine
  * enqueues on its own private HIP stream and "_dev" calls return before the work has run, so a

@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 #include <deque>
 #include <new>
 #include <string>
@@ -1357,6 +1358,13 @@ void orc_engine_destroy(dsr_engine *h) { delete h; }
 int orc_reset_scene(dsr_engine *h) { if (!h) return fail(DSR_E_ARG, "null"); reset_scene(E); return DSR_OK; }
 int orc_sync(dsr_engine *h) { return h ? DSR_OK : fail(DSR_E_ARG, "null"); }
 int orc_device_synchronize(void) { return DSR_OK; }  // the CPU restatement runs synchronously
+int orc_device_mem_info(int, uint64_t *free_bytes, uint64_t *total_bytes) {  /* the "device" is the host: its RAM */
+  if (!free_bytes || !total_bytes) return fail(DSR_E_ARG, "null argument");
+  const long page = sysconf(_SC_PAGESIZE);
+  *total_bytes = (uint64_t)sysconf(_SC_PHYS_PAGES) * (uint64_t)page;
+  *free_bytes = (uint64_t)sysconf(_SC_AVPHYS_PAGES) * (uint64_t)page;
+  return DSR_OK;
+}
 
 int orc_update_view(dsr_engine *h, const uint8_t *rgba, const int16_t *depth_mm) {
   if (!h || !rgba || !depth_mm) return fail(DSR_E_ARG, "null");

@@ -150,13 +150,19 @@ struct ITMVoxelIndex {};
 static_assert(sizeof(ITMVoxel) == sizeof(dsr_voxel), "voxel size");
 
 // ITMSafeCall(err) (ITMLib/Utils/ITMCUDAUtils.h: print + exit on a CUDA error; DynSlam.cpp:165,171) and the two CUDA
-// runtime names DynSLAM's host calls directly after every frame (DynSlam.cpp:165-166: device-wide sync + error
-// poll; upstream they arrive through ITMLib's headers).  They map onto the library's device-wide sync; errors of
+// runtime names DynSLAM's host calls directly (DynSlam.cpp:165-166: device-wide sync + error poll after every frame;
+// DynSLAMGUI.cpp:912: cudaMemGetInfo; upstream they arrive through ITMLib's headers).  They map onto the library's device-wide sync; errors of
 // individual engine calls are already raised as exceptions where they happen.
 typedef int cudaError_t;
 enum { cudaSuccess = 0 };
 inline cudaError_t cudaDeviceSynchronize() { return dsr_device_synchronize(); }
 inline cudaError_t cudaGetLastError() { return cudaSuccess; }
+inline cudaError_t cudaMemGetInfo(size_t *free_bytes, size_t *total_bytes) {  // DynSLAMGUI.cpp:912: the memory read-out
+  uint64_t f = 0, t = 0;
+  const int st = dsr_device_mem_info(-1, &f, &t);
+  *free_bytes = (size_t)f; *total_bytes = (size_t)t;
+  return st;
+}
 inline void ITMSafeCallImpl(int err, const char *file, int line) {
   if (err != 0) throw std::runtime_error(std::string(file) + ":" + std::to_string(line) + ": " + dsr_last_error());
 }

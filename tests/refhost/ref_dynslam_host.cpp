@@ -284,6 +284,12 @@ int main(int argc, char **argv) {
     dsr_get_stats(driver->GetDsrEngine(), &st);
     line += Format("static_decayed_after_catchup=%lld static_saved_decay_bytes=%zu ", (long long)st.decayed_block_count,
                    dynSlam->GetStaticMapSavedDecayMemoryBytes());
+    {  // the GUI's memory read-out (DynSLAMGUI.cpp:909-915)
+      size_t freeBytes = 0, totalBytes = 0;
+      cudaMemGetInfo(&freeBytes, &totalBytes);
+      fprintf(stderr, "[host] device memory: %.1f GiB free of %.1f GiB\n", freeBytes / 1073741824.0, totalBytes / 1073741824.0);
+      if (totalBytes == 0 || freeBytes > totalBytes) throw std::runtime_error("cudaMemGetInfo returned nonsense");
+    }
     printf("%s\n", line.c_str());
     fflush(stdout);
     delete dynSlam;
