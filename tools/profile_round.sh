@@ -3,6 +3,7 @@
 # PMC passes are never combined with tracing (gpurun refuses that combination).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export DSR_BENCH_NO_POOL=1   # no forked worker pool under the profiler (it has hung there: a 30 GPU-minute call in round 2)
 TAG=${1:-r02a}
 O=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
