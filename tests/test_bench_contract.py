@@ -93,7 +93,11 @@ def _volumes_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_configs3_bench_line_at_world_size_2(tmp_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world", [2, 8])  # 8 = the node the driver's scaling run uses: static map + 7 instance volumes
+def test_configs3_bench_line_at_world_size_n(tmp_path, world):
     import socket
 
     import torch.multiprocessing as mp
@@ -101,15 +105,15 @@ def test_configs3_bench_line_at_world_size_2(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_volumes_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_volumes_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     line = json.load(open(tmp_path / "line.json"))
-    assert line["n_gpus"] == 2 and line["unit"] == "volume-frames/s" and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
+    assert line["n_gpus"] == world and line["unit"] == "volume-frames/s" and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
     assert line["metric"].startswith("frames/sec TSDF integrate+raycast") and line["higher_is_better"] is True and line["vs_baseline"] is None
     cfg = line["config"]
-    assert cfg["volumes"] == 2 and cfg["volumes_per_rank"] == [1, 1] and cfg["workload"].startswith("configs[3]")
+    assert cfg["volumes"] == world and cfg["volumes_per_rank"] == [1] * world and cfg["workload"].startswith("configs[3]")
     # value = whole-job volume-frames per second = V * K / (max-over-ranks time)
-    assert abs(line["value"] - 2 * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
-    assert abs(cfg["composited_frames_per_s"] * 2 - line["value"]) / line["value"] < 1e-3
+    assert abs(line["value"] - world * 3 / (line["ms_per_step"] * 3 / 1e3)) / line["value"] < 1e-3
+    assert abs(cfg["composited_frames_per_s"] * world - line["value"]) / line["value"] < 1e-3
     assert cfg["preview_hit_fraction"] > 0.3 and cfg["status"] == 0 and cfg["static_visible_blocks_last_frame"] > 100
     ts = line["time_sliced_1gpu"]
     assert ts and ts["composited_frames_per_s"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0

@@ -148,13 +148,14 @@ def _sharded_worker(rank, world, port, n_volumes, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_volumes", [(2, 3), (3, 4)])
+@pytest.mark.parametrize("world,n_volumes", [(2, 3), (3, 4), (8, 8)])  # (8, 8): configs[3] as the driver's 8-GPU run shards it
 def test_sharded_scene_equals_single_process(tmp_path, oracle_lib, world, n_volumes):
     mp.spawn(_sharded_worker, args=(world, _free_port(), n_volumes, str(tmp_path)), nprocs=world, join=True)
     got = np.load(tmp_path / "sharded.npz")
     rgba1, depth1, layers1 = _sharded_run(1, 0, n_volumes)
     assert (depth1 > 0).mean() > 0.3
     # the instance layers really arrived (non-empty) and the composite used them
-    assert sum(int((got["layers"][l] > 0).any()) for l in range(got["layers"].shape[0])) >= n_volumes - 2
+    # (boxes 4.. of the synthetic street start beyond the 20 m depth clip: at most 4 instances are in range in 3 frames)
+    assert sum(int((got["layers"][l] > 0).any()) for l in range(got["layers"].shape[0])) >= min(n_volumes - 2, 4)
     assert np.array_equal(got["depth"], depth1)
     assert np.array_equal(got["rgba"], rgba1)
