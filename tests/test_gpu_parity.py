@@ -340,3 +340,22 @@ def test_free_view_cache(hip_api):
     feed((g, o), sc, 4)
     same_images(pose_b)
     g.close(); o.close()
+
+
+@pytest.mark.xfail(strict=False, reason="written after round 2's GPU minutes were spent: first GPU run pending (remove this marker once it has passed)")
+@pytest.mark.parametrize("env", [dict(DSR_GRID_INTEGRATE="1"), dict(DSR_GRID_INTEGRATE="37", DSR_GRID_EXPECTED="1", DSR_GRID_DECAY="3"),
+                                 dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768")])
+def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
+    """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
+    kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
+    list of k_integrate is appended in a different order, the range image is folded by other workgroups — never a bit of
+    the result."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc, g, o = make_pair()
+    for i in range(5):
+        feed((g, o), sc, i)
+        for e in (g, o):
+            e.decay(1, 2, False)
+        assert_scene_equal(g, o, voxels=(i in (0, 4)))
+        assert_render_equal(g, o)

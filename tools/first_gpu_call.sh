@@ -7,7 +7,7 @@ TAG=${1:-r03a}
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
 # 1. the tests that are xfail-guarded until their first GPU run (remove the markers when they pass)
-timeout 600 python -m pytest tests/test_reference_pipeline.py tests/test_reference_edges.py -m gpu -q -rxX > $O/${TAG}_new_gpu_tests.log 2>&1
+timeout 600 python -m pytest tests/test_reference_pipeline.py tests/test_reference_edges.py tests/test_gpu_parity.py -m gpu -q -rxX -k "pipeline or special_values or launch_geometry" > $O/${TAG}_new_gpu_tests.log 2>&1
 # 2. the whole GPU suite
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/${TAG}_gpu_suite.log 2>&1
 # 3. the bench line the driver records, and the configs[3] leg on one GPU under torchrun (RCCL path, world 1)
