@@ -5,15 +5,18 @@ A "step" is one pass of the hot path over one frame of the synthetic KITTI-like 
 (dynslam_amd/synth.py): UpdateView (inputs already resident in HBM) -> SetPose ->
 ProcessFrame (allocate + integrate) -> Prepare (expected depths + raycast + ICP maps).
 At N = 1 the workload is BASELINE.json configs[1]: static map only, 1242x375, 5 mm voxels.
-With --gpus N > 1 it is configs[3]: ONE VOLUME PER GPU — the static map on rank 0, instance volume k
-(0.035 m voxels, mu 1.0, 7142 blocks) on rank k — fused every frame, plus the one real exchange of the
-path inside the timed step: every rank raycasts its volume from the shared camera, the per-volume
-depth + colour layers are ALL-GATHERED over RCCL and rank 0 z-composites them over the static map's
-render (dynslam_amd/multigpu.py ShardedScene).  value = volume-frames/s = N*K / max-rank time (weak
-scaling: one volume per GPU); the line also carries composited frames/s and, measured on rank 0 after the
-timed region, the same N volumes TIME-SLICED ON ONE GPU (north_star's denominator).
-`--volumes V` runs that workload with V volumes on any number of GPUs (N = 1: all time-sliced);
-`--replicas` restores N independent copies of configs[1] (no collective).
+
+`python bench.py --gpus N` (N > 1, as the driver starts it — no launcher) forks its N ranks itself, one per GPU, RCCL process
+group over 127.0.0.1; under `python -m torch.distributed.run` it uses the ranks it is given.  The N > 1 line measures what
+north_star names: N CONCURRENT INSTANCE VOLUMES (0.035 m voxels, mu 1.0, 7142 blocks), one per GPU — silhouette split, fusion
+(allocate + integrate + raycast) and, inside the timed step, the one real exchange of the path: every rank raycasts its volume
+from the shared camera, the per-volume depth + colour layers are ALL-GATHERED over RCCL (one collective) and rank 0
+z-composites them (dynslam_amd/multigpu.py ShardedScene).  value = volume-frames/s = N*K / max-rank time (weak scaling: one
+volume per GPU); the line also carries, measured on rank 0 after the timed region, the same N volumes TIME-SLICED ON ONE GPU
+(north_star's denominator) and their ratio.  Nested under "configs3": the same measurement for BASELINE configs[3] — the 5 mm
+static map on rank 0 + N-1 instance volumes on the other ranks.
+`--instance-volumes V` / `--volumes V` run either leg alone with V volumes on any number of GPUs (N = 1: all time-sliced);
+`--replicas` runs N independent copies of configs[1] (no collective).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement) with the
 extra objects "roofline" (dominant kernel: integrate) and "cpu_baseline" (the CPU oracle on
@@ -197,40 +200,156 @@ def roofline_from_profile(prof, args, copy_gbs):
                                                     "and written as an 8 B struct; NOT what this layout moves, kept for reference"},
                         "note": "achieved = layout-true compulsory bytes / HIP-event duration: per visible block 4 B list id "
                                 "+ 16 B hash entry + 1536 B sdf and w_depth planes read, 24 B written per lane that updated a "
-                                "voxel, 10 B per colour voxel, 8 B per pixel of the frames (tallied by the kernel itself); "
+                                "voxel, 8 B per colour voxel (one word read + written), 8 B per pixel of the frames (tallied by the kernel itself); "
                                 "traffic = rocprofv3 PMC bytes per visible block (profiles/) x this run's visible blocks"}
     return roofline, kernels
 
 
-def main_volumes(args):
-    """BASELINE configs[3] (see the module docstring): V volumes sharded over the ranks, fusion + fused preview per step."""
-    V = args.volumes
-    W, H, K, Wm = args.width, args.height, args.steps, args.warmup
-    frames = make_frames(W, H, Wm + K, V - 1)  # before HIP / RCCL start (fork)
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
 
-    import torch
+
+def _test_backend():
+    """TEST SEAM.  The product path is fixed: HIP engines (libdsr_hip.so) on cuda:<LOCAL_RANK>, RCCL.  tests/ may name a module
+    in DSR_BENCH_TEST_BACKEND that stands in for the device layer — `device(local_rank)`, `DIST_BACKEND`,
+    `engine_factory(kinds, calib, local_rank)` and `host_api()` — so that THIS file's command line, rank spawning, collectives
+    and JSON line run in the CPU suite (tests/bench_backend_oracle.py: the CPU oracle over gloo).  bench.py itself never imports
+    anything under oracle/ outside the cpu_baseline leg, and without the variable a missing GPU / HIP library is an error."""
+    name = os.environ.get("DSR_BENCH_TEST_BACKEND")
+    if not name:
+        return None
+    import importlib
+    return importlib.import_module(name)
+
+
+_PREGENERATED = {}  # n_instances -> frames, filled by the parent of spawn_ranks() before it forks
+
+
+def frames_for(args, n_inst):
+    """The synthetic frames of a leg: generated once per job (the forked ranks inherit the parent's copy)."""
+    if n_inst not in _PREGENERATED:
+        _PREGENERATED[n_inst] = make_frames(args.width, args.height, args.warmup + args.steps, n_inst)
+    return _PREGENERATED[n_inst]
+
+
+def multi_gpu_legs(args, world):
+    """-> [(n_volumes, has_static)] of a multi-volume job: the headline leg first.
+    --instance-volumes V: north_star's scaling workload, V concurrent instance volumes;  --volumes V: configs[3], the static map
+    + V-1 instance volumes;  `--gpus N` alone: BOTH, N instance volumes (headline) and configs[3] with N volumes (nested)."""
+    legs = []
+    if args.instance_volumes:
+        legs.append((args.instance_volumes, False))
+    if args.volumes:
+        legs.append((args.volumes, True))
+    if not legs and world > 1 and not args.replicas:
+        legs = [(world, False)] + ([] if args.no_configs3 else [(world, True)])
+    return legs
+
+
+def spawn_ranks(args, legs):
+    """`python bench.py --gpus N` exactly as the driver starts it (no torchrun): generate the inputs ONCE, then fork one rank per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the child's environment, as torch.distributed.run would set them).  The
+    parent has not touched HIP or torch, so the fork is safe; the children inherit the frames copy-on-write.  Rank 0 prints the
+    line; the parent's exit status is the worst of its ranks and a failing rank takes the others down (no hang on a collective)."""
+    import signal
+    N = args.gpus
+    if args.replicas:
+        frames_for(args, args.instances)
+    for V, has_static in legs:
+        frames_for(args, V - 1 if has_static else V)
+    port = _free_port()
+    sys.stdout.flush()
+    pids = {}
+    for r in range(N):
+        pid = os.fork()
+        if pid == 0:
+            rc = 1
+            try:
+                os.environ.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                run_rank(args)
+                rc = 0
+            except BaseException:  # noqa: BLE001 - the child must never return into the parent's stack
+                import traceback
+                traceback.print_exc()
+            finally:
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(rc)
+        pids[pid] = r
+    worst = 0
+    while pids:
+        pid, status = os.wait()
+        if pid not in pids:
+            continue
+        r = pids.pop(pid)
+        rc = os.waitstatus_to_exitcode(status)
+        if rc != 0:
+            worst = worst or (rc if rc > 0 else 1)
+            print(f"bench.py: rank {r} exited with {rc}; stopping the other ranks", file=sys.stderr)
+            for other in list(pids):
+                try:
+                    os.kill(other, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+    return worst
+
+
+def main_volumes(args, legs):
+    """One rank of a multi-volume job (see multi_gpu_legs): the headline leg's line with the other leg nested under "configs3"."""
+    W, H = args.width, args.height
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    frame_sets = [frames_for(args, V - 1 if has_static else V) for V, has_static in legs]  # before HIP / RCCL start (fork)
+
+    import torch
+    tb = _test_backend()
     use_dist = world > 1 or "RANK" in os.environ  # under torchrun the process group (RCCL) is used for one rank too
+    if tb is None:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+        assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} on this node"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = tb.device(local_rank)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if tb is None:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(tb.DIST_BACKEND)
 
-    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+    from dynslam_amd.engine import make_calib
     from dynslam_amd.synth import StreetScene
-    sc = StreetScene(W, H, n_instances=V - 1)
-    calib = make_calib(*sc.intrinsics(), W, H)
+    calib = make_calib(*StreetScene(W, H).intrinsics(), W, H)
     kinds = volume_settings(args.preset)
+    if tb is None:
+        from dynslam_amd.engine import EngineCore, default_settings
 
-    def make_engine(kind):
-        return EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib)
+        def make_engine(kind):
+            return EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib)
+        host_api = None
+    else:
+        make_engine = tb.engine_factory(kinds, calib, local_rank)
+        host_api = tb.host_api()
 
-    out = run_volumes(args, frames, make_engine, dev, world, rank, use_dist)
+    out = None
+    for (V, has_static), frames in zip(legs, frame_sets):
+        a = argparse.Namespace(**vars(args))
+        a.volumes = V
+        line = run_volumes(a, frames, make_engine, dev, world, rank, use_dist, host_api=host_api, has_static=has_static)
+        if rank == 0:
+            if out is None:
+                out = line
+            else:  # the second leg rides along under its own key: ONE line per job
+                out["configs3" if has_static else "instance_volumes"] = {k: line[k] for k in (
+                    "value", "unit", "ms_per_step", "config", "time_sliced_1gpu", "speedup_vs_time_sliced_1gpu", "kernels")}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -239,7 +358,7 @@ def main_volumes(args):
 
 
 def volume_settings(preset):
-    """Engine settings of the three kinds of engine a rank of the configs[3] job may hold."""
+    """Engine settings of the three kinds of engine a rank of a multi-volume job may hold."""
     kw = settings_kwargs(preset)
     inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
                    sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
@@ -247,31 +366,36 @@ def volume_settings(preset):
     return {"static": kw, "instance": inst_kw, "view": view_kw}
 
 
-def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None):
-    """The timed part of the configs[3] job, after the process group and the device are set up: returns the bench line
+def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None, has_static=True):
+    """The timed part of a multi-volume job, after the process group and the device are set up: returns the bench line
     (a dict) on rank 0, None elsewhere.  `dev` is this rank's torch device; with a CPU device (tests/test_bench_contract.py
-    drives this function at world size 2 over gloo with the CPU oracle as `make_engine`) the frames are handed over as host
-    arrays and `host_api` composites; on a GPU everything stays on the device."""
+    drives this function over gloo with the CPU oracle as `make_engine`) the frames are handed over as host arrays and
+    `host_api` composites; on a GPU everything — frames AND silhouette masks — is resident in HBM before the timed region."""
     import torch
     import torch.distributed as dist
     from dynslam_amd.multigpu import ShardedScene, volumes_of_rank
     V = args.volumes
+    n_inst = V - 1 if has_static else V
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     on_gpu = dev.type == "cuda"
+    masks_in = [f[3] for f in frames]
     if on_gpu:
         rgb_in = [torch.from_numpy(f[0]).to(dev) for f in frames]
         dep_in = [torch.from_numpy(f[1]).to(dev) for f in frames]
+        mask_dev = [[torch.from_numpy(np.ascontiguousarray(m)).to(dev) for _, _, _, m, _ in f[3]] for f in frames]
+        masks_in = [[(k, x0, y0, (t.data_ptr(), m.shape[1], m.shape[0]), rel) for (k, x0, y0, m, rel), t in zip(f[3], md)]
+                    for f, md in zip(frames, mask_dev)]
         torch.cuda.synchronize()
-    track_ids = {k: 1 + k for k in range(V - 1)}
+    track_ids = {k: 1 + k for k in range(n_inst)}
     pose_m = [np.linalg.inv(np.asarray(f[2], np.float64)).astype(np.float32) for f in frames]
     inst_m = [{k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in f[3]} for f in frames]
 
     def run(scene, nranks):
         def step(i):
             if on_gpu:
-                scene.step(rgb_in[i].data_ptr(), dep_in[i].data_ptr(), frames[i][2], frames[i][3])
+                scene.step(rgb_in[i].data_ptr(), dep_in[i].data_ptr(), frames[i][2], masks_in[i])
             else:
-                scene.step(frames[i][0], frames[i][1], frames[i][2], frames[i][3])
+                scene.step(frames[i][0], frames[i][1], frames[i][2], masks_in[i])
             scene.preview(pose_m[i], inst_m[i], track_ids)
 
         def barrier():
@@ -291,25 +415,28 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
         t0 = time.perf_counter()
         for i in range(Wm, Wm + K):
             step(i)
+        t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (nothing has been waited for yet)
         barrier()
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, t_enq
 
-    scene = ShardedScene(make_engine, W, H, V, world, rank, dev)
+    scene = ShardedScene(make_engine, W, H, V, world, rank, dev, has_static=has_static)
     scene.exchange.host_api = host_api
     prof = []
-    profiled = scene.owns_static and not args.no_profile and on_gpu
-    if profiled:  # HIP events around the static map's integrate + raycast
-        scene.static.profile_enable(2)
+    probe = scene.static if scene.owns_static else (next(iter(scene.instances.values())) if (scene.instances and rank == 0) else None)
+    profiled = probe is not None and not args.no_profile and on_gpu
+    if profiled:  # HIP events around integrate + raycast of rank 0's map (or first instance volume)
+        probe.profile_enable(2)
 
         def _reset():
-            scene.static.sync()
-            scene.static.profile_reset()
+            probe.sync()
+            probe.profile_reset()
         scene.after_warmup = _reset
-    elapsed = run(scene, world)
+    elapsed, t_enq = run(scene, world)
     if profiled:
-        prof = scene.static.profile_get()
-        scene.static.profile_enable(False)
+        prof = probe.profile_get()
+        probe.profile_enable(False)
     stats = scene.static.get_stats() if scene.owns_static else None
+    inst_stats = [e.get_stats() for e in scene.instances.values()]
     hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
     scene.close()
     if world > 1:
@@ -319,41 +446,51 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
 
     sliced = None
     if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
-        one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True)
+        one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True, has_static=has_static)
         one.exchange.host_api = host_api
-        t1 = run(one, 1)
+        t1, _ = run(one, 1)
         one.close()
-        sliced = {"composited_frames_per_s": round(K / t1, 3), "ms_per_step": round(1e3 * t1 / K, 4),
+        sliced = {"value": round(V * K / t1, 3), "unit": "volume-frames/s", "composited_frames_per_s": round(K / t1, 3),
+                  "ms_per_step": round(1e3 * t1 / K, 4),
                   "note": f"the same {V} volumes fused + previewed sequentially on rank 0's GPU, same frames"}
     if rank != 0:
         return None
-    roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's static map: the dominant kernel of the job
+    roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's probe engine
+    per_rank = [len(volumes_of_rank(r, V, world, has_static)) for r in range(world)]
+    if has_static:
+        what = (f"configs[3]: static map (preset {args.preset}) + {n_inst} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
+                f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1))")
+    else:
+        what = (f"north_star scaling workload: {n_inst} concurrent instance volumes (0.035 m, mu 1.0, 7142 blocks; "
+                f"InstanceReconstructor.cpp:372-379) sharded one volume per GPU over {world} GPU(s) (instance k on rank k mod N), no static map")
+    volume_rate = world > 1 or not has_static
     return {
         "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
-        "value": round(V * K / elapsed, 3) if world > 1 else round(K / elapsed, 3),
-        "unit": "volume-frames/s" if world > 1 else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "value": round(V * K / elapsed, 3) if volume_rate else round(K / elapsed, 3),
+        "unit": "volume-frames/s" if volume_rate else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[3]: static map (preset {args.preset}) + {V - 1} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
-                               f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1)), synthetic "
-                               f"KITTI-like street {W}x{H} with {V - 1} moving boxes, frames {Wm}..{Wm + K - 1}; every step = silhouette "
-                               f"split + fusion (allocate, integrate, raycast) of every volume + fused preview: colour and depth raycast "
-                               f"of every volume from the frame's camera, RCCL all-gather of the {V - 1} instance layers "
-                               f"({(V - 1) * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
-                   "volumes": V, "volumes_per_rank": [len(volumes_of_rank(r, V, world)) for r in range(world)],
+        "config": {"workload": f"{what}, synthetic KITTI-like street {W}x{H} with {n_inst} moving boxes, frames {Wm}..{Wm + K - 1}; "
+                               f"every step = silhouette split (masks resident in HBM) + fusion (allocate, integrate, raycast) of "
+                               f"every volume + fused preview: colour and depth raycast of every volume from the frame's camera, "
+                               f"ONE RCCL all-gather of the {n_inst} instance layers ({n_inst * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
+                   "volumes": V, "volumes_per_rank": per_rank, "has_static_map": bool(has_static),
                    "composited_frames_per_s": round(K / elapsed, 3),
+                   "host_enqueue_ms_per_step_rank0": round(1e3 * t_enq / K, 4),
                    "preview_hit_fraction": round(hit, 4),
                    "static_visible_blocks_last_frame": stats.no_visible_blocks if stats else None,
-                   "status": stats.sticky_status if stats else None},
+                   "instance_visible_blocks_last_frame_rank0": [s_.no_visible_blocks for s_ in inst_stats],
+                   "status": max([stats.sticky_status if stats else 0] + [s_.sticky_status for s_ in inst_stats])},
         "time_sliced_1gpu": sliced,
         "speedup_vs_time_sliced_1gpu": round((K / elapsed) / sliced["composited_frames_per_s"], 3) if sliced else None,
         "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
     }
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="GPUs of this node to use.  N > 1 without a launcher (RANK unset): bench.py forks the N ranks itself")
     ap.add_argument("--steps", type=int, default=45)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preset", default="5mm", choices=sorted(PRESETS))
@@ -376,20 +513,40 @@ def main():
     ap.add_argument("--instances", type=int, default=0,
                     help="configs[2]: also reconstruct this many moving instances in their own volumes "
                          "(voxel 0.035, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379), split on the GPU")
+    ap.add_argument("--instance-volumes", type=int, default=0,
+                    help="north_star's scaling workload: V concurrent INSTANCE volumes (0.035 m, mu 1.0, 7142 blocks), one per GPU "
+                         "(instance k on rank k mod N), silhouette split + fusion + fused preview (all-gather + composite) per "
+                         "step; reports aggregate volume-frames/s and the same V volumes time-sliced on one GPU "
+                         "(the headline of --gpus N > 1, with V = N)")
     ap.add_argument("--volumes", type=int, default=0,
                     help="configs[3]: static map + (V-1) instance volumes sharded one per GPU with the fused-preview "
-                         "all-gather + composite in the timed step (default when --gpus > 1: V = number of GPUs)")
+                         "all-gather + composite in the timed step (nested under \"configs3\" in the --gpus N > 1 line)")
+    ap.add_argument("--no-configs3", action="store_true", help="--gpus N > 1: only the instance-volumes leg")
     ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
-    ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of the configs[3] line")
-    args = ap.parse_args()
+    ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of a multi-volume line")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse_args(argv)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.volumes == 0 and world_env > 1 and not args.replicas:
-        args.volumes = world_env
-    if args.volumes > 1:
-        return main_volumes(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the driver's `python bench.py --gpus N ...`: no launcher around us, so the ranks are ours to start
+        sys.exit(spawn_ranks(args, multi_gpu_legs(args, args.gpus)))
+    if "RANK" in os.environ and args.gpus != world_env and args.gpus != 1:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world_env} rank(s); using {world_env}", file=sys.stderr)
+    run_rank(args)
+
+
+def run_rank(args):
+    """One rank of the job (the only one at N = 1)."""
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    legs = multi_gpu_legs(args, world_env)
+    if legs:
+        return main_volumes(args, legs)
 
     # synthetic frames first: the worker pool forks, which must happen before HIP / RCCL start
-    frames = make_frames(args.width, args.height, args.warmup + args.steps, args.instances)
+    frames = frames_for(args, args.instances)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

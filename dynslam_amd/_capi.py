@@ -8,7 +8,7 @@ import ctypes as C
 import os
 from types import SimpleNamespace
 
-ABI_VERSION = 1
+ABI_VERSION = 2  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
 BLOCK_SIZE = 8
 BLOCK_SIZE3 = 512
 
@@ -125,6 +125,9 @@ SIGNATURES = {
     "depth_m_to_mm_dev": (C.c_int, [C.c_int, _P, _P, _P, C.c_int]),
     "view_extract_silhouette": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "view_remove_silhouette": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "view_extract_silhouette_dev": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "view_remove_silhouette_dev": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "composite_layer_ptrs_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),

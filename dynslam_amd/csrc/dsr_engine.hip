@@ -829,7 +829,8 @@ int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m)
   CHECK_E(e);
   if (!rgba || !depth_m) return fail(DSR_E_ARG, "null image");
   HIP_TRY(hipMemcpyAsync(e->rgb, rgba, (size_t)e->Wr * e->Hr * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->depth, depth_m, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->depthTmp, depth_m, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
+  LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depthTmp, e->depth, e->P);
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->hasView = true;
   return DSR_OK;
@@ -839,7 +840,8 @@ int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *dept
   CHECK_E(e);
   if (!rgba_dev || !depth_m_dev) return fail(DSR_E_ARG, "null image");
   HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->depth, depth_m_dev, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)depth_m_dev, e->depth, e->P);
+  HIP_TRY(hipGetLastError());
   e->hasView = true;
   return DSR_OK;
 }
@@ -1151,8 +1153,8 @@ static short clip_limit_mm(float max_depth_m) {
 int dsr_clip_depth_mm_dev(int device, void *hip_stream, void *depth_mm_dev, int n, float max_depth_m) {
   if (!depth_mm_dev || n <= 0) return fail(DSR_E_ARG, "bad clip arguments");
   if (device >= 0) HIP_TRY(hipSetDevice(device));
-  hipLaunchKernelGGL(k_clip_depth_mm, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, (const short *)depth_mm_dev,
-                     (short *)depth_mm_dev, n, clip_limit_mm(max_depth_m));
+  hipLaunchKernelGGL(k_clip_depth_mm, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, (short *)depth_mm_dev, n,
+                     clip_limit_mm(max_depth_m));
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -1216,6 +1218,8 @@ static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capa
   std::string dt = node.substr(b, e2 - b);
   dt.erase(std::remove_if(dt.begin(), dt.end(), [](char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }), dt.end());
   if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format.");  // :42-44: CV_16SC1 only
+  // a size no camera produces is a malformed file, not something to allocate for (the size query hands it to the caller)
+  if ((long long)rows * cols > (1ll << 28) || rows > (1 << 20) || cols > (1 << 20)) return fail(DSR_E_IO, "depth-frame: implausible rows x cols");
   *width = cols; *height = rows;
   if (rows <= 0 || cols <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map: empty matrix");
   if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
@@ -1229,7 +1233,7 @@ static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capa
     char *next = nullptr;
     const long v = strtol(p, &next, 10);
     if (next == p) return fail(DSR_E_IO, "malformed <data> in depth-frame");
-    depth_mm_out[i++] = (int16_t)v;
+    depth_mm_out[i++] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));  // cv::saturate_cast<short>
     p = next;
   }
   if (i != n) return fail(DSR_E_IO, "depth-frame <data> holds fewer values than rows x cols");
@@ -1249,6 +1253,7 @@ static int read_pfm_impl(const char *path, float *out, int capacity, int *width,
     return fail(DSR_E_IO, "not a single-channel PFM (\"Pf\") file");
   }
   (void)fgetc(f);
+  if ((long long)w * h > (1ll << 28) || w > (1 << 20) || h > (1 << 20)) { fclose(f); return fail(DSR_E_IO, "PFM: implausible width x height"); }
   *width = w; *height = h;
   if (w <= 0 || h <= 0) { fclose(f); return fail(DSR_E_IO, "Could not read precomputed depth map: empty image"); }
   if (!out || (long long)w * h > capacity) { fclose(f); return fail(DSR_E_ARG, "PFM image larger than the buffer"); }
@@ -1296,16 +1301,20 @@ static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h)
   return DSR_OK;
 }
 
-int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
-                                int box_w, int box_h) {
+// maskDev == nullptr: `mask` is a host buffer, staged through the engine's scratch (synchronises)
+static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, const uint8_t *maskDev,
+                              int x0, int y0, int box_w, int box_h) {
   CHECK_E(main_engine);
-  if (!instance || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  if (!instance || (!mask && !maskDev) || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
   if (!main_engine->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (instance->device != main_engine->device || instance->W != main_engine->W || instance->H != main_engine->H ||
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
     return fail(DSR_E_ARG, "main and instance engines must share GPU and image size");
-  int st = upload_mask(main_engine, mask, box_w, box_h);
-  if (st) return st;
+  if (!maskDev) {
+    int st = upload_mask(main_engine, mask, box_w, box_h);
+    if (st) return st;
+    maskDev = main_engine->maskScratch;
+  }
   dsr_engine *e = main_engine;
   // runs on the MAIN engine's stream (ordered after the view's producer and before any later
   // blanking); the instance stream then waits for it.  The kernel OVERWRITES the instance's view,
@@ -1316,7 +1325,7 @@ int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, c
   HIP_TRY(hipStreamWaitEvent(e->stream, instance->xEvent, 0));
   LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
          (const uchar4 *)e->rgb, (const float *)e->depth, instance->rgb, instance->depth, e->W, e->H,
-         (const uint8_t *)e->maskScratch, x0, y0, box_w, box_h);
+         maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
   if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(e->xEvent2, e->stream));
@@ -1325,17 +1334,37 @@ int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, c
   return DSR_OK;
 }
 
-int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
+int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
+                                int box_w, int box_h) {
+  return extract_silhouette(main_engine, instance, mask, nullptr, x0, y0, box_w, box_h);
+}
+int dsr_view_extract_silhouette_dev(dsr_engine *main_engine, dsr_engine *instance, const void *mask_dev, int x0, int y0,
+                                    int box_w, int box_h) {
+  if (!mask_dev) return fail(DSR_E_ARG, "bad silhouette arguments");
+  return extract_silhouette(main_engine, instance, nullptr, (const uint8_t *)mask_dev, x0, y0, box_w, box_h);
+}
+
+static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *maskDev, int x0, int y0, int box_w, int box_h) {
   CHECK_E(e);
-  if (!mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  if ((!mask && !maskDev) || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
-  int st = upload_mask(e, mask, box_w, box_h);
-  if (st) return st;
+  if (!maskDev) {
+    int st = upload_mask(e, mask, box_w, box_h);
+    if (st) return st;
+    maskDev = e->maskScratch;
+  }
   LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
-         e->depth, e->W, e->H, (const uint8_t *)e->maskScratch, x0, y0, box_w, box_h);
+         e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
+}
+int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
+  return remove_silhouette(e, mask, nullptr, x0, y0, box_w, box_h);
+}
+int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, int y0, int box_w, int box_h) {
+  if (!mask_dev) return fail(DSR_E_ARG, "bad silhouette arguments");
+  return remove_silhouette(e, nullptr, (const uint8_t *)mask_dev, x0, y0, box_w, box_h);
 }
 
 // ---- instance compositing
@@ -1343,6 +1372,17 @@ int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y
 static const unsigned char kMatplotlib2Palette[10][3] = {  // InstanceReconstructor.cpp:44-55
     {0x1f, 0x77, 0xb4}, {0xff, 0x7f, 0x0e}, {0x2c, 0xa0, 0x2c}, {0xd6, 0x27, 0x28}, {0x94, 0x67, 0xbd},
     {0x8c, 0x56, 0x4b}, {0xe3, 0x77, 0xc2}, {0x71, 0x71, 0x71}, {0xbc, 0xbd, 0x22}, {0x17, 0xbe, 0xcf}};
+
+static CompositeP composite_params(const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength, int dim_background) {
+  CompositeP c;
+  memset(&c, 0, sizeof c);
+  c.nLayers = n_layers; c.nPixels = n_pixels; c.dimBackground = dim_background; c.tintStrength = tint_strength;
+  for (int l = 0; l < n_layers; ++l) {
+    const unsigned char *t = kMatplotlib2Palette[((track_ids[l] % 10) + 10) % 10];
+    c.tint[l] = make_uchar4(t[0], t[1], t[2], 255);
+  }
+  return c;
+}
 
 int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
                                 const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
@@ -1352,16 +1392,35 @@ int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_
     return fail(DSR_E_ARG, "null layer buffers");
   if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
   if (device >= 0) HIP_TRY(hipSetDevice(device));
-  CompositeP c;
-  memset(&c, 0, sizeof c);
-  c.nLayers = n_layers; c.nPixels = n_pixels; c.dimBackground = dim_background; c.tintStrength = tint_strength;
-  for (int l = 0; l < n_layers; ++l) {
-    const unsigned char *t = kMatplotlib2Palette[((track_ids[l] % 10) + 10) % 10];
-    c.tint[l] = make_uchar4(t[0], t[1], t[2], 255);
-  }
-  hipLaunchKernelGGL(k_composite, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
+  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  CompositeLayers none;
+  memset(&none, 0, sizeof none);
+  hipLaunchKernelGGL(k_composite<false>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
                      (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
-                     (const float *)layers_depth_dev);
+                     (const float *)layers_depth_dev, none);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                 const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
+                                 const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
+                                 int dim_background) {
+  if (!target_depth_dev || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
+  if (n_layers > 0 && (!layer_depth_ptrs || !track_ids || (target_rgba_dev && !layer_rgba_ptrs)))
+    return fail(DSR_E_ARG, "null layer buffers");
+  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
+  CompositeLayers lp;
+  memset(&lp, 0, sizeof lp);
+  for (int l = 0; l < n_layers; ++l) {
+    lp.depth[l] = (const float *)layer_depth_ptrs[l];
+    lp.rgba[l] = target_rgba_dev ? (const uchar4 *)layer_rgba_ptrs[l] : nullptr;
+    if (!lp.depth[l] || (target_rgba_dev && !lp.rgba[l])) return fail(DSR_E_ARG, "null layer buffers");
+  }
+  if (device >= 0) HIP_TRY(hipSetDevice(device));
+  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  hipLaunchKernelGGL(k_composite<true>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
+                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -1794,8 +1853,8 @@ int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
       k.bytes = V * (16.0 + 2.0 * B) + L * 8.0 * P;  // the reference's AoS formulation
       // what THIS layout has to move (DESIGN.md "byte model"): per visible block its list id (4 B), hash
       // entry (16 B) and the sdf + w_depth planes (1536 B) read; 24 B written back per lane that updated
-      // a voxel; per colour voxel 4 + 1 B read and written; the depth and RGB frames (8 B per pixel)
-      k.bytes_layout = V * (4.0 + 16.0 + 1536.0) + storeLanes * 24.0 + colourVoxels * 10.0 + L * 8.0 * P;
+      // a voxel; per colour voxel ONE 4-byte word (r, g, b, w_color) read and written; the depth and RGB frames (8 B per pixel)
+      k.bytes_layout = V * (4.0 + 16.0 + 1536.0) + storeLanes * 24.0 + colourVoxels * 8.0 + L * 8.0 * P;
       k.units = V;
     }
     else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;

@@ -18,9 +18,15 @@ struct CompositeP {
   float tintStrength;
   uchar4 tint[kMaxCompositeLayers];  // kMatplotlib2Palette[track_id % 10], resolved on the host
 };
+struct CompositeLayers {  // one (colour, depth) pointer pair per layer: the layers stay where the all-gather left them
+  const uchar4 *rgba[kMaxCompositeLayers];
+  const float *depth[kMaxCompositeLayers];
+};
 
+template <bool PTRS>
 __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
-                                                   const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth) {
+                                                   const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth,
+                                                   CompositeLayers lp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c.nPixels) return;
   float t = tDepth[i];
@@ -36,12 +42,12 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
   }
   const double colStrength = 1.0 + (double)0.50f - (double)c.tintStrength;
   for (int l = 0; l < c.nLayers; ++l) {
-    const float s = lDepth[(size_t)l * c.nPixels + i];
+    const float s = PTRS ? lp.depth[l][i] : lDepth[(size_t)l * c.nPixels + i];
     const bool onTop = (s != 0.0f) && (t == 0.0f || t > s);
     if (!onTop) continue;
     t = s;
     if (tRgba) {
-      const uchar4 sc = lRgba[(size_t)l * c.nPixels + i];
+      const uchar4 sc = PTRS ? lp.rgba[l][i] : lRgba[(size_t)l * c.nPixels + i];
       const uchar4 tint = c.tint[l];
       const double r = fmin(255.0, (double)sc.x * colStrength + (double)((float)tint.x * c.tintStrength));
       const double g = fmin(255.0, (double)sc.y * colStrength + (double)((float)tint.y * c.tintStrength));

@@ -72,11 +72,22 @@ __global__ __launch_bounds__(256) void k_remove_silhouette(uchar4 *__restrict__ 
   }
 }
 
+// Float views handed over by the host (dsr_set_view_float[_dev]) may hold +inf.  The reference's arithmetic treats
+// such a pixel like any depth far beyond the volume: computeUpdatedVoxelDepthInfo fuses MIN(1, eta / mu) = 1 and the
+// colour gate (eta > mu) rejects it.  The integrate kernel's division-by-reciprocal sequence would turn eta = inf
+// into a NaN quotient instead, so the view is stored with values above 1e30 replaced by 1e30 — every result is the one
+// the reference computes for +inf (eta >= 1e30 - z: quotient > 1, gate rejects; the allocation rejects the pixel
+// through depth + mu > viewFrustum_max either way).  NaN and -inf pass through (compare false / rejected by d <= 0).
+__global__ __launch_bounds__(256) void k_copy_depth_finite(const float *__restrict__ in, float *__restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float d = in[i]; out[i] = d > 1e30f ? 1e30f : d; }
+}
+
 // PrecomputedDepthProvider::ReadPrecomputed, the input_is_depth_ clamp for int16 maps
 // (PrecomputedDepthProvider.cpp:55-74): depth > max_depth_mm_s -> 0
-__global__ __launch_bounds__(256) void k_clip_depth_mm(const short *__restrict__ in, short *__restrict__ out, int n, short maxMm) {
+__global__ __launch_bounds__(256) void k_clip_depth_mm(short *__restrict__ depth, int n, short maxMm) {  // in place
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const short d = in[i]; out[i] = d > maxMm ? (short)0 : d; }
+  if (i < n) { const short d = depth[i]; if (d > maxMm) depth[i] = (short)0; }
 }
 
 }  // namespace dsr

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         dirtyDepth |= upd;
         // ---- ComputeUpdatedVoxelInfo<true>::compute gate: !(eta > mu || fabs(eta/mu) > 0.25); voxels the
         //      depth step rejected carry eta = -1.  q is the correctly rounded eta / mu and mu > 0, so
-        //      eta > mu implies q >= 1 > 0.25: the first comparison never decides (a NaN fails both)
+        //      eta > mu implies q >= 1 > 0.25: the first comparison never decides (a NaN fails both).  eta = +inf
+        //      (the one input whose quotient this division sequence gets wrong: NaN) cannot reach this point:
+        //      float views are stored with depths above 1e30 clamped to 1e30 (k_edges.h k_copy_depth_finite)
         const bool gateOk = !(fabsf(q) > 0.25f);
         const bool gate = REJ ? (!skip & (ok[x] ? gateOk : true)) : (okx & gateOk);
         // append to the wave's pending colour list (ordered compaction across the 64 lanes)

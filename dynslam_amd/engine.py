@@ -176,6 +176,14 @@ class EngineCore:
         self._check(self.api.view_extract_silhouette(self._h, instance._h, _ptr(mask), int(x0), int(y0),
                                                      mask.shape[1], mask.shape[0]))
 
+    def extract_silhouette_dev(self, instance, mask_dev_ptr, x0, y0, box_w, box_h):
+        """... with the mask already in HBM: no copy, no synchronisation (dsr_view_extract_silhouette_dev)."""
+        self._check(self.api.view_extract_silhouette_dev(self._h, instance._h, C.c_void_p(mask_dev_ptr), int(x0), int(y0),
+                                                         int(box_w), int(box_h)))
+
+    def remove_silhouette_dev(self, mask_dev_ptr, x0, y0, box_w, box_h):
+        self._check(self.api.view_remove_silhouette_dev(self._h, C.c_void_p(mask_dev_ptr), int(x0), int(y0), int(box_w), int(box_h)))
+
     def remove_silhouette(self, mask, x0, y0):
         """RemoveSilhouette (InstanceReconstructor.cpp:135-170)."""
         mask = np.ascontiguousarray(mask, dtype=np.uint8)

@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define DSR_ABI_VERSION 1
+/* bumped whenever a public struct layout or the meaning of a field changes, so that a library and a caller built on
+ * different sides of the change refuse each other at load (2: dsr_kernel_time grew bytes_layout/units, dsr_stats was
+ * extended, DSR_E_IO) */
+#define DSR_ABI_VERSION 2
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
 #define DSR_BLOCK_SIZE 8
@@ -211,6 +214,8 @@ int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m
  * is what InstanceReconstructor builds per instance
  * (InstanceReconstructor.cpp:238-263,580) and what it writes back into the main
  * view after masking (:196-197). */
+/* Depth values above 1e30 (+inf included) are stored as 1e30: every fusion result is the one the reference's
+ * arithmetic gives for them (sdf update with +1, no colour), and dsr_get_view returns 1e30 for such pixels. */
 int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m);
 int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m_dev);
 /* view->rgb / view->depth ->UpdateHostFromDevice()
@@ -322,6 +327,13 @@ int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, c
 /* RemoveSilhouette_CPU (InstanceReconstructor.cpp:135-170): pixels of the engine's view under
  * the mask become rgba 0 / depth 0.0f. */
 int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h);
+/* The same two steps with the mask ALREADY IN HBM (e.g. the segmentation network's output, or masks uploaded ahead
+ * of the frame): nothing is copied and nothing synchronises — the host variants above must wait for the stream before
+ * returning because the caller may reuse its pageable mask buffer.  The mask must stay unmodified until the engine's
+ * stream has passed the call (dsr_sync / dsr_stream_wait_for_engine). */
+int dsr_view_extract_silhouette_dev(dsr_engine *main_engine, dsr_engine *instance, const void *mask_dev, int x0, int y0,
+                                    int box_w, int box_h);
+int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, int y0, int box_w, int box_h);
 
 /* ---- instance compositing (the fused preview) ------------------------------------ */
 
@@ -342,6 +354,13 @@ int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_
                                 const void *layers_rgba_dev, const void *layers_depth_dev,
                                 const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
                                 int dim_background);
+/* ... with one pointer PER LAYER (host arrays of HBM pointers; layer_rgba_ptrs may be NULL for depth only): the layers
+ * are composited where the collective left them — any slot of the all-gathered exchange buffer, in track-id order —
+ * without first being copied into one contiguous array. */
+int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                 const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
+                                 const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
+                                 int dim_background);
 int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
                             const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
                             float tint_strength, int dim_background);

@@ -1553,6 +1553,7 @@ static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capa
   if (!element(node, "dt", t)) return fail(DSR_E_IO, "no dt");
   std::string dt; for (char c : t) if (!isspace((unsigned char)c)) dt += c;
   if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format."); /* out.type() != CV_16SC1 */
+  if ((long long)rows * cols > (1ll << 28) || rows > (1 << 20) || cols > (1 << 20)) return fail(DSR_E_IO, "depth-frame: implausible rows x cols");
   *width = cols; *height = rows;
   if (rows <= 0 || cols <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
   if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
@@ -1560,7 +1561,7 @@ static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capa
   std::istringstream data(t);
   long long i = 0, n = (long long)rows * cols;
   long v;
-  while (i < n && (data >> v)) depth_mm_out[i++] = (int16_t)v;
+  while (i < n && (data >> v)) depth_mm_out[i++] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));  /* cv::saturate_cast<short> */
   if (i != n) return fail(DSR_E_IO, "depth-frame <data> holds fewer values than rows x cols");
   return DSR_OK;
 }
@@ -1574,6 +1575,7 @@ static int read_pfm_impl(const char *path, float *out, int capacity, int *width,
   in >> magic >> w >> h >> scale;
   if (!in || magic != "Pf") return fail(DSR_E_IO, "not a single-channel PFM file");
   in.get();
+  if ((long long)w * h > (1ll << 28) || w > (1 << 20) || h > (1 << 20)) return fail(DSR_E_IO, "PFM: implausible width x height");
   *width = w; *height = h;
   if (w <= 0 || h <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map");
   if (!out || (long long)w * h > capacity) return fail(DSR_E_ARG, "PFM image larger than the buffer");
@@ -1725,6 +1727,26 @@ int orc_composite_instances(uint8_t *target_rgba, float *target_depth, const uin
     }
   }
   return DSR_OK;
+}
+/* test infrastructure: "device" pointers are host pointers here */
+int orc_view_extract_silhouette_dev(dsr_engine *m, dsr_engine *inst, const void *mask, int x0, int y0, int box_w, int box_h) {
+  return orc_view_extract_silhouette(m, inst, (const uint8_t *)mask, x0, y0, box_w, box_h);
+}
+int orc_view_remove_silhouette_dev(dsr_engine *h, const void *mask, int x0, int y0, int box_w, int box_h) {
+  return orc_view_remove_silhouette(h, (const uint8_t *)mask, x0, y0, box_w, box_h);
+}
+int orc_composite_layer_ptrs_dev(int, void *, void *target_rgba, void *target_depth, const void *const *layer_rgba_ptrs,
+                                 const void *const *layer_depth_ptrs, const int32_t *track_ids, int n_layers, int n_pixels,
+                                 float tint_strength, int dim_background) {
+  if (n_layers < 0 || n_pixels <= 0 || (n_layers > 0 && (!layer_depth_ptrs || (target_rgba && !layer_rgba_ptrs)))) return fail(DSR_E_ARG, "bad composite arguments");
+  std::vector<uint8_t> lr(target_rgba ? (size_t)n_layers * n_pixels * 4 : 0);
+  std::vector<float> ld((size_t)n_layers * n_pixels);
+  for (int l = 0; l < n_layers; ++l) {  /* gather the layers, then the restated loops below */
+    memcpy(ld.data() + (size_t)l * n_pixels, layer_depth_ptrs[l], (size_t)n_pixels * 4);
+    if (target_rgba) memcpy(lr.data() + (size_t)l * n_pixels * 4, layer_rgba_ptrs[l], (size_t)n_pixels * 4);
+  }
+  return orc_composite_instances((uint8_t *)target_rgba, (float *)target_depth, target_rgba ? lr.data() : nullptr, ld.data(), track_ids,
+                                 n_layers, n_pixels, tint_strength, dim_background);
 }
 int orc_composite_instances_dev(int, void *, void *target_rgba, void *target_depth, const void *layers_rgba,
                                 const void *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,

@@ -118,3 +118,49 @@ def test_configs3_bench_line_at_world_size_n(tmp_path, world):
     ts = line["time_sliced_1gpu"]
     assert ts and ts["composited_frames_per_s"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0
     assert line["roofline"] is None and line["cpu_baseline"] is None  # no HIP events on a CPU device; N = 1 item
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The REAL command line, as the driver starts it: `python bench.py --gpus N --steps K --warmup W` with no launcher around it.
+# bench.py must fork its N ranks itself and print ONE rank-0 line with n_gpus = N (`--gpus` used to be ignored).
+# The device layer is swapped for the CPU oracle over gloo through bench.py's test seam; everything else is the shipped file.
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_cli_gpus_n_spawns_its_own_ranks(n):
+    import subprocess
+    import sys
+    env = dict(os.environ, DSR_BENCH_TEST_BACKEND="tests.bench_backend_oracle", PYTHONPATH=ROOT, DSR_BENCH_NO_POOL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--width", "256", "--height", "80", "--preset", "5cm"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout  # ONE line for the whole job
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == n and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["unit"] == "volume-frames/s" and line["metric"].startswith("frames/sec TSDF integrate+raycast")
+    cfg = line["config"]
+    # the headline leg: N concurrent instance volumes, one per rank, no static map
+    assert cfg["workload"].startswith("north_star scaling workload") and cfg["has_static_map"] is False
+    assert cfg["volumes"] == n and cfg["volumes_per_rank"] == [1] * n and cfg["status"] == 0
+    assert abs(line["value"] - n * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-3
+    assert line["time_sliced_1gpu"]["value"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0
+    assert cfg["preview_hit_fraction"] > 0.001  # the composited preview holds the instances' pixels
+    # the second leg, nested: configs[3] with the static map on rank 0
+    c3 = line["configs3"]
+    assert c3["config"]["workload"].startswith("configs[3]") and c3["config"]["has_static_map"] is True
+    assert c3["config"]["volumes_per_rank"] == [1] * n and c3["value"] > 0 and c3["time_sliced_1gpu"]["value"] > 0
+    assert c3["config"]["static_visible_blocks_last_frame"] > 100
+
+
+def test_cli_rank_failure_does_not_hang():
+    """A rank that dies (here: the test backend module cannot be imported in the children) takes the job down with a
+    non-zero status instead of leaving the other ranks in a collective."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DSR_BENCH_TEST_BACKEND="tests.no_such_backend", PYTHONPATH=ROOT, DSR_BENCH_NO_POOL="1")
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--width", "96", "--height", "32", "--preset", "5cm"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "no_such_backend" in p.stderr

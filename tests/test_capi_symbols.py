@@ -32,6 +32,8 @@ def test_hip_library_exports_every_symbol():
     lib = C.CDLL(path)
     api = _capi.bind(lib, "dsr_")  # AttributeError if a symbol is missing
     assert api.abi_version() == _capi.ABI_VERSION
+    # ... and the header's: a struct-layout change must bump all three together
+    assert int(re.search(r"#define\s+DSR_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1)) == _capi.ABI_VERSION
     s = _capi.Settings()
     api.default_settings(C.byref(s))
     # upstream ITMLibSettings defaults

@@ -112,10 +112,9 @@ def test_preview_exchange_over_rccl(hip_api, oracle_lib):
         layers_c = rng.integers(0, 256, (3, P, 4)).astype(np.uint8)
         layers_d = rng.uniform(1, 9, (3, P)).astype(np.float32); layers_d[rng.random((3, P)) < 0.5] = 0
         ex.local_rgba.copy_(torch.from_numpy(layers_c)); ex.local_depth.copy_(torch.from_numpy(layers_d))
-        # force the collective path even for one rank
-        ex.world = 1
-        dist.all_gather_into_tensor(ex.all_depth, ex.local_depth)
-        dist.all_gather_into_tensor(ex.all_rgba.view(ex.slots, P * 4), ex.local_rgba.view(ex.slots, P * 4))
+        ex.gather()  # with a process group the collective runs for one rank too: ONE all_gather_into_tensor of the packed layers
+        torch.cuda.synchronize()
+        assert np.array_equal(ex.all_depth.cpu().numpy(), layers_d) and np.array_equal(ex.all_rgba.cpu().numpy(), layers_c)
         bg_c = rng.integers(0, 256, (P, 4)).astype(np.uint8); bg_d = rng.uniform(1, 9, P).astype(np.float32)
         t_c, t_d = torch.from_numpy(bg_c).to(dev), torch.from_numpy(bg_d).to(dev)
         ids = {0: 12, 1: 5, 2: 31}

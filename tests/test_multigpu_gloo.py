@@ -110,22 +110,23 @@ SH_INST = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_f
 SH_VIEW = dict(SH_STATIC, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
 
 
-def _sharded_run(world, rank, n_volumes, group=None):
+def _sharded_run(world, rank, n_volumes, group=None, has_static=True):
     from bench import _gen_frame
     from dynslam_amd.engine import make_calib
     from dynslam_amd.multigpu import ShardedScene
     from dynslam_amd.synth import StreetScene
     from oracle.oracle import OracleEngine, load_api, oracle_settings
-    sc = StreetScene(SH_W, SH_H, n_instances=n_volumes - 1)
+    n_inst = n_volumes - 1 if has_static else n_volumes
+    sc = StreetScene(SH_W, SH_H, n_instances=n_inst)
     calib = make_calib(*sc.intrinsics(), SH_W, SH_H)
     kinds = {"static": SH_STATIC, "instance": SH_INST, "view": SH_VIEW}
     scene = ShardedScene(lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib), SH_W, SH_H, n_volumes, world, rank,
-                         torch.device("cpu"), group)
+                         torch.device("cpu"), group, has_static=has_static)
     scene.exchange.host_api = load_api()  # CPU composite = the oracle's restatement (tests only)
-    track_ids = {k: 7 + 2 * k for k in range(n_volumes - 1)}
+    track_ids = {k: 7 + 2 * k for k in range(n_inst)}
     out = None
     for i in range(SH_FRAMES):
-        rgba, d, T, masks = _gen_frame((SH_W, SH_H, i, n_volumes - 1))
+        rgba, d, T, masks = _gen_frame((SH_W, SH_H, i, n_inst))
         scene.step(rgba, d, T, masks)
         M = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
         inst_m = {k: np.linalg.inv(rel.astype(np.float64)).astype(np.float32) for k, _, _, _, rel in masks}
@@ -137,11 +138,11 @@ def _sharded_run(world, rank, n_volumes, group=None):
     return res
 
 
-def _sharded_worker(rank, world, port, n_volumes, out_dir):
+def _sharded_worker(rank, world, port, n_volumes, out_dir, has_static=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = _sharded_run(world, rank, n_volumes)
+    res = _sharded_run(world, rank, n_volumes, has_static=has_static)
     if rank == 0:
         np.savez(os.path.join(out_dir, "sharded.npz"), rgba=res[0], depth=res[1], layers=res[2])
     dist.barrier()
@@ -159,3 +160,20 @@ def test_sharded_scene_equals_single_process(tmp_path, oracle_lib, world, n_volu
     assert sum(int((got["layers"][l] > 0).any()) for l in range(got["layers"].shape[0])) >= min(n_volumes - 2, 4)
     assert np.array_equal(got["depth"], depth1)
     assert np.array_equal(got["rgba"], rgba1)
+
+
+@pytest.mark.parametrize("world,n_volumes", [(2, 2), (3, 4), (8, 8)])  # (8, 8): north_star's "8 concurrent instance volumes"
+def test_instance_volumes_sharded_equals_single_process(tmp_path, oracle_lib, world, n_volumes):
+    """The scaling workload of `bench.py --gpus N`: N instance volumes and NO static map, instance k on rank k mod world,
+    composited over an empty frame — same preview as all volumes in one process, bit for bit."""
+    mp.spawn(_sharded_worker, args=(world, _free_port(), n_volumes, str(tmp_path), False), nprocs=world, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    rgba1, depth1, layers1 = _sharded_run(1, 0, n_volumes, has_static=False)
+    assert (depth1 > 0).any() and (depth1 == 0).any()  # instances over an EMPTY frame: most pixels stay empty
+    assert sum(int((got["layers"][l] > 0).any()) for l in range(got["layers"].shape[0])) >= min(n_volumes, 4) - 1
+    assert np.array_equal(got["depth"], depth1)
+    assert np.array_equal(got["rgba"], rgba1)
+    # where a layer hit, the composite holds the nearest hit of all layers
+    hit = layers1 > 0
+    nearest = np.where(hit, layers1, np.inf).min(axis=0)
+    assert np.array_equal(np.where(np.isfinite(nearest), nearest, 0.0).astype(np.float32), depth1)

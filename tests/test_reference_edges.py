@@ -29,7 +29,12 @@ def ref():
     if HAVE_REF_SRC:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref"], stdout=subprocess.DEVNULL)
     if not os.path.exists(REF_LIB):
-        pytest.skip("oracle/_ref/libref_edges.so is not built and /root/reference is not on this machine")
+        msg = ("oracle/_ref/libref_edges.so is missing: __graft_entry__.build() makes it where /root/reference exists "
+               "and it travels to the GPU box with the snapshot")
+        import torch
+        if torch.cuda.is_available():  # on a GPU box these are the only tests pinned by the reference's own code
+            pytest.fail(msg)
+        pytest.skip(msg)
     from dynslam_amd import _capi
     _capi.preload_hip_runtime()
     return C.CDLL(REF_LIB)
@@ -235,6 +240,5 @@ def test_oracle_edges_equal_reference_code_on_special_values(oracle_lib, ref):
 
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after round 2's GPU minutes were spent: first GPU run pending (remove this marker once it has passed)")
 def test_hip_edges_equal_reference_code_on_special_values(hip_api, ref):
     check_special_values(hip_api, ref, 20)

@@ -224,11 +224,11 @@ def test_reference_evaluation_scores_the_engine_renders_against_lidar(oracle_hos
 # --- GPU ---------------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
-@pytest.mark.xfail(strict=False, reason="written after round 2's GPU minutes were spent: first GPU run pending (remove this marker once it has passed)")
 def test_reference_pipeline_on_the_hip_engine_matches_the_oracle(tmp_path):
     hip, orc = os.path.join(BUILD, "ref_dynslam_host"), os.path.join(BUILD, "ref_dynslam_host_orc")
     if not (os.path.exists(hip) and os.path.exists(orc)):
-        pytest.skip("prebuilt hosts missing: run __graft_entry__.build() where /root/reference exists")
+        pytest.fail("tests/refhost/_build/ref_dynslam_host{,_orc} are missing: __graft_entry__.build() makes them where "
+                    "/root/reference exists and they travel to the GPU box with the snapshot")
     from tests.refhost.make_dataset import write_dataset
     root = str(tmp_path / "kitti_like")
     os.makedirs(root)
