@@ -35,7 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_GUIDE_COPY_GBS = 6290.0  # ... and the 6.29 TB/s its float4 copy kernel measures (79 %)
 
 PRESETS = {
     # BASELINE.json "5mm voxels": upstream InfiniTAM indoor ratio mu = 4 * voxel
@@ -78,22 +79,28 @@ def make_frames(w, h, n, n_inst=0):
 
 
 def pmc_traffic(args, kernel, visible_blocks_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, separate passes, MI355X_MICROARCH.md corrections; summarised by the round's
-    profiling run into profiles/).  PMC counters cannot be collected from inside this process.
-    k_integrate's traffic is proportional to the visible blocks it walks, so the profile stores
-    bytes PER VISIBLE BLOCK (measured over the profiled launches) and the figure reported here is
-    that x this run's visible blocks per launch — valid for any --steps / --warmup of the same
-    workload (preset, image size, static map only).  Returns (bytes per launch, source file)."""
-    if args.width != 1242 or args.height != 375 or args.decay or args.swap or args.instances or getattr(args, "volumes", 0) > 1:
+    """HBM bytes per launch of `kernel` (k_integrate / k_raycast of the static map) from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md corrections; summarised by the round's profiling run into
+    profiles/).  PMC counters cannot be collected from inside this process.  The traffic of both kernels is proportional to the
+    visible blocks they walk, so the profile's bytes PER VISIBLE BLOCK (measured over the profiled launches of the configs[1]
+    workload) x this run's visible blocks per launch is reported — valid for any --steps / --warmup, and for the static map of
+    the --instances / --volumes / --decay workloads (same preset, image size, kernel and kind of data; the line says so in
+    `traffic_source`).  Other presets / image sizes / --swap have no committed set: (None, None), not a wrong number."""
+    if args.width != 1242 or args.height != 375 or args.swap:
         return None, None
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench{args.preset}_pmc_traffic.json")))
     for f in reversed(files):  # newest set that has the per-block figure
         try:
-            k = json.load(open(f))["kernels"].get(kernel)
-            if k and k.get("hbm_bytes_per_visible_block"):
-                return round(k["hbm_bytes_per_visible_block"] * visible_blocks_per_launch, 0), os.path.relpath(f, ROOT)
+            ks = json.load(open(f))["kernels"]
+            per_block = ks["k_integrate"].get("hbm_bytes_per_visible_block")
+            if kernel != "k_integrate" and per_block:
+                per_block = ks[kernel]["hbm_bytes"] / ks["k_integrate"]["visible_blocks_per_launch"]
+            if per_block:
+                src = os.path.relpath(f, ROOT)
+                if args.decay or args.instances or getattr(args, "volumes", 0) > 1:
+                    src += " (per-visible-block figure of the configs[1] static map)"
+                return round(per_block * visible_blocks_per_launch, 0), src
         except Exception:
             continue
     return None, None
@@ -190,6 +197,10 @@ def roofline_from_profile(prof, args, copy_gbs):
                         "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
                         "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                         "traffic_source": traffic_src,
+                        # the same bytes against what a copy kernel reaches: the guide's figure and this library's own probe
+                        # on THIS box (best of 3 grids x plain / non-temporal, dsr_measure_copy_bandwidth)
+                        "guide_copy_GBps": HBM_GUIDE_COPY_GBS, "frac_of_guide_copy": round(achieved / HBM_GUIDE_COPY_GBS, 4),
+                        "traffic_frac_of_guide_copy": round(traffic / avg_s / 1e9 / HBM_GUIDE_COPY_GBS, 4) if traffic else None,
                         "measured_copy_GBps": copy_gbs,
                         "frac_of_measured_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
                         "avg_launch_us": round(1e6 * avg_s, 2),
@@ -202,7 +213,40 @@ def roofline_from_profile(prof, args, copy_gbs):
                                 "+ 16 B hash entry + 1536 B sdf and w_depth planes read, 24 B written per lane that updated a "
                                 "voxel, 8 B per colour voxel (one word read + written), 8 B per pixel of the frames (tallied by the kernel itself); "
                                 "traffic = rocprofv3 PMC bytes per visible block (profiles/) x this run's visible blocks"}
+    ray = next((r for r in prof if r["name"] == "raycast" and r["total_ms"] > 0), None)
+    if roofline and ray:
+        # second kernel of the frame: compulsory bytes of THIS layout = per visible block its hash entry
+        # (16 B) + its sdf plane (1024 B: the raycast never touches weights or colour) + 16 B per pixel written + the range
+        # image; R (blocks some ray really enters) <= V, so this is an upper bound of the compulsory traffic
+        avg_s = ray["total_ms"] * 1e-3 / ray["launches"]
+        V = roofline["visible_blocks_per_launch"]
+        P = args.width * args.height
+        comp = V * (16.0 + 1024.0) + 16.0 * P + 8.0 * ((args.width + 7) // 8) * ((args.height + 7) // 8)
+        traffic, src = pmc_traffic(args, "k_raycast", V)
+        roofline["raycast"] = {"bound": "hbm", "kernel": "k_raycast", "achieved": round(comp / avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": round(comp / avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                               "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
+                               "traffic_frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                               "traffic_source": src, "avg_launch_us": round(1e6 * avg_s, 2), "bytes_per_launch": round(comp, 0),
+                               "note": "compulsory = V*(16 + 1024) + 16*P + range image; the kernel is bound by its per-wave chain of "
+                                       "dependent gathers (latency), not by bandwidth: DESIGN.md"}
+        kernels["raycast"]["GBps"] = roofline["raycast"]["achieved"]
     return roofline, kernels
+
+
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the driver reads stdout for ONE JSON line.
+    File-descriptor level (the banner comes from C code): fd 1 points at stderr inside the block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
 
 
 def _free_port():
@@ -320,10 +364,12 @@ def main_volumes(args, legs):
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if tb is None:
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(tb.DIST_BACKEND)
+        with _stdout_to_stderr():
+            if tb is None:
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(tb.DIST_BACKEND)
+            dist.barrier()  # the first collective creates the communicator (and prints RCCL's banner)
 
     from dynslam_amd.engine import make_calib
     from dynslam_amd.synth import StreetScene
@@ -555,7 +601,9 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)

@@ -178,6 +178,22 @@ __device__ __forceinline__ dsr_hash_entry load_entry(const dsr_hash_entry *table
   return e;
 }
 
+// ---- the visible-block STREAM ------------------------------------------------------------------------------------
+// The kernels that walk a visible list (integrate, expected depths, next frame's frustum re-test) used to follow every
+// list id into the hash table: ~610 k scattered 16-byte reads per kernel, each costing a 64-128 B line (62 + 58 + 40 MB
+// fetched for 10 MB of entries, profiles/r02f).  k_visible_write — which walks the table in ascending order anyway — now
+// also writes one 16-byte record per visible entry, in list order: the entry's pos and ptr with the ENTRY INDEX in the
+// slot of `offset` (no consumer of the list needs the chain link).  The consumers read this stream coalesced; the table
+// is gathered once per frame instead of three times.  Kept consistent by every kernel that rewrites a visible list
+// (k_visible_write, k_flag_write, the post-decay compaction k_live_keep_write).
+__device__ __forceinline__ int4 make_vis_record(int4 rawEntry, int entryIdx) { return make_int4(rawEntry.x, rawEntry.y, entryIdx, rawEntry.w); }
+__device__ __forceinline__ dsr_hash_entry entry_of_record(int4 r) {  // .offset holds the entry index
+  dsr_hash_entry e;
+  e.pos[0] = (short)(r.x & 0xffff); e.pos[1] = (short)((uint32_t)r.x >> 16); e.pos[2] = (short)(r.y & 0xffff);
+  e._pad = 0; e.offset = r.z; e.ptr = r.w;
+  return e;
+}
+
 // ------------------------------------------------------- workgroup-ordered scans
 
 // Exclusive scan of an int2 over a workgroup of NT threads (NT multiple of 64).

@@ -103,6 +103,8 @@ bool m4_inv(const Mat4 &in, Mat4 &out) {
 struct RenderStateDev {  // ITMRenderState_VH
   int32_t *visibleIDs = nullptr;
   int32_t *visibleIDsAlt = nullptr;  // ping-pong target of the post-decay compaction (live only)
+  int4 *visBlocks = nullptr;         // the visible-block stream: one 16-byte record per list entry (dsr_device.h)
+  int4 *visBlocksAlt = nullptr;
   uint8_t *visType = nullptr;
   float2 *minmax = nullptr;
   float4 *raycastResult = nullptr;
@@ -130,6 +132,11 @@ struct dsr_engine {
   // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
+  // a volume of instance size (7142 blocks in the reference, InstanceReconstructor.cpp:379): its frames are bound by the number
+  // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
+  // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
+  bool smallVolume = false;
+  bool expectedFilter = false;  // k_expected_depth_lds<FILTER> (env DSR_EXPECTED_FILTER)
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
@@ -311,7 +318,7 @@ void free_all(dsr_engine *e) {
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
   F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
-    F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
+    F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
   F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
@@ -398,7 +405,7 @@ int allocate_scene(dsr_engine *e) {
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
   LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
-         (const int32_t *)rs.visibleIDs, rs.visType);
+         (const int4 *)rs.visBlocks, rs.visType);
   LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
          (const float *)e->depth, rs.visType);
   int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
@@ -411,7 +418,7 @@ int allocate_scene(dsr_engine *e) {
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
          (int)SCAN_VISIBLE_LIVE, e->noBlocks);
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
-         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping);
+         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -423,7 +430,7 @@ int integrate_scene(dsr_engine *e) {
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
   LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
-         (const float *)e->depth, (const uchar4 *)e->rgb, (const int32_t *)e->live.visibleIDs, e->integrateStats)
+         (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats)
 #define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
   do {                                                                                                       \
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
@@ -438,16 +445,28 @@ int integrate_scene(dsr_engine *e) {
 
 int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
+  if (e->smallVolume && (size_t)mw * mh * sizeof(int2) <= 64 * 1024) {
+    // an instance-sized volume: one workgroup, one launch (k_raycast.h k_expected_depth_one)
+    ProfScope _ps(e, "expected_depth");
+    hipLaunchKernelGGL(k_expected_depth_one, dim3(1), dim3(1024), (size_t)mw * mh * sizeof(int2), e->stream, p, e->scene,
+                       (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax),
+                       rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? 1 : 0);
+    return DSR_OK;
+  }
   LAUNCH(e, "minmax_init", k_minmax_init, dim3(div_up(mw * mh, 256)), dim3(256), rs.minmax, mw * mh,
          (const int32_t *)e->scene.ctr, rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? (int)CTR_NO_VISIBLE_LIVE : -1);
   const size_t ldsBytes = (size_t)mw * mh * sizeof(int2);
   if (ldsBytes <= 64 * 1024) {
     // range image privatised in LDS by a few large workgroups (k_raycast.h)
     ProfScope _ps(e, "expected_depth");
-    hipLaunchKernelGGL(k_expected_depth_lds, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
-                       (const int32_t *)rs.visibleIDs, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+    if (e->expectedFilter)
+      hipLaunchKernelGGL(k_expected_depth_lds<true>, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
+                         (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+    else
+      hipLaunchKernelGGL(k_expected_depth_lds<false>, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
+                         (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
   } else {
-    LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int32_t *)rs.visibleIDs,
+    LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int4 *)rs.visBlocks,
            rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
   }
   return DSR_OK;
@@ -562,6 +581,16 @@ int swap_out(dsr_engine *e) {
 
 }  // namespace
 
+// ---- HBM ceiling probe kernel (dsr_measure_copy_bandwidth)
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void k_copy16(const copy_v4f *__restrict__ in, copy_v4f *__restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);  // streaming: no reuse to keep in L2
+    else out[i] = in[i];
+  }
+}
+
 // per-pixel conversion kernels of the boundary (k_edges.h): device-resident and host-buffer drivers
 template <class K, class TI, class TO>
 int convert_dev(K kernel, int device, void *hip_stream, const void *in, void *out, int n) {
@@ -664,6 +693,9 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e->maxSteps = (uint32_t)S;
   }
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
+  if (const char *ef = getenv("DSR_EXPECTED_FILTER")) e->expectedFilter = atoi(ef) != 0;
+  e->smallVolume = s.sdf_local_block_num <= 16384;
+  if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
@@ -689,12 +721,14 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     ALLOC(dmalloc(&rs->visibleIDs, (size_t)e->noBlocks));
+    ALLOC(dmalloc(&rs->visBlocks, (size_t)e->noBlocks));
     ALLOC(dmalloc(&rs->visType, (size_t)e->E));
     ALLOC(dmalloc(&rs->minmax, (size_t)mw * mh));
     ALLOC(dmalloc(&rs->raycastResult, (size_t)e->P));
     ALLOC(dmalloc(&rs->raycastImage, (size_t)e->P));
   }
   ALLOC(dmalloc(&e->live.visibleIDsAlt, (size_t)e->noBlocks));
+  ALLOC(dmalloc(&e->live.visBlocksAlt, (size_t)e->noBlocks));
   e->live.ctrIdx = CTR_NO_VISIBLE_LIVE; e->freeview.ctrIdx = CTR_NO_VISIBLE_FREE;
   ALLOC(dmalloc(&e->tileSums, (size_t)e->numTilesMax + 1));
   ALLOC(dmalloc(&e->integrateStats, (size_t)e->gridIntegrate * kIntegrateWaves));
@@ -1004,8 +1038,10 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene,
          (int)SCAN_COMPACT_LIVE, e->noBlocks);
   LAUNCH(e, "decay_compact", k_live_keep_write, dim3(e->numTilesB), dim3(kTileThreads), (const int32_t *)rs.visibleIDs,
-         (const int32_t *)e->scene.ctr, (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDsAlt);
+         (const int32_t *)e->scene.ctr, (const uint8_t *)rs.visType, (const int2 *)e->tileSums, rs.visibleIDsAlt,
+         (const int4 *)rs.visBlocks, rs.visBlocksAlt);
   std::swap(rs.visibleIDs, rs.visibleIDsAlt);
+  std::swap(rs.visBlocks, rs.visBlocksAlt);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -1039,7 +1075,21 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
       const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
                           memcmp(e->fvProj, proj, sizeof proj) == 0 && !getenv("DSR_NO_FREEVIEW_CACHE");
-      if (!cached) {
+      if (!cached && e->smallVolume) {
+        // FindVisibleBlocks by ONE sweep over the table (frustum test inside) + ordered compaction: 3 launches where the
+        // cached list of allocated entries below takes 7 — that list pays when a large, unchanged map is rendered from
+        // several cameras; an instance volume changes every frame and its table sweep is a few microseconds
+        LAUNCH(e, "freeview_visible", (k_visible_count<true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
+               e->tileSums);
+        LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+               (int)SCAN_VISIBLE_FREE, e->noBlocks);
+        LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
+               (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0, rs.visBlocks);
+        int st = expected_depths(e, rs, p);
+        if (st) return st;
+        launch_raycast(e, "raycast_freeview", p, rs);
+        e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+      } else if (!cached) {
       // FindVisibleBlocks: the allocated entries (ascending list, rebuilt when the scene has changed)
       // are tested densely against the free camera's frustum, the visible ones compacted in order
       if (e->allocListVersion != e->sceneVersion) {
@@ -1058,14 +1108,21 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesB, e->scene,
              (int)SCAN_VISIBLE_FREE, e->noBlocks);
       LAUNCH(e, "freeview_visible", k_flag_write, dim3(e->numTilesB), dim3(kTileThreads), (const int32_t *)e->allocList,
-             (const uint8_t *)e->decayFlags, nAlloc, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks);
+             (const uint8_t *)e->decayFlags, nAlloc, (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks,
+             (const dsr_hash_entry *)e->scene.table, rs.visBlocks);
       int st = expected_depths(e, rs, p);
       if (st) return st;
       launch_raycast(e, "raycast_freeview", p, rs);
       e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
       }
+      if (outIsDevice) {  // the shading writes the caller's HBM buffers itself: no copy launches behind it
+        LAUNCH(e, "render", k_render, g, dim3(256), p, e->scene, type, (const float4 *)rs.raycastResult, rs.raycastImage,
+               (float *)depth_out, (uchar4 *)rgba_out);
+        HIP_TRY(hipGetLastError());
+        break;
+      }
       LAUNCH(e, "render", k_render, g, dim3(256), p, e->scene, type, (const float4 *)rs.raycastResult, rs.raycastImage,
-             depth_out ? e->freeDepth : (float *)nullptr);
+             depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
       HIP_TRY(hipGetLastError());
       if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
       if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
@@ -1664,10 +1721,6 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
 
 // ---- HBM ceiling probe (roofline harness)
 
-__global__ __launch_bounds__(256) void k_copy16(const float4 *__restrict__ in, float4 *__restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
-}
-
 int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gbps_out) {
   if (!gbps_out || bytes < 16 || iters <= 0) return fail(DSR_E_ARG, "bad bandwidth probe arguments");
   if (device >= 0) HIP_TRY(hipSetDevice(device));
@@ -1679,16 +1732,29 @@ int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gb
   if (err == hipSuccess) err = hipMemset(b, 2, bytes);
   if (err == hipSuccess) err = hipEventCreate(&e0);
   if (err == hipSuccess) err = hipEventCreate(&e1);
+  // The ceiling a copy kernel reaches depends on its launch shape (4.57 TB/s with one fixed shape where the
+  // guide's float4 copy reaches 6.29): three grids x plain / non-temporal accesses, `iters` passes each, the BEST is reported.
   float ms = 0.0f;
   if (err == hipSuccess) {
     const size_t n = bytes / 16;
-    const int grid = 256 * 16;  // 16 workgroups per CU, 16 B per lane: the guide's copy kernel
-    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const float4 *)a, b, n);
-    (void)hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, 0, (const float4 *)a, b, n);
-    (void)hipEventRecord(e1, 0);
-    err = hipEventSynchronize(e1);
-    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    float best = 0.0f;
+    for (int variant = 0; variant < 6 && err == hipSuccess; ++variant) {
+      const int grid = 256 * (variant % 3 == 0 ? 4 : variant % 3 == 1 ? 8 : 16);  // 4 / 8 / 16 workgroups per CU, grid-stride
+      const bool nt = variant >= 3;
+      auto launch = [&]() {
+        if (nt) hipLaunchKernelGGL((k_copy16<true>), dim3(grid), dim3(256), 0, 0, (const copy_v4f *)a, (copy_v4f *)b, n);
+        else hipLaunchKernelGGL((k_copy16<false>), dim3(grid), dim3(256), 0, 0, (const copy_v4f *)a, (copy_v4f *)b, n);
+      };
+      launch();
+      (void)hipEventRecord(e0, 0);
+      for (int i = 0; i < iters; ++i) launch();
+      (void)hipEventRecord(e1, 0);
+      err = hipEventSynchronize(e1);
+      float t = 0.0f;
+      if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
+      if (err == hipSuccess && t > 0.0f && (best == 0.0f || t < best)) best = t;
+    }
+    ms = best;
   }
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);

@@ -409,12 +409,12 @@ __device__ __forceinline__ void check_block_visibility(bool &isVisible, bool &is
 // the mark: visible -> 3, otherwise 0.  The mark then overwrites the entries it sees with 1/2
 // exactly as in the serial order, so every entry ends with the same type — and the 10-million-entry
 // sweep no longer carries a divergent 8-corner test in 6 % of its lanes (55 -> ~15 us).
-__global__ __launch_bounds__(256) void k_retest_previous_visible(FrameP p, SceneP s, const int32_t *__restrict__ visibleIDs,
+__global__ __launch_bounds__(256) void k_retest_previous_visible(FrameP p, SceneP s, const int4 *__restrict__ visBlocks,
                                                                  uint8_t *__restrict__ visType) {
   const int n = s.ctr[CTR_NO_VISIBLE_LIVE];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int t = visibleIDs[i];
-    const dsr_hash_entry he = load_entry(s.table, t);
+    const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the stream: coalesced, no table gather (pos never changes)
+    const int t = he.offset;
     bool isVisible, isVisibleEnlarged;
     if (p.useSwapping) {
       check_block_visibility<true>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP
 __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntries, const uint8_t *__restrict__ visType,
                                                                 const int2 *__restrict__ tileOffsets,
                                                                 int32_t *__restrict__ visibleIDs, int capacity,
-                                                                SceneP s, int useSwapping) {
+                                                                SceneP s, int useSwapping, int4 *__restrict__ visBlocks) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
   uint8_t v[kTileItems];
@@ -495,6 +495,14 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntri
       if (useSwapping && s.table[base + j].ptr == -1) { re[j] = true; c.y++; }
     }
   }
+  // the table entries of this thread's visible items (the visible-block stream, dsr_device.h): all requested before the
+  // scan, so that the gathers overlap it and each other instead of forming a chain of up to 8 load -> store pairs
+  int4 rawE[kTileItems];
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    rawE[j] = make_int4(0, 0, 0, -2);
+    if (v[j] > 0) rawE[j] = *reinterpret_cast<const int4 *>(s.table + (base + j));
+  }
   int2 total;
   int2 ex = wg_exclusive_scan2<kTileThreads>(c, total, lds);
   if (total.x == 0) return;
@@ -504,13 +512,14 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntri
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
     if (v[j] > 0) {
-      if (rank < capacity) visibleIDs[rank] = base + j;
-      rank++;
+      int4 raw = rawE[j];
       if (re[j]) {
         const int vbaIdx = oldHead - rrank;
         rrank++;
-        if (vbaIdx >= 0) s.table[base + j].ptr = s.voxelAllocList[vbaIdx];
+        if (vbaIdx >= 0) { raw.w = s.voxelAllocList[vbaIdx]; s.table[base + j].ptr = raw.w; }
       }
+      if (rank < capacity) { visibleIDs[rank] = base + j; visBlocks[rank] = make_vis_record(raw, base + j); }
+      rank++;
     }
 }
 

@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void k_freeview_test(FrameP p, SceneP s, const
 __global__ __launch_bounds__(kTileThreads) void k_flag_write(const int32_t *__restrict__ list, const uint8_t *__restrict__ flags,
                                                              const int32_t *__restrict__ nPtr,
                                                              const int2 *__restrict__ tileOffsets,
-                                                             int32_t *__restrict__ out, int capacity) {
+                                                             int32_t *__restrict__ out, int capacity,
+                                                             const dsr_hash_entry *__restrict__ table, int4 *__restrict__ outBlocks) {
   __shared__ int2 lds[kTileThreads / 64];
   const int n = *nPtr;
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
@@ -285,7 +286,14 @@ __global__ __launch_bounds__(kTileThreads) void k_flag_write(const int32_t *__re
   int rank = tileOffsets[blockIdx.x].x + ex.x;
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
-    if (f[j]) { if (rank < capacity) out[rank] = list[base + j]; rank++; }
+    if (f[j]) {
+      if (rank < capacity) {
+        const int t = list[base + j];
+        out[rank] = t;
+        outBlocks[rank] = make_vis_record(*reinterpret_cast<const int4 *>(table + t), t);  // the visible-block stream (dsr_device.h)
+      }
+      rank++;
+    }
 }
 
 // live visible list compaction after decay: keep ids whose visType is still != 0
@@ -308,7 +316,8 @@ __global__ __launch_bounds__(kTileThreads) void k_live_keep_write(const int32_t 
                                                                   const int32_t *__restrict__ ctr,
                                                                   const uint8_t *__restrict__ visType,
                                                                   const int2 *__restrict__ tileOffsets,
-                                                                  int32_t *__restrict__ out) {
+                                                                  int32_t *__restrict__ out, const int4 *__restrict__ inBlocks,
+                                                                  int4 *__restrict__ outBlocks) {
   __shared__ int2 lds[kTileThreads / 64];
   const int nOld = ctr[CTR_TMP_OLD_NVIS];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(kTileThreads) void k_live_keep_write(const int32_t 
   int rank = tileOffsets[blockIdx.x].x + ex.x;
 #pragma unroll
   for (int j = 0; j < kTileItems; ++j)
-    if (keep[j]) out[rank++] = id[j];
+    if (keep[j]) { out[rank] = id[j]; outBlocks[rank] = inBlocks[base + j]; rank++; }  // kept entries: pos and ptr unchanged
 }
 
 }  // namespace dsr

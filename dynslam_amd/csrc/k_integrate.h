@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
-                                                                         const int32_t *__restrict__ visibleIDs,
+                                                                         const int4 *__restrict__ visBlocks,
                                                                          uint2 *__restrict__ waveStats) {
   constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
   constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       const uint32_t w = pend[base + lane];
       const int vox = (int)(w & 511u);
       const int tt = t0 + (int)(w >> 9) * stride;
-      const dsr_hash_entry hc = load_entry(s.table, (uint32_t)visibleIDs[tt / kTasksPerBlock]);
+      const dsr_hash_entry hc = entry_of_record(visBlocks[tt / kTasksPerBlock]);
       const uint32_t bptr = (uint32_t)hc.ptr;
       const int bx = hc.pos[0], by = hc.pos[1], bz = hc.pos[2];
       const float mx = (float)(bx * kBlockSize + (vox & 7)) * p.voxelSize;
@@ -209,9 +209,9 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
   // task t = (visible block t / kTasksPerBlock, half t % kTasksPerBlock); a lane owns the VOX
   // consecutive voxels starting at vox0 (linear index x + 8y + 64z inside the block)
-  auto task_entry = [&](int tt) -> dsr_hash_entry {
-    return load_entry(s.table, __builtin_amdgcn_readfirstlane(visibleIDs[tt / kTasksPerBlock]));
-  };
+  // the block's record of the visible-block stream (dsr_device.h): ONE load where the id -> table entry chain took two
+  // dependent ones, and consecutive tasks read consecutive 16-byte records instead of scattered table lines
+  auto task_entry = [&](int tt) -> dsr_hash_entry { return entry_of_record(visBlocks[tt / kTasksPerBlock]); };
   auto task_vox0 = [&](int tt) -> int { return VOX * lane + kVoxPerTask * (tt % kTasksPerBlock); };
 
   // software pipeline over this wave's tasks: entries two ahead, voxel planes one ahead

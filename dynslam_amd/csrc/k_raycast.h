@@ -269,7 +269,7 @@ __device__ __forceinline__ bool project_single_block(const short pos[3], const F
 // One thread per visible block: project, then min/max into the range image.  All values are
 // positive floats, so integer atomicMin/atomicMax on the bit patterns order them correctly and
 // the result is independent of the order of arrival.
-__global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, const int32_t *__restrict__ visibleIDs,
+__global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, const int4 *__restrict__ visBlocks,
                                                         int ctrIdx, int2 *__restrict__ minmax) {
   const int n = s.ctr[ctrIdx];
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, cons
     int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
     float2 zr = make_float2(0.f, 0.f);
     if (i < n) {
-      dsr_hash_entry he = load_entry(s.table, visibleIDs[i]);
+      const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the visible-block stream: 16 B per lane, coalesced
       if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
@@ -320,7 +320,9 @@ __global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, cons
 // image in LDS, folds its share of the visible blocks into it with ds_min/ds_max (no global
 // same-address atomic traffic at all during the fold), then flushes the cells it touched with
 // filtered global atomics.  min/max are order independent, so the image is identical.
-__global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s, const int32_t *__restrict__ visibleIDs,
+// FILTER: read the cell first and skip the LDS atomic when it cannot change it (k_expected_depth_one below explains)
+template <bool FILTER>
+__global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s, const int4 *__restrict__ visBlocks,
                                                              int ctrIdx, int2 *__restrict__ minmax) {
   extern __shared__ int2 cellsLds[];
   const int n = s.ctr[ctrIdx];
@@ -339,29 +341,32 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
     int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
     float2 zr = make_float2(0.f, 0.f);
     if (i < n) {
-      dsr_hash_entry he = load_entry(s.table, visibleIDs[i]);
+      const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the visible-block stream: 16 B per lane, coalesced
       if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
     const bool big = valid && bw * bh > 16;
+    auto fold = [&](int idx, int zmn, int zmx) {
+      if (FILTER) {
+        const int2 cur = cellsLds[idx];
+        if (zmn < cur.x) atomicMin(&cellsLds[idx].x, zmn);
+        if (zmx > cur.y) atomicMax(&cellsLds[idx].y, zmx);
+      } else {
+        atomicMin(&cellsLds[idx].x, zmn);
+        atomicMax(&cellsLds[idx].y, zmx);
+      }
+    };
     if (valid && !big)
       for (int y = ul.y; y <= lr.y; ++y)
-        for (int x = ul.x; x <= lr.x; ++x) {
-          atomicMin(&cellsLds[x + y * mw].x, zmin);
-          atomicMax(&cellsLds[x + y * mw].y, zmax);
-        }
+        for (int x = ul.x; x <= lr.x; ++x) fold(x + y * mw, zmin, zmax);
     unsigned long long m = __ballot(big);
     while (m) {
       const int src = __ffsll((long long)m) - 1;
       m &= m - 1;
       const int x0 = __shfl(ul.x, src), y0 = __shfl(ul.y, src), w = __shfl(bw, src), cells = w * __shfl(bh, src);
       const int zmn = __shfl(zmin, src), zmx = __shfl(zmax, src);
-      for (int c = lane; c < cells; c += 64) {
-        const int idx = (x0 + c % w) + (y0 + c / w) * mw;
-        atomicMin(&cellsLds[idx].x, zmn);
-        atomicMax(&cellsLds[idx].y, zmx);
-      }
+      for (int c = lane; c < cells; c += 64) fold((x0 + c % w) + (y0 + c / w) * mw, zmn, zmx);
     }
   }
   __syncthreads();
@@ -372,6 +377,60 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
     if (v.x < cur.x) atomicMin(&minmax[c].x, v.x);
     if (v.y > cur.y) atomicMax(&minmax[c].y, v.y);
   }
+}
+
+// K6 for SMALL volumes (an instance volume: a few hundred visible blocks): ONE workgroup owns the whole range image —
+// initialise it in LDS, fold every visible block, store every cell.  No global atomics, no separate initialisation
+// launch (k_minmax_init), no 128 workgroups that each clear and flush a 58 KB image for nothing: on an instance volume
+// K6 was 2 launches and ~25 us of a ~300 us frame, twice per frame (tracking view + preview).  min / max are order
+// independent: the image is the one the other two kernels give.  `keepIfEmpty`: the live view's Prepare() is skipped
+// without visible blocks (the image keeps its previous contents).
+__global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s, const int4 *__restrict__ visBlocks, int ctrIdx,
+                                                             int2 *__restrict__ minmax, int keepIfEmpty) {
+  extern __shared__ int2 cellsLds[];
+  const int n = s.ctr[ctrIdx];
+  if (n <= 0 && keepIfEmpty) return;
+  if (threadIdx.x == 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const int nCells = mw * mh;
+  const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
+  for (int c = threadIdx.x; c < nCells; c += blockDim.x) cellsLds[c] = make_int2(farBits, closeBits);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int base = threadIdx.x & ~63; base < n; base += blockDim.x) {  // wave-uniform trip count
+    const int i = base + lane;
+    bool valid = false;
+    int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
+    float2 zr = make_float2(0.f, 0.f);
+    if (i < n) {
+      const dsr_hash_entry he = entry_of_record(visBlocks[i]);
+      if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
+    }
+    const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
+    const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
+    const bool big = valid && bw * bh > 16;
+    // The few hundred blocks of an instance all fall into the same ~100 cells: unfiltered, every block costs a pair of
+    // same-address LDS atomics per cell, which serialise (measured: ~20 us of a 28 us kernel).  min only decreases and
+    // max only increases, so a plain read that already satisfies the bound makes the atomic unnecessary.
+    auto fold = [&](int idx, int zmn, int zmx) {
+      const int2 cur = cellsLds[idx];
+      if (zmn < cur.x) atomicMin(&cellsLds[idx].x, zmn);
+      if (zmx > cur.y) atomicMax(&cellsLds[idx].y, zmx);
+    };
+    if (valid && !big)
+      for (int y = ul.y; y <= lr.y; ++y)
+        for (int x = ul.x; x <= lr.x; ++x) fold(x + y * mw, zmin, zmax);
+    unsigned long long m = __ballot(big);
+    while (m) {  // large boxes (coarse voxels seen from close: hundreds of cells) are filled by the whole wave
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int x0 = __shfl(ul.x, src), y0 = __shfl(ul.y, src), w = __shfl(bw, src), cells = w * __shfl(bh, src);
+      const int zmn = __shfl(zmin, src), zmx = __shfl(zmax, src);
+      for (int c = lane; c < cells; c += 64) fold((x0 + c % w) + (y0 + c / w) * mw, zmn, zmx);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < nCells; c += blockDim.x) minmax[c] = cellsLds[c];
 }
 
 // ----------------------------------------------------------------- K7: raycast
@@ -682,8 +741,10 @@ __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const Fram
 
 // RenderImage_common shading + the fork's FREECAMERA_DEPTH / COLOUR_FROM_DEPTH_WEIGHT
 // (definitions adopted in oracle/dsr_oracle.cpp render_image()).
+// outRgba2: a second destination of the colour image (the caller's HBM buffer: no copy kernel after the shading)
 __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, const float4 *__restrict__ pointsRay,
-                                                uchar4 *__restrict__ outRgba, float *__restrict__ outDepth) {
+                                                uchar4 *__restrict__ outRgba, float *__restrict__ outDepth,
+                                                uchar4 *__restrict__ outRgba2) {
   __shared__ int s_blocks[256][9];  // normal_from_sdf: the <= 8 blocks of a pixel's neighbourhood (row padded)
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= p.W || y >= p.H) return;
@@ -737,6 +798,7 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
     default: break;
   }
   if (outRgba) outRgba[locId] = out;
+  if (outRgba2) outRgba2[locId] = out;
   if (outDepth) {
     float d = 0.0f;
     if (pt.w > 0) {

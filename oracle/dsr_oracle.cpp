@@ -558,7 +558,8 @@ static inline float computeUpdatedVoxelDepthInfo(dsr_voxel &voxel, const V4f &pt
   if (eta < -mu) return eta;
   float oldF = sdf_to_float((float)voxel.sdf);
   int oldW = voxel.w_depth;
-  float newF = std::min(1.0f, eta / mu);
+  const float q_ = eta / mu;
+  float newF = (1.0f < q_) ? 1.0f : q_; /* MIN(1.0f, eta / mu) — ITMMath.h's macro ((a < b) ? a : b): a NaN quotient passes through (std::min would return 1) */
   int newW = depthWeighting ? depth_weight(depth_measure) : 1;
   newF = oldW * oldF + newW * newF;
   newW = oldW + newW;

@@ -13,6 +13,8 @@ Cases
                  BASELINE configs[4]) with voxel GC (max_weight 1, min_age 3) + host swapping.
   seq06_5cm_50frames  configs[0]/[1] at the reference's own settings: 1226x370 (seq 06), 50 frames, 5 cm voxels,
                  upstream's default table sizes, voxel GC (1, 20).
+  gc_defaults_5cm_230frames  voxel GC at the reference's defaults (max_weight 1, min_age 200) over 230 frames: the FIFO of
+                 visible lists fills, wraps around and pops 30 lists.
   cfg2_instances BASELINE configs[2]: static 5 mm map + 4 instance volumes (0.035 m, mu 1.0,
                  7142 blocks: InstanceReconstructor.cpp:372-379), masks split on the device
                  (ProcessSilhouette / RemoveSilhouette), 3 frames.
@@ -51,6 +53,12 @@ CASES = {
     "seq06_5cm_50frames": dict(frames=50, instances=0, decay=(1, 20), render_every=10, width=1226, height=370,
                                settings=dict(voxel_size=0.05, mu=0.2, sdf_local_block_num=0x40000, hash_bucket_num=0x100000,
                                              excess_list_size=0x20000, **COMMON)),
+    # voxel GC at the reference's DEFAULTS (DynSLAMGUI.cpp:36-42: max_weight 1, min_age 200) long enough for the FIFO of
+    # visible lists to fill (201 slots), wrap around and pop 30 lists: the steady-state GC path the 4541-frame run of
+    # configs[4] exercises, here compared state for state.  5 cm voxels keep the oracle cheap.
+    "gc_defaults_5cm_230frames": dict(frames=230, instances=0, decay=(1, 200), render_every=23,
+                                      settings=dict(voxel_size=0.05, mu=0.2, sdf_local_block_num=0x40000, hash_bucket_num=0x100000,
+                                                    excess_list_size=0x20000, **COMMON)),
     "cfg2_instances": dict(frames=3, instances=4, decay=None, render_every=1,
                            settings=dict(voxel_size=0.005, mu=0.02, sdf_local_block_num=1 << 21, hash_bucket_num=1 << 22,
                                          excess_list_size=1 << 20, **COMMON)),

@@ -27,9 +27,16 @@ def test_pmc_traffic_is_available_for_the_default_workload_and_any_step_count():
     import glob
     newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench5mm_pmc_traffic.json")))[-1]
     assert bench.pmc_traffic(_args(), "k_integrate", 1.0)[1] == os.path.relpath(newest, ROOT)
-    # other workloads have no committed PMC set: null, not a wrong number
-    for other in (_args(decay=True), _args(swap=True), _args(instances=4), _args(width=640), _args(volumes=8), _args(preset="4mm")):
+    # the static map of the multi-volume / GC workloads is the same kernel on the same kind of data: the per-block figure applies (and says so)
+    for same_map in (_args(decay=True), _args(instances=4), _args(volumes=8)):
+        t, src = bench.pmc_traffic(same_map, "k_integrate", 1e5)
+        assert t and "configs[1] static map" in src
+    # other image sizes / presets / host swapping have no committed PMC set: null, not a wrong number
+    for other in (_args(swap=True), _args(width=640), _args(preset="4mm")):
         assert bench.pmc_traffic(other, "k_integrate", 1e5) == (None, None)
+    # the second kernel of the frame has its figure too
+    t, src = bench.pmc_traffic(_args(), "k_raycast", 617000.0)
+    assert t and 0.8e9 < t < 2.5e9
 
 
 def test_roofline_object_from_an_engine_profile():
@@ -42,7 +49,11 @@ def test_roofline_object_from_an_engine_profile():
     assert abs(r["achieved"] - 1.684e9 / 0.608e-3 / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
     assert 0 < r["frac"] <= 1 and r["traffic"] and 0 < r["traffic_frac"] < 1 and r["frac"] < r["traffic_frac"]
     assert abs(r["avg_launch_us"] - 608.0) < 0.1 and r["algorithmic_aos"]["GBps"] > r["achieved"]
-    assert kernels["raycast"]["avg_us"] == 476.0 and kernels["raycast"]["GBps"] is None
+    assert kernels["raycast"]["avg_us"] == 476.0
+    rc = r["raycast"]  # a roofline object for the second kernel
+    assert rc["kernel"] == "k_raycast" and 0 < rc["frac"] < rc["traffic_frac"] < 1 and abs(rc["avg_launch_us"] - 476.0) < 0.1
+    assert abs(rc["bytes_per_launch"] - (V * 1040 + 16 * 1242 * 375 + 8 * 156 * 47)) < 1 and kernels["raycast"]["GBps"] == rc["achieved"]
+    assert r["guide_copy_GBps"] == 6290.0 and abs(r["frac_of_guide_copy"] - r["achieved"] / 6290.0) < 1e-3
     json.dumps(r)  # serialisable
     assert bench.roofline_from_profile([], _args(), None) == (None, {})
 

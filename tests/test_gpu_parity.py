@@ -66,6 +66,20 @@ def test_instance_volume_params(hip_api):
         feed((g, o), sc, i, ignore_oob=True)
     assert_scene_equal(g, o)
     assert_render_equal(g, o)
+    # the fused-preview pair (colour + float depth from one call) of a 7142-block volume: the small-volume paths
+    M = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
+    gc, gd = g.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+    oc, od = o.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+    assert np.array_equal(gd, od) and np.array_equal(gc, oc) and (gd > 0).any()
+    assert np.array_equal(g.dump_visible_list(True), o.dump_visible_list(True))
+    assert_render_equal(g, o, freeview=True)
+    # ... and straight into HBM buffers of the caller (dsr_get_image_dev: the shading kernel writes them itself)
+    import torch
+    c_t = torch.zeros((80 * 256, 4), dtype=torch.uint8, device="cuda")
+    d_t = torch.zeros((80 * 256,), dtype=torch.float32, device="cuda")
+    g.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, M, None, c_t.data_ptr(), d_t.data_ptr())
+    g.sync()
+    assert np.array_equal(c_t.cpu().numpy().reshape(80, 256, 4), oc) and np.array_equal(d_t.cpu().numpy().reshape(80, 256), od)
 
 
 def test_depth_weighting_and_stop_at_max_w(hip_api):
@@ -343,7 +357,10 @@ def test_free_view_cache(hip_api):
 
 
 @pytest.mark.parametrize("env", [dict(DSR_GRID_INTEGRATE="1"), dict(DSR_GRID_INTEGRATE="37", DSR_GRID_EXPECTED="1", DSR_GRID_DECAY="3"),
-                                 dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768")])
+                                 dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768"),
+                                 # the small-volume paths (expected depths by one workgroup, free-view list by one sweep) forced
+                                 # onto this 40000-block volume; the large-volume paths are what the other cases run
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
@@ -358,6 +375,13 @@ def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env)
             e.decay(1, 2, False)
         assert_scene_equal(g, o, voxels=(i in (0, 4)))
         assert_render_equal(g, o)
+    # a free-view render goes through the free-view visible list, the range image, the raycast and the shading
+    M = np.linalg.inv(sc.pose(2).astype(np.float64)).astype(np.float32)
+    gc, gd = g.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+    oc, od = o.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+    assert np.array_equal(gd, od) and np.array_equal(gc, oc)
+    assert np.array_equal(g.dump_visible_list(True), o.dump_visible_list(True))
+    assert_render_equal(g, o, freeview=True)
 
 
 def test_non_finite_depth_in_a_float_view(hip_api):
