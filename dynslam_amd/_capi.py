@@ -100,6 +100,8 @@ SIGNATURES = {
     "set_view_float": (C.c_int, [_H, _P, _P]),
     "set_view_float_dev": (C.c_int, [_H, _P, _P]),
     "get_view": (C.c_int, [_H, _P, _P]),
+    "get_view_previews": (C.c_int, [_H, _P, _P]),
+    "get_no_visible_blocks": (C.c_int, [_H, C.POINTER(C.c_int32)]),
     "set_pose_inv_m": (C.c_int, [_H, _P]),
     "set_pose_m": (C.c_int, [_H, _P]),
     "get_pose": (C.c_int, [_H, _P, _P]),

@@ -192,9 +192,19 @@ struct dsr_engine {
   hipEvent_t hostUsedEvent = nullptr;
   bool hostUsedPending = false;
   long long hostUsedCallsSince = 0;              // swap-out batches enqueued since that read-back was issued
-  // silhouette masks (instance view split)
-  uint8_t *maskScratch = nullptr;
-  size_t maskCap = 0;
+  // silhouette masks handed over as HOST buffers (instance view split): a ring of pinned staging slots, each with its
+  // device twin.  The host copies the mask into a slot, the copy to the device is asynchronous, and the call returns
+  // without waiting for the stream: the caller's buffer is free again and the slot is only reused once its copy has run.
+  static constexpr int kMaskSlots = 8;
+  uint8_t *maskHost = nullptr, *maskDev = nullptr;
+  size_t maskSlotBytes = 0;
+  hipEvent_t maskEvent[kMaskSlots] = {};
+  bool maskEventUsed[kMaskSlots] = {};
+  int maskNext = 0;
+  // noVisibleBlocks of the live view as the host last saw it (read together with the status word: dsr_process_frame with
+  // sync_status, dsr_get_stats); valid until the next call that changes the list
+  int32_t noVisibleSeen = 0;
+  bool noVisibleValid = false;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
   hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
@@ -290,6 +300,7 @@ void depth_proj(const dsr_engine *e, float proj[4]) {
 
 int reset_scene(dsr_engine *e) {
   e->sceneVersion++;
+  e->noVisibleValid = false;
   LAUNCH(e, "reset", k_reset_table, dim3(div_up(e->E, 256)), dim3(256), e->scene.table, e->E, e->scene.allocKey);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noExcess, 256)), dim3(256), e->scene.excessAllocList, e->noExcess);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noBlocks, 256)), dim3(256), e->scene.voxelAllocList, e->noBlocks);
@@ -322,7 +333,9 @@ void free_all(dsr_engine *e) {
   }
   F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
-  F(e->fifoPlanes); F(e->decayCand); F(e->decayFlags); F(e->maskScratch);
+  F(e->fifoPlanes); F(e->decayCand); F(e->decayFlags); F(e->maskDev);
+  if (e->maskHost) (void)hipHostFree(e->maskHost);
+  for (auto ev : e->maskEvent) if (ev) (void)hipEventDestroy(ev);
   F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
   F(e->scene.swapSlot); F(e->scene.hostSlabs);
   if (e->hostUsedSeen) (void)hipHostFree(e->hostUsedSeen);
@@ -401,6 +414,7 @@ int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthD
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
 int allocate_scene(dsr_engine *e) {
   e->sceneVersion++;
+  e->noVisibleValid = false;
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
@@ -483,9 +497,15 @@ const char *status_text(int status) {
                                        : "allocation ray longer than the order key allows: the pose is not rigid (k_alloc.h)";
 }
 
+// the status word, and with it (same copy, same synchronisation) the live view's noVisibleBlocks: the host reads that
+// count right after fusion (InfiniTamDriver.h:150) and should not pay a second synchronisation for it
 int sticky_status(dsr_engine *e, int *status) {
-  HIP_TRY(hipMemcpyAsync(status, e->scene.ctr + CTR_STATUS, 4, hipMemcpyDeviceToHost, e->stream));
+  static_assert(CTR_NO_VISIBLE_LIVE + 2 == CTR_STATUS, "the three words are fetched with one copy");
+  int32_t w[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(w, e->scene.ctr + CTR_NO_VISIBLE_LIVE, sizeof w, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  *status = w[2];
+  e->noVisibleSeen = w[0]; e->noVisibleValid = true;
   return DSR_OK;
 }
 
@@ -988,6 +1008,7 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   CHECK_E(e);
   if (min_age < 0) return fail(DSR_E_ARG, "negative min_age");
   e->sceneVersion++;
+  e->noVisibleValid = false;
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -1344,17 +1365,32 @@ int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *he
   return st;
 }
 
-static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h) {
+// -> device pointer of the staged mask (see the ring's description in dsr_engine)
+static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h, const uint8_t **devOut) {
   const size_t n = (size_t)box_w * box_h;
-  if (e->maskCap < n) {
-    if (e->maskScratch) (void)hipFree(e->maskScratch);
-    e->maskScratch = nullptr; e->maskCap = 0;
-    int st = dmalloc(&e->maskScratch, n);
+  if (e->maskSlotBytes < n) {  // grow: rare (a mask larger than any before) — drain, then reallocate the ring
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->maskHost) (void)hipHostFree(e->maskHost);
+    if (e->maskDev) (void)hipFree(e->maskDev);
+    e->maskHost = e->maskDev = nullptr; e->maskSlotBytes = 0;
+    const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocDefault) != hipSuccess)
+      return fail(DSR_E_NOMEM, "mask staging allocation failed");
+    int st = dmalloc(&e->maskDev, slot * dsr_engine::kMaskSlots);
     if (st) return st;
-    e->maskCap = n;
+    e->maskSlotBytes = slot;
+    for (bool &u : e->maskEventUsed) u = false;
   }
-  HIP_TRY(hipMemcpyAsync(e->maskScratch, mask, n, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));  // the caller may reuse its (pageable) mask buffer
+  const int s = e->maskNext;
+  e->maskNext = (s + 1) % dsr_engine::kMaskSlots;
+  if (!e->maskEvent[s]) HIP_TRY(hipEventCreateWithFlags(&e->maskEvent[s], hipEventDisableTiming));
+  if (e->maskEventUsed[s]) HIP_TRY(hipEventSynchronize(e->maskEvent[s]));  // the copy that last read this slot (8 uploads ago)
+  memcpy(e->maskHost + (size_t)s * e->maskSlotBytes, mask, n);  // the caller's (pageable) buffer is free after this line
+  HIP_TRY(hipMemcpyAsync(e->maskDev + (size_t)s * e->maskSlotBytes, e->maskHost + (size_t)s * e->maskSlotBytes, n,
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipEventRecord(e->maskEvent[s], e->stream));
+  e->maskEventUsed[s] = true;
+  *devOut = e->maskDev + (size_t)s * e->maskSlotBytes;
   return DSR_OK;
 }
 
@@ -1368,9 +1404,8 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
     return fail(DSR_E_ARG, "main and instance engines must share GPU and image size");
   if (!maskDev) {
-    int st = upload_mask(main_engine, mask, box_w, box_h);
+    int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev);
     if (st) return st;
-    maskDev = main_engine->maskScratch;
   }
   dsr_engine *e = main_engine;
   // runs on the MAIN engine's stream (ordered after the view's producer and before any later
@@ -1407,9 +1442,8 @@ static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
   if (!maskDev) {
-    int st = upload_mask(e, mask, box_w, box_h);
+    int st = upload_mask(e, mask, box_w, box_h, &maskDev);
     if (st) return st;
-    maskDev = e->maskScratch;
   }
   LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
          e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
@@ -1779,6 +1813,7 @@ int dsr_get_stats(dsr_engine *e, dsr_stats *out) {
   out->last_free_block_id = ctr[CTR_LAST_FREE_BLOCK];
   out->last_free_excess_list_id = ctr[CTR_LAST_FREE_EXCESS];
   out->no_visible_blocks = ctr[CTR_NO_VISIBLE_LIVE];
+  e->noVisibleSeen = ctr[CTR_NO_VISIBLE_LIVE]; e->noVisibleValid = true;
   out->no_total_entries = e->E;
   out->voxel_bytes = (int)sizeof(dsr_voxel);
   out->block_voxels = kBlockSize3;
@@ -1788,6 +1823,42 @@ int dsr_get_stats(dsr_engine *e, dsr_stats *out) {
   out->no_visible_blocks_freeview = ctr[CTR_NO_VISIBLE_FREE];
   out->host_store_slots = e->s.use_swapping ? ctr[CTR_HOST_USED] : 0;
   out->host_store_capacity_slots = (int32_t)std::min<long long>((long long)e->hostSlabs.size() * e->scene.slabBlocks, 0x7fffffff);
+  return DSR_OK;
+}
+
+int dsr_get_no_visible_blocks(dsr_engine *e, int32_t *out) {
+  CHECK_E(e);
+  if (!out) return fail(DSR_E_ARG, "null");
+  if (!e->noVisibleValid) {
+    int status = 0;
+    int st = sticky_status(e, &status);  // one 12-byte copy + synchronisation; the status word stays sticky
+    if (st) return st;
+  }
+  *out = e->noVisibleSeen;
+  return DSR_OK;
+}
+
+// InfiniTamDriver::PrepareNextStep's "Keep the OpenCV previews up to date" (InfiniTamDriver.h:154-156):
+// ItmToCv(*view->rgb) + ItmDepthToCv(*view->depth) from the engine's device-resident view — two conversion kernels, two
+// D2H copies, ONE synchronisation (the host-buffer conversions dsr_rgba_to_bgr / dsr_depth_m_to_mm cost an upload, a
+// download and a synchronisation EACH)
+int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out) {
+  CHECK_E(e);
+  if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
+  // scratch (both only ever hold data within one call): depthTmp takes the BGR triples, freeDepth the millimetre map
+  uint8_t *bgrDev = reinterpret_cast<uint8_t *>(e->depthTmp);
+  short *mmDev = reinterpret_cast<short *>(e->freeDepth);
+  if (bgr_out) {
+    LAUNCH(e, "preview_convert", k_rgba_to_bgr, dim3(div_up(e->P, 256)), dim3(256), (const uchar4 *)e->rgb, bgrDev, e->P);
+    HIP_TRY(hipMemcpyAsync(bgr_out, bgrDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, e->stream));
+  }
+  if (depth_mm_out) {
+    LAUNCH(e, "preview_convert", k_depth_m_to_mm, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depth, mmDev, e->P);
+    HIP_TRY(hipMemcpyAsync(depth_mm_out, mmDev, (size_t)e->P * 2, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return DSR_OK;
 }
 

@@ -222,6 +222,11 @@ int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *dept
  * (InstanceReconstructor.cpp:180-181; InfiniTamDriver.h:155-156).  Either
  * pointer may be NULL. */
 int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out);
+/* InfiniTamDriver::PrepareNextStep's "Keep the OpenCV previews up to date" (InfiniTamDriver.h:154-156): the current view as
+ * packed BGR bytes (ItmToCv, InfiniTamDriver.cpp:108-120) and int16 millimetres (ItmDepthToCv / FloatDepthmapToShort,
+ * :128-144), converted on the GPU from the engine's device-resident view: two D2H copies, one synchronisation.  Either
+ * pointer may be NULL. */
+int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out);
 
 /* ---- pose (trackingState->pose_d) ------------------------------------------- */
 
@@ -367,6 +372,10 @@ int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uin
 
 /* ---- statistics / parity dumps ------------------------------------------------ */
 
+/* renderState_live->noVisibleBlocks, which the host reads right after fusion (InfiniTamDriver.h:150).  The value travels
+ * with the status word: after a dsr_process_frame with `sync_status` (or a dsr_get_stats) it is known on the host and this
+ * call does not touch the device; otherwise it costs one 12-byte read-back. */
+int dsr_get_no_visible_blocks(dsr_engine *e, int32_t *out);
 /* Synchronises. */
 int dsr_get_stats(dsr_engine *e, dsr_stats *out);
 

@@ -1656,6 +1656,22 @@ int orc_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n) {
 }
 int orc_depth_m_to_mm_dev(int, void *, const void *i, void *o, int n) { return orc_depth_m_to_mm((const float *)i, (int16_t *)o, n); }
 
+/* InfiniTamDriver.h:154-156: ItmToCv(*view->rgb) + ItmDepthToCv(*view->depth) of the current view */
+int orc_get_view_previews(dsr_engine *h, uint8_t *bgr_out, int16_t *depth_mm_out) {
+  if (!h) return fail(DSR_E_ARG, "null");
+  if (!E.hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  if (E.W != E.Wr || E.H != E.Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
+  int st = DSR_OK;
+  if (bgr_out) st = orc_rgba_to_bgr(reinterpret_cast<const uint8_t *>(E.rgb.data()), bgr_out, E.W * E.H);
+  if (st == DSR_OK && depth_mm_out) st = orc_depth_m_to_mm(E.depth.data(), depth_mm_out, E.W * E.H);
+  return st;
+}
+int orc_get_no_visible_blocks(dsr_engine *h, int32_t *out) {
+  if (!h || !out) return fail(DSR_E_ARG, "null");
+  *out = E.live.noVisibleBlocks;
+  return DSR_OK;
+}
+
 /* ProcessSilhouette_CPU (InstanceReconstructor.cpp:59-133), restated on the engines' views. */
 int orc_view_extract_silhouette(dsr_engine *m, dsr_engine *inst, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
   if (!m || !inst || !mask || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");

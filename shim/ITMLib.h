@@ -244,7 +244,8 @@ struct ITMRenderState_VH : ITMRenderState {
     mutable int cached = 0;
     mutable bool valid = true;
     operator int() const {
-      if (!valid && e) { dsr_stats s; if (dsr_get_stats(e, &s) == DSR_OK) cached = s.no_visible_blocks; valid = true; }
+      // known on the host already when the status of the fusion call was fetched (one read-back for both), else 12 bytes
+      if (!valid && e) { int32_t n = 0; if (dsr_get_no_visible_blocks(e, &n) == DSR_OK) cached = n; valid = true; }
       return cached;
     }
     LazyCount &operator=(int v) { cached = v; valid = true; return *this; }

@@ -65,8 +65,12 @@ class HostDriver : public ITMMainEngine {
   void PrepareNextStep() {  // .h:148-158 (incl. the two preview conversions)
     if (static_cast<ITMRenderState_VH *>(renderState_live)->noVisibleBlocks > 0) {
       trackingController->Prepare(trackingState, view, renderState_live);
-      dynslam_shim::ItmToCv(*view->rgb, previewBgr_.data());
-      dynslam_shim::ItmDepthToCv(*view->depth, previewMm_.data());
+      if (view->owner == GetDsrEngine() && !view->deviceStale)  // the view is current in HBM: both previews from there, one sync
+        ITMLib::Engine::dsr_throw(dsr_get_view_previews(GetDsrEngine(), previewBgr_.data(), previewMm_.data()));
+      else {
+        dynslam_shim::ItmToCv(*view->rgb, previewBgr_.data());
+        dynslam_shim::ItmDepthToCv(*view->depth, previewMm_.data());
+      }
     }
   }
   void Decay() { if (decay_) denseMapper->Decay(scene, renderState_live, decayMaxW_, decayMinAge_, false); }  // .h:201-206

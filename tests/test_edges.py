@@ -229,3 +229,71 @@ def test_gpu_instance_pipeline(hip_api, oracle_lib):
     assert oi.get_stats().no_visible_blocks > 0
     assert_scene_equal(gm, om); assert_render_equal(gm, om)
     assert_scene_equal(gi, oi); assert_render_equal(gi, oi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("x0,y0,h,w", [(40, 10, 30, 50), (-7, -5, 40, 60), (300, 80, 40, 60), (0, 0, 96, 320)])
+def test_gpu_silhouette_ops_with_masks_in_hbm(hip_api, oracle_lib, x0, y0, h, w):
+    """dsr_view_extract_silhouette_dev / dsr_view_remove_silhouette_dev (mask already in HBM: no staging copy, no
+    synchronisation) == the host-mask variants == the oracle's restatement of ProcessSilhouette_CPU /
+    RemoveSilhouette_CPU, for boxes inside the frame, sticking out on every side, and covering it."""
+    import torch
+    W, H = 320, 96
+    rng = np.random.default_rng(x0 * 7 + y0)
+    mask = (rng.random((h, w)) < 0.6).astype(np.uint8)
+    mask[rng.random((h, w)) < 0.05] = 2  # only the value 1 copies (InstanceReconstructor.cpp:113)
+    sc, gm, gi = make_engines(hip_factory, W, H)
+    _, gm2, gi2 = make_engines(hip_factory, W, H)
+    _, om, oi = make_engines(oracle_factory, W, H)
+    rgba, d, T, _ = StreetScene(W, H).frame(1)
+    for m in (gm, gm2, om):
+        m.update_view(rgba, d)
+    mask_t = torch.from_numpy(mask).cuda()
+    gm.extract_silhouette_dev(gi, mask_t.data_ptr(), x0, y0, w, h)
+    gm.remove_silhouette_dev(mask_t.data_ptr(), x0, y0, w, h)
+    gm.sync(); gi.sync()
+    gm2.extract_silhouette(gi2, mask, x0, y0)
+    gm2.remove_silhouette(mask, x0, y0)
+    om.extract_silhouette(oi, mask, x0, y0)
+    om.remove_silhouette(mask, x0, y0)
+    for a, b, c in ((gm, gm2, om), (gi, gi2, oi)):
+        va, vb, vc = a.get_view(), b.get_view(), c.get_view()
+        assert np.array_equal(va[0], vc[0]) and np.array_equal(va[1], vc[1])
+        assert np.array_equal(vb[0], vc[0]) and np.array_equal(vb[1], vc[1])
+    # a null mask is an argument error, not a crash
+    assert hip_api.view_remove_silhouette_dev(gm._h, None, x0, y0, w, h) != 0
+
+
+@pytest.mark.gpu
+def test_gpu_view_previews_and_visible_count(hip_api, oracle_lib):
+    """dsr_get_view_previews (ItmToCv + ItmDepthToCv of the current view, InfiniTamDriver.h:154-156, from HBM with one
+    synchronisation) and dsr_get_no_visible_blocks (the count the host reads after fusion) against the oracle and against
+    the host-buffer conversions."""
+    W, H = 320, 96
+    sc, g, _ = make_engines(hip_factory, W, H)
+    _, o, _ = make_engines(oracle_factory, W, H)
+    n = C.c_int32(-1)
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        for e in (g, o):
+            e.update_view(rgba, d)
+            e.set_pose_inv_m(T)
+            e.process_frame()
+        assert hip_api.get_no_visible_blocks(g._h, C.byref(n)) == 0  # known from the status read-back of process_frame
+        assert n.value == o.get_stats().no_visible_blocks == g.get_stats().no_visible_blocks > 0
+        g.decay(1, 0, False)  # changes the list: the cached value must not be served
+        o.decay(1, 0, False)
+        assert hip_api.get_no_visible_blocks(g._h, C.byref(n)) == 0 and n.value == o.get_stats().no_visible_blocks
+    out = {}
+    for name, e, api in (("g", g, hip_api), ("o", o, oracle_lib)):
+        bgr = np.zeros((H, W, 3), np.uint8); mm = np.zeros((H, W), np.int16)
+        assert api.get_view_previews(e._h, vp(bgr), vp(mm)) == 0
+        out[name] = (bgr, mm)
+    assert np.array_equal(out["g"][0], out["o"][0]) and np.array_equal(out["g"][1], out["o"][1])
+    rgba_v, depth_v = g.get_view()
+    assert np.array_equal(out["g"][0], rgba_v[..., 2::-1])  # BGR of the view's RGBA
+    mm2 = np.zeros((H, W), np.int16)
+    assert hip_api.depth_m_to_mm(vp(depth_v), vp(mm2), W * H) == 0 and np.array_equal(mm2, out["g"][1])
+    # either output alone
+    bgr = np.zeros((H, W, 3), np.uint8)
+    assert hip_api.get_view_previews(g._h, vp(bgr), None) == 0 and np.array_equal(bgr, out["g"][0])

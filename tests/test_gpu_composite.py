@@ -128,3 +128,39 @@ def test_preview_exchange_over_rccl(hip_api, oracle_lib):
         assert np.array_equal(t_d.cpu().numpy(), o_d) and np.array_equal(t_c.cpu().numpy(), o_c)
     finally:
         dist.destroy_process_group()
+
+
+def test_composite_layers_where_they_lie(hip_api, oracle_lib):
+    """dsr_composite_layer_ptrs_dev: one pointer per layer into a larger buffer (the all-gathered exchange buffer: a layer's
+    depth plane followed by its colour plane, layers of other ranks in between) — same result as the contiguous-layer form."""
+    import torch
+    P, L = 5000, 5
+    rng = np.random.default_rng(11)
+    slots = 9  # the buffer holds more layers than are composited, in another order
+    buf = np.zeros((slots, 2, P * 4), np.uint8)
+    depth = rng.uniform(1, 9, (slots, P)).astype(np.float32); depth[rng.random((slots, P)) < 0.5] = 0
+    rgba = rng.integers(0, 256, (slots, P, 4)).astype(np.uint8)
+    buf[:, 0] = depth.view(np.uint8).reshape(slots, P * 4)
+    buf[:, 1] = rgba.reshape(slots, P * 4)
+    order = [7, 2, 8, 0, 4]
+    tids = np.array([3, 5, 12, 13, 40], np.int32)
+    bg_c = rng.integers(0, 256, (P, 4)).astype(np.uint8); bg_d = rng.uniform(1, 9, P).astype(np.float32); bg_d[::7] = 0
+    dev = torch.device("cuda", 0)
+    t_buf = torch.from_numpy(buf).to(dev)
+    t_c, t_d = torch.from_numpy(bg_c).to(dev), torch.from_numpy(bg_d).to(dev)
+    base = t_buf.data_ptr()
+    dp = (C.c_void_p * L)(*[base + l * 8 * P for l in order])
+    rp = (C.c_void_p * L)(*[base + l * 8 * P + 4 * P for l in order])
+    assert hip_api.composite_layer_ptrs_dev(0, None, C.c_void_p(t_c.data_ptr()), C.c_void_p(t_d.data_ptr()), rp, dp, vp(tids), L, P, 0.7, 1) == 0
+    torch.cuda.synchronize()
+    o_c, o_d = bg_c.copy(), bg_d.copy()
+    lc, ld = np.ascontiguousarray(rgba[order]), np.ascontiguousarray(depth[order])
+    assert oracle_lib.composite_instances(vp(o_c), vp(o_d), vp(lc), vp(ld), vp(tids), L, P, 0.7, 1) == 0
+    assert np.array_equal(t_d.cpu().numpy(), o_d) and np.array_equal(t_c.cpu().numpy(), o_c)
+    # depth only (CompositeDepth): no colour pointers needed
+    t_d2 = torch.from_numpy(bg_d).to(dev)
+    assert hip_api.composite_layer_ptrs_dev(0, None, None, C.c_void_p(t_d2.data_ptr()), None, dp, vp(tids), L, P, 1.0, 0) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(t_d2.cpu().numpy(), o_d)
+    # argument errors
+    assert hip_api.composite_layer_ptrs_dev(0, None, C.c_void_p(t_c.data_ptr()), C.c_void_p(t_d.data_ptr()), None, dp, vp(tids), L, P, 1.0, 1) != 0
