@@ -121,6 +121,15 @@ struct dsr_engine {
   dsr_calib calib;
   int device = 0;
   hipStream_t stream = nullptr;
+  // The range image of the live view (K6) needs the visible list and the pose — not a single voxel — so it is computed on
+  // a SIDE stream while k_integrate runs (the host's Integrate(); PrepareNextStep(); pair, InfiniTamDriver.h:137-158):
+  // its LDS / atomic / latency phases hide under the VALU-bound integration.  dsr_prepare takes the result when list and
+  // camera are still the ones it was computed for, else it recomputes on the main stream.  env DSR_OVERLAP_EXPECTED=0: off.
+  hipStream_t sideStream = nullptr;
+  hipEvent_t evList = nullptr, evExpected = nullptr;
+  bool overlapExpected = true;
+  unsigned long long listVersion = 0;  // bumped by every call that rewrites the live visible list
+  struct { bool valid = false; unsigned long long version = 0; Mat4 M; float proj[4] = {0, 0, 0, 0}; } liveExp;
   int W = 0, H = 0, Wr = 0, Hr = 0, P = 0;
   int noBuckets = 0, noExcess = 0, E = 0, noBlocks = 0;
   int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
@@ -136,6 +145,7 @@ struct dsr_engine {
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
+  int threadsExpected = 1024;   // ... and their size (env DSR_EXPECTED_THREADS: a multiple of 64 up to 1024)
   bool expectedFilter = false;  // k_expected_depth_lds<FILTER> (env DSR_EXPECTED_FILTER)
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
@@ -236,6 +246,7 @@ hipEvent_t get_event(dsr_engine *e) {
 void prof_resolve(dsr_engine *e) {
   if (e->profPending.empty()) return;
   (void)hipStreamSynchronize(e->stream);
+  if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
   for (auto &p : e->profPending) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { e->profRecs[p.rec].ms += ms; e->profRecs[p.rec].launches++; }
@@ -264,6 +275,13 @@ struct ProfScope {
     (void)hipEventRecord(b, e->stream);
     e->profPending.push_back({rec, a, b});
   }
+};
+
+// kernels enqueued inside the scope go to `s` (LAUNCH and ProfScope read e->stream)
+struct StreamSwap {
+  dsr_engine *e; hipStream_t saved;
+  StreamSwap(dsr_engine *e_, hipStream_t s) : e(e_), saved(e_->stream) { e->stream = s; }
+  ~StreamSwap() { e->stream = saved; }
 };
 
 #define LAUNCH(e, name, kernel, grid, block, ...)                                \
@@ -301,6 +319,7 @@ void depth_proj(const dsr_engine *e, float proj[4]) {
 int reset_scene(dsr_engine *e) {
   e->sceneVersion++;
   e->noVisibleValid = false;
+  e->listVersion++;
   LAUNCH(e, "reset", k_reset_table, dim3(div_up(e->E, 256)), dim3(256), e->scene.table, e->E, e->scene.allocKey);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noExcess, 256)), dim3(256), e->scene.excessAllocList, e->noExcess);
   LAUNCH(e, "reset", k_iota, dim3(div_up(e->noBlocks, 256)), dim3(256), e->scene.voxelAllocList, e->noBlocks);
@@ -346,6 +365,9 @@ void free_all(dsr_engine *e) {
   if (e->orderEvent) (void)hipEventDestroy(e->orderEvent);
   for (auto &p : e->profPending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
+  if (e->evList) (void)hipEventDestroy(e->evList);
+  if (e->evExpected) (void)hipEventDestroy(e->evExpected);
+  if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
 
@@ -412,9 +434,12 @@ int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthD
 }
 
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
+int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p);
+
 int allocate_scene(dsr_engine *e) {
   e->sceneVersion++;
   e->noVisibleValid = false;
+  e->listVersion++;
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
@@ -434,6 +459,20 @@ int allocate_scene(dsr_engine *e) {
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
          (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks);
   HIP_TRY(hipGetLastError());
+  e->liveExp.valid = false;
+  if (e->overlapExpected) {
+    // the list is final: start the live view's range image on the side stream, under the integration that follows
+    HIP_TRY(hipEventRecord(e->evList, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->sideStream, e->evList, 0));
+    {
+      StreamSwap sw(e, e->sideStream);
+      int st = expected_depths(e, rs, p);
+      if (st) return st;
+    }
+    HIP_TRY(hipEventRecord(e->evExpected, e->sideStream));
+    e->liveExp.valid = true; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
+    memcpy(e->liveExp.proj, proj, sizeof proj);
+  }
   return DSR_OK;
 }
 
@@ -474,10 +513,10 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
     // range image privatised in LDS by a few large workgroups (k_raycast.h)
     ProfScope _ps(e, "expected_depth");
     if (e->expectedFilter)
-      hipLaunchKernelGGL(k_expected_depth_lds<true>, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
+      hipLaunchKernelGGL(k_expected_depth_lds<true>, dim3(e->gridExpected), dim3(e->threadsExpected), ldsBytes, e->stream, p, e->scene,
                          (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
     else
-      hipLaunchKernelGGL(k_expected_depth_lds<false>, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
+      hipLaunchKernelGGL(k_expected_depth_lds<false>, dim3(e->gridExpected), dim3(e->threadsExpected), ldsBytes, e->stream, p, e->scene,
                          (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
   } else {
     LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int4 *)rs.visBlocks,
@@ -714,6 +753,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   }
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
   if (const char *ef = getenv("DSR_EXPECTED_FILTER")) e->expectedFilter = atoi(ef) != 0;
+  if (const char *et = getenv("DSR_EXPECTED_THREADS")) e->threadsExpected = std::min(1024, std::max(64, (atoi(et) / 64) * 64));
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
@@ -728,6 +768,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
+  if (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
+  if (const char *ov = getenv("DSR_OVERLAP_EXPECTED")) e->overlapExpected = atoi(ov) != 0;
   ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
   ALLOC(dmalloc(&e->scene.voxelAllocList, (size_t)e->noBlocks));
@@ -800,6 +844,7 @@ void dsr_engine_destroy(dsr_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
   free_all(e);
   delete e;
 }
@@ -812,6 +857,7 @@ int dsr_reset_scene(dsr_engine *e) {
 int dsr_sync(dsr_engine *e) {
   CHECK_E(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipStreamSynchronize(e->sideStream));
   return DSR_OK;
 }
 
@@ -994,8 +1040,15 @@ int dsr_prepare(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
-  int st = expected_depths(e, rs, p);
-  if (st) return st;
+  if (e->liveExp.valid && e->liveExp.version == e->listVersion && memcmp(e->liveExp.M.m, e->M_d.m, sizeof e->M_d.m) == 0 &&
+      memcmp(e->liveExp.proj, proj, sizeof proj) == 0) {
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // computed under the integration (allocate_scene)
+  } else {
+    if (e->liveExp.valid) HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // a stale one may still be writing the image
+    e->liveExp.valid = false;
+    int st = expected_depths(e, rs, p);
+    if (st) return st;
+  }
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
   launch_raycast(e, "raycast", p, rs);
   LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
@@ -1009,6 +1062,7 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   if (min_age < 0) return fail(DSR_E_ARG, "negative min_age");
   e->sceneVersion++;
   e->noVisibleValid = false;
+  e->listVersion++;
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -1929,6 +1983,7 @@ int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycas
   RenderStateDev &rs = which ? e->freeview : e->live;
   const size_t P = (size_t)e->P;
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
+  if (!which && e->liveExp.valid) HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // a range image still in flight on the side stream
   if (minmax) HIP_TRY(hipMemcpyAsync(minmax, rs.minmax, (size_t)mw * mh * 8, hipMemcpyDeviceToHost, e->stream));
   if (raycast_result) HIP_TRY(hipMemcpyAsync(raycast_result, rs.raycastResult, P * 16, hipMemcpyDeviceToHost, e->stream));
   if (points) HIP_TRY(hipMemcpyAsync(points, e->pointsMap, P * 16, hipMemcpyDeviceToHost, e->stream));

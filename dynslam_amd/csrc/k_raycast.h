@@ -408,14 +408,15 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
-    const bool big = valid && bw * bh > 16;
-    // The few hundred blocks of an instance all fall into the same ~100 cells: unfiltered, every block costs a pair of
-    // same-address LDS atomics per cell, which serialise (measured: ~20 us of a 28 us kernel).  min only decreases and
-    // max only increases, so a plain read that already satisfies the bound makes the atomic unnecessary.
+    // An instance is seen from close: a 0.28 m block at 8 m covers ~5 x 5 cells, so with the other kernels' threshold
+    // (16 cells) nearly every block took the wave-cooperative path below — 64 SEQUENTIAL rounds of seven cross-lane
+    // broadcasts per wave (measured: ~28 us for 539 blocks).  Here the owning lane fills boxes of up to 144 cells itself
+    // (fire-and-forget LDS atomics, ~10 cycles a cell) and only a block right in front of the camera is shared.
+    // (Reading the cell first to skip atomics that cannot change it was measured too: slower, 35 us — the read's latency.)
+    const bool big = valid && bw * bh > 144;
     auto fold = [&](int idx, int zmn, int zmx) {
-      const int2 cur = cellsLds[idx];
-      if (zmn < cur.x) atomicMin(&cellsLds[idx].x, zmn);
-      if (zmx > cur.y) atomicMax(&cellsLds[idx].y, zmx);
+      atomicMin(&cellsLds[idx].x, zmn);
+      atomicMax(&cellsLds[idx].y, zmx);
     };
     if (valid && !big)
       for (int y = ul.y; y <= lr.y; ++y)
@@ -518,7 +519,11 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         //  (1 / 8 / 16 neighbouring tiles) instead of 256: 601 / 536 / 519 vs 488 us; round 2: a per-wave
         //  direct-mapped LDS cache of lookup OUTCOMES (found block / no block) shared by the 64 rays of a
         //  tile, 572 vs 435 us — also when compiled for 7 or 6 waves per SIMD, which by themselves change
-        //  nothing (439 / 438 us).  Every variant
+        //  nothing (439 / 438 us); round 3: issuing the four corner-pair loads of the trilinear cell TOGETHER with the
+        //  step's own voxel load whenever the previous step was inside the interpolation band (one round trip per band
+        //  step instead of two, no extra loads when the guess holds), 441-443 vs 429 us, and requesting the NEXT step's
+        //  voxel one iteration ahead in saturated space, 518 us (7 spilled registers at the 64-VGPR limit), both 543 us
+        //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact).  Every variant
         //  that adds requests or iterations loses: the march is bound by gather-request
         //  throughput and by the per-wave chain of dependent round trips.)
       }

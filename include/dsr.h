@@ -396,7 +396,9 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
  *   minmax        : 2 * ceil(W/8) * ceil(H/8) floats (renderingRangeImage)
  *   raycast_result: 4*W*H floats (voxel units, w = found)
  *   points/normals: 4*W*H floats (trackingState->pointCloud; live only)
- *   raycast_image : 4*W*H bytes */
+ *   raycast_image : 4*W*H bytes   (The range image of the LIVE view is computed right after the visible list,
+ * under the integration — so between dsr_process_frame and dsr_prepare a dump already shows the new frame's image; the
+ * reference's structure of the same name is internal to its visualisation engine and never read by the host.) */
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result,
                           float *points, float *normals, uint8_t *raycast_image);
 

@@ -239,7 +239,7 @@ def test_gpu_silhouette_ops_with_masks_in_hbm(hip_api, oracle_lib, x0, y0, h, w)
     RemoveSilhouette_CPU, for boxes inside the frame, sticking out on every side, and covering it."""
     import torch
     W, H = 320, 96
-    rng = np.random.default_rng(x0 * 7 + y0)
+    rng = np.random.default_rng(abs(x0 * 7 + y0) + 1)
     mask = (rng.random((h, w)) < 0.6).astype(np.uint8)
     mask[rng.random((h, w)) < 0.05] = 2  # only the value 1 copies (InstanceReconstructor.cpp:113)
     sc, gm, gi = make_engines(hip_factory, W, H)

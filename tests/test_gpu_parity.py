@@ -409,3 +409,32 @@ def test_non_finite_depth_in_a_float_view(hip_api):
     big = ov > 1e30
     assert big.any() and np.all(gv[big] == np.float32(1e30))
     assert np.array_equal(gv[~big], ov[~big], equal_nan=True)
+
+
+def test_pose_or_list_change_between_fusion_and_prepare(hip_api):
+    """The live view's range image is computed speculatively under the integration (side stream, dsr_engine.hip); Prepare must
+    not take it when the camera moved or the visible list changed (voxel GC) between Integrate and PrepareNextStep."""
+    sc, g, o = make_pair()
+    for i in range(3):
+        feed((g, o), sc, i)
+    rgba, d, T, _ = sc.frame(3)
+    T2 = sc.pose(5)
+    for e in (g, o):
+        e.update_view(rgba, d)
+        e.set_pose_inv_m(T)
+        e.process_frame()
+        e.set_pose_inv_m(T2)   # the tracker refined the pose after fusion
+        e.prepare()
+    assert_render_equal(g, o)
+    rgba, d, T, _ = sc.frame(4)
+    for e in (g, o):
+        e.update_view(rgba, d)
+        e.set_pose_inv_m(T)
+        e.process_frame()
+        e.decay(3, 0, True)    # GC rewrote the visible list
+        e.prepare()
+    assert_scene_equal(g, o)
+    assert_render_equal(g, o)
+    # ... and the plain sequence afterwards still takes the speculative image and matches
+    feed((g, o), sc, 5)
+    assert_render_equal(g, o)

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KEYS = {"GRID": "DSR_GRID_INTEGRATE", "GRIDX": "DSR_GRID_EXPECTED", "GRIDD": "DSR_GRID_DECAY"}  # switches the library reads at engine creation
+KEYS = {"GRID": "DSR_GRID_INTEGRATE", "GRIDX": "DSR_GRID_EXPECTED", "GRIDD": "DSR_GRID_DECAY", "OVERLAP": "DSR_OVERLAP_EXPECTED"}  # switches the library reads at engine creation
 
 
 def main():
