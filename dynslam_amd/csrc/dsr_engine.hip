@@ -768,7 +768,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
-  if (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
+  // the side stream gets the HIGHEST priority: its one short kernel pair needs whole compute units (1024-thread workgroups,
+  // 58 KB of LDS) and would otherwise only be placed when the integration, which fills every unit, drains
+  int prLeast = 0, prGreatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+  if (const char *sp = getenv("DSR_SIDE_PRIORITY")) { if (atoi(sp) == 0) prGreatest = prLeast; }
+  if (hipStreamCreateWithPriority(&e->sideStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
       hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
   if (const char *ov = getenv("DSR_OVERLAP_EXPECTED")) e->overlapExpected = atoi(ov) != 0;

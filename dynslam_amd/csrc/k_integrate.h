@@ -111,6 +111,12 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 //           (no change), colour list appended once per task from a per-lane bit mask + wave prefix
 //           sum (688 us: six dependent ds_bpermute), skipping x-slices without updates (no change),
 //           5 / 6 instead of 7 waves per SIMD (no change).
+// (Round 3, measured and dropped: copying the 13 uniform operands of the per-voxel arithmetic — first matrix column and
+//  translation, projection, voxel size, mu and its reciprocal — into VECTOR registers, because tools/ubench times a full-rate
+//  VALU instruction with an SGPR operand at half rate and the voxel loop holds ~110 of them per task: 78 VGPRs = 6 waves per
+//  SIMD, 546 / 561 us against 559 / 559 us — nothing, profiles/r03g_integrate_vreg_variants.log.  With the row products
+//  hoisted by hand (to_camera below) the kernel needs 65 VGPRs; compiled for 8 waves per SIMD (64 VGPRs, 35 SGPR spills) it
+//  is slower: 576-584 vs 557-560 us, profiles/r03h_integrate_occ8_variants.log.)
 template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
@@ -154,6 +160,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const __amdgpu_buffer_rsrc_t depthRsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(depth), 0, (int)((uint32_t)p.W * (uint32_t)p.H * 4u), 0x00020000);
   const int rowBytes = p.W * 4;
+  const float hM0 = p.M.m[0], hM1 = p.M.m[1], hM2 = p.M.m[2], hM12 = p.M.m[12], hM13 = p.M.m[13], hM14 = p.M.m[14];
+  const float hPx = p.proj.x, hPy = p.proj.y, hPz = p.proj.z, hPw = p.proj.w, hVs = p.voxelSize, hMu = p.mu, hYMu = yMu;
 
   // ------------------------------------------------------------ colour pass
   // computeUpdatedVoxelColorInfo for `cnt` (<= 64) pending voxels starting at list position `base`,
@@ -245,8 +253,19 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     const int vox0 = task_vox0(t);
     const int lx0 = vox0 & 7, ly = (vox0 >> 3) & 7, lz = vox0 >> 6;
     const int gx = he.pos[0] * kBlockSize + lx0, gy = he.pos[1] * kBlockSize, gz = he.pos[2] * kBlockSize;
-    const float my = (float)(gy + ly) * p.voxelSize;
-    const float mz = (float)(gz + lz) * p.voxelSize;
+    const float my = (float)(gy + ly) * hVs;
+    const float mz = (float)(gz + lz) * hVs;
+    // ORUtils Matrix4 * Vector4 (mat_mul3), row by row in its order ((m0 x + m4 y) + m8 z) + m12 w: the y and z products are
+    // the same for the lane's eight voxels
+    const float yx = p.M.m[4] * my, yy = p.M.m[5] * my, yz_ = p.M.m[6] * my;
+    const float zx = p.M.m[8] * mz, zy = p.M.m[9] * mz, zz = p.M.m[10] * mz;
+    auto to_camera = [&](float mx) -> float3 {
+      float3 r;
+      r.x = hM0 * mx + yx + zx + hM12 * 1.0f;
+      r.y = hM1 * mx + yy + zy + hM13 * 1.0f;
+      r.z = hM2 * mx + yz_ + zz + hM14 * 1.0f;
+      return r;
+    };
 
     // ---------------------------------------------- phase A1: project, issue the depth gathers
     float pz[VOX], dm[VOX];
@@ -255,13 +274,13 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       bool allTame = true;
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
-        const float mx = (float)(gx + x) * p.voxelSize;
-        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+        const float mx = (float)(gx + x) * hVs;
+        const float3 pc = to_camera(mx);
         const bool tame = pc.z >= 1e-4f;
         const float zs = tame ? pc.z : 1.0f;
         const float yz = rcp_refined(zs);
-        const float u = div_with_rcp(p.proj.x * pc.x, zs, yz) + p.proj.z;
-        const float v = div_with_rcp(p.proj.y * pc.y, zs, yz) + p.proj.w;
+        const float u = div_with_rcp(hPx * pc.x, zs, yz) + hPz;
+        const float v = div_with_rcp(hPy * pc.y, zs, yz) + hPw;
         const bool in = tame & !((u < 1) | (u > wLim) | (v < 1) | (v > hLim));  // bitwise: no short-circuit branches
         // byte offset of the pixel (rows and bytes per row are < 2^24); out of the image -> out of the
         // buffer's range -> the load returns 0: "no depth", rejected by (dm <= 0) like an invalid pixel
@@ -278,8 +297,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
         if (!(pz[x] > 0) || pz[x] >= 1e-4f) continue;
-        const float mx = (float)(gx + x) * p.voxelSize;
-        const float3 pc = mat_mul3(p.M, mx, my, mz, 1.0f);
+        const float mx = (float)(gx + x) * hVs;
+        const float3 pc = to_camera(mx);
         const float u = p.proj.x * pc.x / pc.z + p.proj.z;
         const float v = p.proj.y * pc.y / pc.z + p.proj.w;
         const bool in = !((u < 1) || (u > wLim) || (v < 1) || (v > hLim));
@@ -289,14 +308,12 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
     // computeUpdatedVoxelDepthInfo's rejection tests; a task none of whose voxels is updated
     // (behind the surface / outside the image: ~15 % of the visible half blocks) ends here
-    float eta[VOX];
-    bool ok[VOX];
     bool anyUpd = false;
 #pragma unroll
     for (int x = 0; x < VOX; ++x) {
-      ok[x] = !(dm[x] <= 0.0f);  // lanes out of the image read dm = 0
-      eta[x] = dm[x] - pz[x];
-      anyUpd |= ok[x] & !(eta[x] < -p.mu);
+      const bool ok = !(dm[x] <= 0.0f);  // lanes out of the image read dm = 0
+      const float eta = dm[x] - pz[x];
+      anyUpd |= ok & !(eta < -hMu);
     }
     if (!rejectedPassGate && !__any(anyUpd)) continue;
 
@@ -312,9 +329,13 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         const short sdf = (short)((pl.sdf[x >> 1] >> ((x & 1) * 16)) & 0xffffu);
         const int wDepth = (int)((pl.wd[x >> 2] >> ((x & 3) * 8)) & 0xffu);
         const bool skip = stopAtMaxW & (wDepth == p.maxW);
-        const bool okx = !skip & ok[x];  // (bitwise: the compiler turns && / || chains into exec-mask branches)
-        const bool upd = okx & !(eta[x] < -p.mu);
-        const float q = PLAIN ? div_short(eta[x], p.mu, yMu) : div_with_rcp(eta[x], p.mu, yMu);  // eta / mu
+        // the two values of the rejection loop above are recomputed (a compare and a subtraction) rather than kept: held
+        // across the task they are 8 VGPRs and 8 lane masks, which the register allocator answered with spills
+        const bool okv = !(dm[x] <= 0.0f);
+        const float etax = dm[x] - pz[x];
+        const bool okx = !skip & okv;  // (bitwise: the compiler turns && / || chains into exec-mask branches)
+        const bool upd = okx & !(etax < -hMu);
+        const float q = PLAIN ? div_short(etax, hMu, hYMu) : div_with_rcp(etax, hMu, hYMu);  // eta / mu
         const float oldF = PLAIN ? div_short((float)sdf, 32767.0f, y32767)
                                  : div_with_rcp((float)sdf, 32767.0f, y32767);  // SDF_valueToFloat
         float newF = (1.0f < q) ? 1.0f : q;                              // MIN(1.0f, eta / mu)
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         //      (the one input whose quotient this division sequence gets wrong: NaN) cannot reach this point:
         //      float views are stored with depths above 1e30 clamped to 1e30 (k_edges.h k_copy_depth_finite)
         const bool gateOk = !(fabsf(q) > 0.25f);
-        const bool gate = REJ ? (!skip & (ok[x] ? gateOk : true)) : (okx & gateOk);
+        const bool gate = REJ ? (!skip & (okv ? gateOk : true)) : (okx & gateOk);
         // append to the wave's pending colour list (ordered compaction across the 64 lanes)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(gate);
         if (gate)  // slot = number of gated lanes below this one (v_mbcnt)

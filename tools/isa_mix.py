@@ -37,8 +37,11 @@ def main():
         text = open(sys.argv[1]).read()
     else:
         src = os.path.join(ROOT, "dynslam_amd", "csrc", "dsr_engine.hip")
-        text = subprocess.check_output(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                        "-fno-fast-math", "--cuda-device-only", "-S", "-o", "-", src], stderr=subprocess.DEVNULL).decode()
+        sys.path.insert(0, ROOT)
+        from __graft_entry__ import HIPCC_FLAGS  # the flags the library is built with (minus the link step)
+        flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+        text = subprocess.check_output(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "-o", "-", src],
+                                       stderr=subprocess.DEVNULL).decode()
     m = re.search(r"^(_ZN3dsr11k_integrateILb1ELb1ELi8ELi7EE\w*):.*?s_endpgm", text, re.S | re.M)
     body = m.group(0).split("\n")
     blocks, cur = [], ["entry", []]
