@@ -125,6 +125,11 @@ struct dsr_engine {
   // a SIDE stream while k_integrate runs (the host's Integrate(); PrepareNextStep(); pair, InfiniTamDriver.h:137-158):
   // its LDS / atomic / latency phases hide under the VALU-bound integration.  dsr_prepare takes the result when list and
   // camera are still the ones it was computed for, else it recomputes on the main stream.  env DSR_OVERLAP_EXPECTED=0: off.
+  // Measured (profiles/r03j_range_image_overlap_ab.json): 1.176 vs 1.192 ms per frame.  K6's 1024-thread, 58 KB-LDS
+  // workgroups only find room as integration workgroups retire, so under a profiler its SPAN is the integration's (~510 us
+  // for ~40 us of work): a span, not a cost.  Tried on top: raised wave priority (s_setprio 3: no change — the waves are not
+  // resident, not slow) and the global-atomics kernel, whose 256-thread workgroups do co-reside (182 us) but whose atomics
+  // slow the integration to 692 us (profiles/r03m_*).
   hipStream_t sideStream = nullptr;
   hipEvent_t evList = nullptr, evExpected = nullptr;
   bool overlapExpected = true;
