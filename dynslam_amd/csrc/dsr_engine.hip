@@ -37,6 +37,7 @@ namespace {
 
 thread_local std::string g_err;
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
+std::atomic<int> g_enginesOnDevice[64];         // live engines per device (range-image overlap policy, allocate_scene)
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 #define HIP_TRY(expr)                                                                              \
@@ -207,11 +208,13 @@ struct dsr_engine {
   hipEvent_t hostUsedEvent = nullptr;
   bool hostUsedPending = false;
   long long hostUsedCallsSince = 0;              // swap-out batches enqueued since that read-back was issued
-  // silhouette masks handed over as HOST buffers (instance view split): a ring of pinned staging slots, each with its
-  // device twin.  The host copies the mask into a slot, the copy to the device is asynchronous, and the call returns
-  // without waiting for the stream: the caller's buffer is free again and the slot is only reused once its copy has run.
+  // silhouette masks handed over as HOST buffers (instance view split): a ring of pinned, device-mapped staging slots.
+  // The host copies the mask into a slot and the silhouette kernel reads it from there over the host link (10-20 KB,
+  // once): no copy command, no synchronisation — the caller's buffer is free when the call returns and a slot is reused
+  // only once the kernel that read it has run.  (A hipMemcpyAsync from the pinned slot into a device twin was measured
+  // first: the copy engine's hand-over to the compute queue costs ~40 us per mask, configs[2] 623 -> 505 frames/s.)
   static constexpr int kMaskSlots = 8;
-  uint8_t *maskHost = nullptr, *maskDev = nullptr;
+  uint8_t *maskHost = nullptr, *maskHostDev = nullptr;  // the ring and its device-side address
   size_t maskSlotBytes = 0;
   hipEvent_t maskEvent[kMaskSlots] = {};
   bool maskEventUsed[kMaskSlots] = {};
@@ -357,7 +360,7 @@ void free_all(dsr_engine *e) {
   }
   F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
-  F(e->fifoPlanes); F(e->decayCand); F(e->decayFlags); F(e->maskDev);
+  F(e->fifoPlanes); F(e->decayCand); F(e->decayFlags);
   if (e->maskHost) (void)hipHostFree(e->maskHost);
   for (auto ev : e->maskEvent) if (ev) (void)hipEventDestroy(ev);
   F(e->scene.swapState); F(e->scene.swapStored); F(e->swapStagingDev); F(e->swapIdsDev); F(e->swapFlagsDev);
@@ -465,7 +468,9 @@ int allocate_scene(dsr_engine *e) {
          (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks);
   HIP_TRY(hipGetLastError());
   e->liveExp.valid = false;
-  if (e->overlapExpected) {
+  // ... when this volume has the GPU to itself: with other volumes' engines on the device (a map + its instance volumes)
+  // their streams fill the phases the side stream would, and the extra stream only costs (configs[2]: 733 vs 686 frames/s)
+  if (e->overlapExpected && (e->device >= 64 || g_enginesOnDevice[e->device].load(std::memory_order_relaxed) <= 1)) {
     // the list is final: start the live view's range image on the side stream, under the integration that follows
     HIP_TRY(hipEventRecord(e->evList, e->stream));
     HIP_TRY(hipStreamWaitEvent(e->sideStream, e->evList, 0));
@@ -743,6 +748,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   else if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
   if (e->device >= nDev) { delete e; return fail(DSR_E_ARG, "device ordinal out of range"); }
   if (e->device < 64) g_devMask.fetch_or(1ull << e->device);
+  const int countedDevice = e->device;
   e->W = calib->depth.width; e->H = calib->depth.height; e->Wr = calib->rgb.width; e->Hr = calib->rgb.height;
   e->P = e->W * e->H;
   e->noBuckets = s.hash_bucket_num; e->noExcess = s.excess_list_size; e->E = e->noBuckets + e->noExcess;
@@ -773,15 +779,16 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
-  // the side stream gets the HIGHEST priority: its one short kernel pair needs whole compute units (1024-thread workgroups,
-  // 58 KB of LDS) and would otherwise only be placed when the integration, which fills every unit, drains
-  int prLeast = 0, prGreatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
-  if (const char *sp = getenv("DSR_SIDE_PRIORITY")) { if (atoi(sp) == 0) prGreatest = prLeast; }
-  if (hipStreamCreateWithPriority(&e->sideStream, hipStreamNonBlocking, prGreatest) != hipSuccess ||
-      hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
+  // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
+  // ones), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
+  // map + N instance volumes is N + 1 engines — with a (high-priority) side stream per engine `bench.py --instance-volumes 8`
+  // fell from 4900 to 1400 volume-frames/s, with plain ones to 4570 (profiles/r03n_*; GPU_MAX_HW_QUEUES tells the same story).
+  e->overlapExpected = s.sdf_local_block_num > 16384;
   if (const char *ov = getenv("DSR_OVERLAP_EXPECTED")) e->overlapExpected = atoi(ov) != 0;
+  if (e->overlapExpected &&
+      (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
   ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
   ALLOC(dmalloc(&e->scene.voxelAllocList, (size_t)e->noBlocks));
@@ -846,6 +853,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(reset_scene(e));
   if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "engine initialisation failed"); }
 #undef ALLOC
+  if (countedDevice < 64) g_enginesOnDevice[countedDevice].fetch_add(1);
   *out = e;
   return DSR_OK;
 }
@@ -855,6 +863,7 @@ void dsr_engine_destroy(dsr_engine *e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
+  if (e->device < 64) g_enginesOnDevice[e->device].fetch_sub(1);
   free_all(e);
   delete e;
 }
@@ -867,7 +876,7 @@ int dsr_reset_scene(dsr_engine *e) {
 int dsr_sync(dsr_engine *e) {
   CHECK_E(e);
   HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipStreamSynchronize(e->sideStream));
+  if (e->sideStream) HIP_TRY(hipStreamSynchronize(e->sideStream));
   return DSR_OK;
 }
 
@@ -1429,32 +1438,34 @@ int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *he
   return st;
 }
 
-// -> device pointer of the staged mask (see the ring's description in dsr_engine)
-static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h, const uint8_t **devOut) {
+// -> device-side address of the staged mask (see the ring's description in dsr_engine); `mask_slot_used` must be called
+// after the kernel that reads it has been enqueued
+static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h, const uint8_t **devOut, int *slotOut) {
   const size_t n = (size_t)box_w * box_h;
   if (e->maskSlotBytes < n) {  // grow: rare (a mask larger than any before) — drain, then reallocate the ring
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->maskHost) (void)hipHostFree(e->maskHost);
-    if (e->maskDev) (void)hipFree(e->maskDev);
-    e->maskHost = e->maskDev = nullptr; e->maskSlotBytes = 0;
+    e->maskHost = e->maskHostDev = nullptr; e->maskSlotBytes = 0;
     const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
-    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocMapped) != hipSuccess)
       return fail(DSR_E_NOMEM, "mask staging allocation failed");
-    int st = dmalloc(&e->maskDev, slot * dsr_engine::kMaskSlots);
-    if (st) return st;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&e->maskHostDev), e->maskHost, 0) != hipSuccess)
+      return fail(DSR_E_DEVICE, "mask staging is not device-visible");
     e->maskSlotBytes = slot;
     for (bool &u : e->maskEventUsed) u = false;
   }
   const int s = e->maskNext;
   e->maskNext = (s + 1) % dsr_engine::kMaskSlots;
   if (!e->maskEvent[s]) HIP_TRY(hipEventCreateWithFlags(&e->maskEvent[s], hipEventDisableTiming));
-  if (e->maskEventUsed[s]) HIP_TRY(hipEventSynchronize(e->maskEvent[s]));  // the copy that last read this slot (8 uploads ago)
+  if (e->maskEventUsed[s]) HIP_TRY(hipEventSynchronize(e->maskEvent[s]));  // the kernel that last read this slot (8 masks ago)
   memcpy(e->maskHost + (size_t)s * e->maskSlotBytes, mask, n);  // the caller's (pageable) buffer is free after this line
-  HIP_TRY(hipMemcpyAsync(e->maskDev + (size_t)s * e->maskSlotBytes, e->maskHost + (size_t)s * e->maskSlotBytes, n,
-                         hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipEventRecord(e->maskEvent[s], e->stream));
-  e->maskEventUsed[s] = true;
-  *devOut = e->maskDev + (size_t)s * e->maskSlotBytes;
+  *devOut = e->maskHostDev + (size_t)s * e->maskSlotBytes;
+  *slotOut = s;
+  return DSR_OK;
+}
+static int mask_slot_used(dsr_engine *e, int slot) {
+  HIP_TRY(hipEventRecord(e->maskEvent[slot], e->stream));
+  e->maskEventUsed[slot] = true;
   return DSR_OK;
 }
 
@@ -1467,8 +1478,9 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   if (instance->device != main_engine->device || instance->W != main_engine->W || instance->H != main_engine->H ||
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
     return fail(DSR_E_ARG, "main and instance engines must share GPU and image size");
+  int maskSlot = -1;
   if (!maskDev) {
-    int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev);
+    int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
   }
   dsr_engine *e = main_engine;
@@ -1483,6 +1495,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
          (const uchar4 *)e->rgb, (const float *)e->depth, instance->rgb, instance->depth, e->W, e->H,
          maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
+  if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
   if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(e->xEvent2, e->stream));
   HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent2, 0));
@@ -1505,13 +1518,15 @@ static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *
   if ((!mask && !maskDev) || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
+  int maskSlot = -1;
   if (!maskDev) {
-    int st = upload_mask(e, mask, box_w, box_h, &maskDev);
+    int st = upload_mask(e, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
   }
   LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
          e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
+  if (maskSlot >= 0) return mask_slot_used(e, maskSlot);
   return DSR_OK;
 }
 int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
