@@ -213,7 +213,7 @@ struct dsr_engine {
   // once): no copy command, no synchronisation — the caller's buffer is free when the call returns and a slot is reused
   // only once the kernel that read it has run.  (A hipMemcpyAsync from the pinned slot into a device twin was measured
   // first: the copy engine's hand-over to the compute queue costs ~40 us per mask, configs[2] 623 -> 505 frames/s.)
-  static constexpr int kMaskSlots = 8;
+  static constexpr int kMaskSlots = 32;  // two masks per instance and frame: a scene of up to 16 instances never waits on a slot
   uint8_t *maskHost = nullptr, *maskHostDev = nullptr;  // the ring and its device-side address
   size_t maskSlotBytes = 0;
   hipEvent_t maskEvent[kMaskSlots] = {};
@@ -1457,7 +1457,7 @@ static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h,
   const int s = e->maskNext;
   e->maskNext = (s + 1) % dsr_engine::kMaskSlots;
   if (!e->maskEvent[s]) HIP_TRY(hipEventCreateWithFlags(&e->maskEvent[s], hipEventDisableTiming));
-  if (e->maskEventUsed[s]) HIP_TRY(hipEventSynchronize(e->maskEvent[s]));  // the kernel that last read this slot (8 masks ago)
+  if (e->maskEventUsed[s]) HIP_TRY(hipEventSynchronize(e->maskEvent[s]));  // the kernel that last read this slot (kMaskSlots masks ago)
   memcpy(e->maskHost + (size_t)s * e->maskSlotBytes, mask, n);  // the caller's (pageable) buffer is free after this line
   *devOut = e->maskHostDev + (size_t)s * e->maskSlotBytes;
   *slotOut = s;
