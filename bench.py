@@ -491,7 +491,7 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
     scene.close()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -16,6 +16,11 @@ import ctypes as C
 import numpy as np
 
 
+def torch_empty_like_cpu(t):
+    import torch
+    return torch.empty(t.shape, dtype=t.dtype, device="cpu")
+
+
 def volume_owner(volume_index, world_size, has_static=True):
     """Owning rank of a volume.  With a static map (configs[3]): volume 0 = static map on rank 0, volume 1+k =
     instance k on rank 1 + (k mod (world-1)).  Without (north_star's "N concurrent instance volumes": every volume is an
@@ -94,6 +99,13 @@ class PreviewExchange:
             return
         # (with a process group the collective runs for a single rank too: `torchrun --nproc-per-node 1` exercises
         #  the RCCL path of the multi-GPU layout on a one-GPU box)
+        if self.all.is_cuda and dist.get_backend(self.group) != "nccl":
+            # a process group without device collectives (gloo: ranks on different hosts over TCP, or several ranks sharing
+            # one GPU in the tests): the layers are staged through host memory
+            host = torch_empty_like_cpu(self.all)
+            dist.all_gather_into_tensor(host, self.local.cpu(), group=self.group)
+            self.all.copy_(host)
+            return
         dist.all_gather_into_tensor(self.all, self.local, group=self.group)
 
     def ordered_layers(self, track_id_of_instance):

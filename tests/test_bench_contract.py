@@ -175,3 +175,25 @@ def test_cli_rank_failure_does_not_hang():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--width", "96", "--height", "32", "--preset", "5cm"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "no_such_backend" in p.stderr
+
+
+@pytest.mark.gpu
+def test_cli_gpus_2_with_hip_engines_on_one_gpu(hip_api):
+    """`python bench.py --gpus 2` on the GPU box with the REAL engines: two forked ranks, each with its own HIP engines on
+    cuda:0, masks in HBM, renders written into the exchange slots, the collective over gloo (RCCL refuses two ranks on one
+    device; its own path runs at world size 1 under torchrun), the HIP composite on rank 0 — the N > 1 code path end to end."""
+    import subprocess
+    import sys
+    env = dict(os.environ, DSR_BENCH_TEST_BACKEND="tests.bench_backend_hip_gloo", PYTHONPATH=ROOT, DSR_BENCH_NO_POOL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--width", "640", "--height", "192", "--preset", "5cm"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["unit"] == "volume-frames/s" and line["config"]["volumes_per_rank"] == [1, 1]
+    assert line["config"]["status"] == 0 and line["config"]["preview_hit_fraction"] > 0.001
+    assert line["time_sliced_1gpu"]["value"] > 0 and line["configs3"]["config"]["static_visible_blocks_last_frame"] > 100
+    assert line["configs3"]["config"]["preview_hit_fraction"] > 0.3

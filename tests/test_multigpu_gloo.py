@@ -110,7 +110,7 @@ SH_INST = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_f
 SH_VIEW = dict(SH_STATIC, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
 
 
-def _sharded_run(world, rank, n_volumes, group=None, has_static=True):
+def _sharded_run(world, rank, n_volumes, group=None, has_static=True, hip=False):
     from bench import _gen_frame
     from dynslam_amd.engine import make_calib
     from dynslam_amd.multigpu import ShardedScene
@@ -120,29 +120,44 @@ def _sharded_run(world, rank, n_volumes, group=None, has_static=True):
     sc = StreetScene(SH_W, SH_H, n_instances=n_inst)
     calib = make_calib(*sc.intrinsics(), SH_W, SH_H)
     kinds = {"static": SH_STATIC, "instance": SH_INST, "view": SH_VIEW}
-    scene = ShardedScene(lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib), SH_W, SH_H, n_volumes, world, rank,
-                         torch.device("cpu"), group, has_static=has_static)
-    scene.exchange.host_api = load_api()  # CPU composite = the oracle's restatement (tests only)
+    if hip:  # the real engines, every rank on cuda:0 (a one-GPU box), collectives over gloo staged through host memory
+        from dynslam_amd.engine import EngineCore, default_settings
+        torch.cuda.set_device(0)
+        scene = ShardedScene(lambda kind: EngineCore(default_settings(**kinds[kind], device=0, sync_status=0), calib), SH_W, SH_H,
+                             n_volumes, world, rank, torch.device("cuda", 0), group, has_static=has_static)
+    else:
+        scene = ShardedScene(lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib), SH_W, SH_H, n_volumes, world, rank,
+                             torch.device("cpu"), group, has_static=has_static)
+        scene.exchange.host_api = load_api()  # CPU composite = the oracle's restatement (tests only)
     track_ids = {k: 7 + 2 * k for k in range(n_inst)}
     out = None
     for i in range(SH_FRAMES):
         rgba, d, T, masks = _gen_frame((SH_W, SH_H, i, n_inst))
-        scene.step(rgba, d, T, masks)
+        if hip:  # frames and masks resident in HBM, as bench.py hands them over
+            keep = (torch.from_numpy(rgba).cuda(), torch.from_numpy(d).cuda(), [torch.from_numpy(np.ascontiguousarray(m[3])).cuda() for m in masks])
+            dev_masks = [(k, x0, y0, (t.data_ptr(), m.shape[1], m.shape[0]), rel) for (k, x0, y0, m, rel), t in zip(masks, keep[2])]
+            scene.step(keep[0].data_ptr(), keep[1].data_ptr(), T, dev_masks)
+            scene.sync()
+        else:
+            scene.step(rgba, d, T, masks)
         M = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
         inst_m = {k: np.linalg.inv(rel.astype(np.float64)).astype(np.float32) for k, _, _, _, rel in masks}
         out = scene.preview(M, inst_m, track_ids)
     res = None
+    if hip:
+        scene.sync()
+        torch.cuda.synchronize()
     if rank == 0:
-        res = (out[0].numpy().copy(), out[1].numpy().copy(), scene.exchange.all_depth.numpy().copy())
+        res = (out[0].cpu().numpy().copy(), out[1].cpu().numpy().copy(), scene.exchange.all_depth.cpu().numpy().copy())
     scene.close()
     return res
 
 
-def _sharded_worker(rank, world, port, n_volumes, out_dir, has_static=True):
+def _sharded_worker(rank, world, port, n_volumes, out_dir, has_static=True, hip=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = _sharded_run(world, rank, n_volumes, has_static=has_static)
+    res = _sharded_run(world, rank, n_volumes, has_static=has_static, hip=hip)
     if rank == 0:
         np.savez(os.path.join(out_dir, "sharded.npz"), rgba=res[0], depth=res[1], layers=res[2])
     dist.barrier()
@@ -177,3 +192,18 @@ def test_instance_volumes_sharded_equals_single_process(tmp_path, oracle_lib, wo
     hit = layers1 > 0
     nearest = np.where(hit, layers1, np.inf).min(axis=0)
     assert np.array_equal(np.where(np.isfinite(nearest), nearest, 0.0).astype(np.float32), depth1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n_volumes,has_static", [(2, 3, True), (3, 3, False)])
+def test_sharded_hip_engines_equal_single_process_and_oracle(tmp_path, hip_api, oracle_lib, world, n_volumes, has_static):
+    """The N > 1 path with the REAL engines: `world` processes, each with its own HIP engines on cuda:0 (a one-GPU box),
+    device-resident frames and masks, renders written into the exchange slots, gloo staging for the collective, the HIP
+    composite on rank 0 — the composited preview equals the one-process HIP run AND the one-process oracle run, bit for bit."""
+    mp.spawn(_sharded_worker, args=(world, _free_port(), n_volumes, str(tmp_path), has_static, True), nprocs=world, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    rgba1, depth1, layers1 = _sharded_run(1, 0, n_volumes, has_static=has_static, hip=True)
+    rgba0, depth0, layers0 = _sharded_run(1, 0, n_volumes, has_static=has_static, hip=False)
+    assert (depth0 > 0).any()
+    assert np.array_equal(depth1, depth0) and np.array_equal(rgba1, rgba0)  # one process: HIP == oracle
+    assert np.array_equal(got["depth"], depth0) and np.array_equal(got["rgba"], rgba0)  # sharded HIP == oracle
