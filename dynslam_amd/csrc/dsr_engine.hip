@@ -780,10 +780,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
   // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
-  // ones), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
+  // ones, not for a map at the reference's 5 cm / 2^18 blocks, whose whole frame is 0.24 ms), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
   // map + N instance volumes is N + 1 engines — with a (high-priority) side stream per engine `bench.py --instance-volumes 8`
   // fell from 4900 to 1400 volume-frames/s, with plain ones to 4570 (profiles/r03n_*; GPU_MAX_HW_QUEUES tells the same story).
-  e->overlapExpected = s.sdf_local_block_num > 16384;
+  e->overlapExpected = s.sdf_local_block_num >= (1 << 20);  // >= 4 GiB of voxels: fine voxels, integrations of hundreds of us
   if (const char *ov = getenv("DSR_OVERLAP_EXPECTED")) e->overlapExpected = atoi(ov) != 0;
   if (e->overlapExpected &&
       (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||

@@ -346,7 +346,11 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
-    const bool big = valid && bw * bh > 16;
+    // boxes of up to 144 cells are filled by the owning lane (fire-and-forget LDS atomics); the wave-cooperative path below
+    // costs a round of seven cross-lane broadcasts per box, SEQUENTIAL within the wave — with the 16-cell threshold this
+    // kernel shared with the global-atomics one, coarse voxels (5 cm: a block covers ~5 x 5 cells at 10 m) sent nearly
+    // every block down that path (32 us for ~5 k blocks at the reference's own operating point)
+    const bool big = valid && bw * bh > 144;
     auto fold = [&](int idx, int zmn, int zmx) {
       if (FILTER) {
         const int2 cur = cellsLds[idx];
