@@ -127,31 +127,39 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
       };
       if (p0 == -2) { p0 = resolve(h0, b0x, b0y, b0z); cache2.bx = b0x; cache2.by = b0y; cache2.bz = b0z; cache2.ptr = p0; }
       if (p1 == -2) { p1 = resolve(h1, b1x, b1y, b1z); cache2.bx = b1x; cache2.by = b1y; cache2.bz = b1z; cache2.ptr = p1; }
+      // The corner loads are UNCONDITIONAL (a missing block reads block 0 and the value is replaced afterwards): one load
+      // per `if (ptr >= 0)` made every load its own basic block with its own s_waitcnt vmcnt(0) — 4 or 8 SERIALISED round
+      // trips for this sample, paid by the whole wave whenever one of its 64 rays took this path (round 3, found in the ISA).
       const uint8_t *vb = s.vba + kOffSdf;
       float v[8];
       if (!fx) {
         // the straddle is in y or z: the x-pairs of corners stay inside one block each -> four dword loads
+        uint32_t w[4];
+        bool have[4];
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
           const int dy = (k >> 1) & 1, dz = k >> 2;
           const int ptr = ((fy && dy) || (fz && dz)) ? p1 : p0;
           const int lin = (ix & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-          v[k] = 32767.0f; v[k + 1] = 32767.0f;
-          if (ptr >= 0) {
-            const uint32_t w = load_pair(reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes) + lin);
-            v[k] = (float)(short)(w & 0xffffu); v[k + 1] = (float)(short)(w >> 16);
-          }
+          have[k >> 1] = ptr >= 0;
+          w[k >> 1] = load_pair(reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes) + lin);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          v[k] = have[k >> 1] ? (float)(short)(w[k >> 1] & 0xffffu) : 32767.0f;
+          v[k + 1] = have[k >> 1] ? (float)(short)(w[k >> 1] >> 16) : 32767.0f;
         }
       } else {
+        short sv[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-        const bool other = (fx && dx) || (fy && dy) || (fz && dz);
-        const int ptr = other ? p1 : p0;
-        const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-        v[k] = 32767.0f;
-        if (ptr >= 0) v[k] = (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + lin * 2);
-      }
+        for (int k = 0; k < 8; ++k) {
+          const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+          const int ptr = dx ? p1 : p0;  // fx is the only straddle here: the +x corners lie in the neighbour block
+          const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
+          sv[k] = *reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + lin * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (((k & 1) ? p1 : p0) >= 0) ? (float)sv[k] : 32767.0f;
       }
       res1 = (1.0f - cx) * v[0] + cx * v[1];
       res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
@@ -201,14 +209,18 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
     }
     const uint8_t *vb = s.vba + kOffSdf;
     float v[8];
+    short sv[8];
+    bool have[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 8; ++k) {  // unconditional loads, replaced afterwards (see the two-block path)
       const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
       const int ptr = bptr[((fx && dx) ? 1 : 0) | ((fy && dy) ? 2 : 0) | ((fz && dz) ? 4 : 0)];
       const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-      v[k] = 32767.0f;
-      if (ptr >= 0) v[k] = (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + lin * 2);
+      have[k] = ptr >= 0;
+      sv[k] = *reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + lin * 2);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = have[k] ? (float)sv[k] : 32767.0f;
     res1 = (1.0f - cx) * v[0] + cx * v[1];
     res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
     res2 = (1.0f - cx) * v[4] + cx * v[5];
