@@ -68,165 +68,97 @@ __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const 
 }
 
 // returns the trilinear combination BEFORE SDF_valueToFloat (the division by 32767)
+//
+// readFromSDF_float_interpolated reads the 8 corners of the cell one after the other — lookup, voxel, lookup, voxel ...: up to
+// 16 dependent round trips.  A lookup is a pure function of the table and a voxel read of the block array, so HOW the corners
+// are fetched cannot change a value; the combination at the end is the reference's expression order.
+//
+// Round 3 (found in the ISA, confirmed by SQ counters: the kernel's duration = VMEM instructions per wave x ~1.1 us, i.e.
+// every load of a wave is waited for before the next is issued): rounds 1-2 had three separate code paths here — cell inside
+// one block (2/3 of the samples), straddling two (29 %), four or eight (4 %) — which a wave with rays in all three executes ONE
+// AFTER THE OTHER, each with its own lookups and its own waits (a band iteration cost ~10 serialised round trips, with the
+// corner loads in their own `if (ptr >= 0)` blocks ~25).  Now every ray of the wave goes through the SAME two phases:
+//   1. resolve the blocks the cell touches — slot c = (ox, oy, oz) in {0,1}^3, needed iff the cell straddles in every axis
+//      where o = 1; blocks the march already knows (cache, cache2) cost nothing, the others are looked up in rounds of one
+//      bucket head per ray for all rays together;
+//   2. all corner loads of all rays issued back to back, unconditionally (a missing block reads block 0 and the value is
+//      replaced afterwards), ONE wait.
 __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
                                                            VoxCache &cache, VoxCache &cache2) {
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
-  float res1, res2;
-  if (((ix & 7) != 7) && ((iy & 7) != 7) && ((iz & 7) != 7)) {
-    // all 8 corners inside one voxel block (2/3 of the samples): ONE lookup, then the 8 sdf
-    // loads are independent and issued together instead of 8 dependent lookup+load pairs.
-    // (A lookup is a pure function of the table, so how the corners are fetched cannot
-    // change the values; the combination below is the reference's expression order.)
-    int lin;
-    const int ptr = find_block(s, p, ix, iy, iz, lin, cache);
-    float v[8];
+  const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
+  const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
+  int bp[8];  // block index per slot (-1: no such block); only the needed slots are meaningful
+  uint32_t need = 0;  // bit c: slot c has to be looked up
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 32767.0f;
-    if (ptr >= 0) {
-      // the two corners of a cell that differ in x are neighbouring shorts of the sdf plane: FOUR (possibly
-      // 2-byte aligned) dword loads fetch the 8 corners — half the gather instructions of 8 short loads
-      const short *b = reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf) + lin;
-      const uint32_t w0 = load_pair(b), w1 = load_pair(b + 8), w2 = load_pair(b + 64), w3 = load_pair(b + 72);
-      v[0] = (float)(short)(w0 & 0xffffu); v[1] = (float)(short)(w0 >> 16);
-      v[2] = (float)(short)(w1 & 0xffffu); v[3] = (float)(short)(w1 >> 16);
-      v[4] = (float)(short)(w2 & 0xffffu); v[5] = (float)(short)(w2 >> 16);
-      v[6] = (float)(short)(w3 & 0xffffu); v[7] = (float)(short)(w3 >> 16);
-    }
-    res1 = (1.0f - cx) * v[0] + cx * v[1];
-    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
-    res2 = (1.0f - cx) * v[4] + cx * v[5];
-    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
-    return (1.0f - cz) * res1 + cz * res2;
-  }
-  {
-    const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
-    if ((int)fx + (int)fy + (int)fz == 1) {
-      // the cell straddles exactly TWO blocks (29 % of the samples).  Either may be the block the
-      // march is in (cache) or the one a previous trilinear sample needed (cache2, which also
-      // remembers blocks that do NOT exist: the table does not change during the kernel); what is
-      // still unknown is looked up with the bucket heads of both blocks requested TOGETHER, then
-      // the 8 corner loads go out together — instead of 8 dependent lookup+load pairs.
-      const int b0x = ix >> 3, b0y = iy >> 3, b0z = iz >> 3;
-      const int b1x = b0x + (fx ? 1 : 0), b1y = b0y + (fy ? 1 : 0), b1z = b0z + (fz ? 1 : 0);
-      int p0 = -2, p1 = -2;  // -2: unknown, -1: no such block
-      if (b0x == cache.bx && b0y == cache.by && b0z == cache.bz) p0 = cache.ptr;
-      else if (b0x == cache2.bx && b0y == cache2.by && b0z == cache2.bz) p0 = cache2.ptr;
-      if (b1x == cache.bx && b1y == cache.by && b1z == cache.bz) p1 = cache.ptr;
-      else if (b1x == cache2.bx && b1y == cache2.by && b1z == cache2.bz) p1 = cache2.ptr;
-      int4 h0 = make_int4(0, 0, 0, -2), h1 = make_int4(0, 0, 0, -2);
-      if (p0 == -2) h0 = *reinterpret_cast<const int4 *>(s.table + hash_index(b0x, b0y, b0z, p.hashMask));
-      if (p1 == -2) h1 = *reinterpret_cast<const int4 *>(s.table + hash_index(b1x, b1y, b1z, p.hashMask));
-      auto resolve = [&](int4 raw, int bx, int by, int bz) -> int {  // ITMRepresentationAccess.h findVoxel
-        while (true) {
-          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-          if (hx == bx && hy == by && hz == bz && raw.w >= 0) return raw.w;
-          if (raw.z < 1) return -1;
-          raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
-        }
-      };
-      if (p0 == -2) { p0 = resolve(h0, b0x, b0y, b0z); cache2.bx = b0x; cache2.by = b0y; cache2.bz = b0z; cache2.ptr = p0; }
-      if (p1 == -2) { p1 = resolve(h1, b1x, b1y, b1z); cache2.bx = b1x; cache2.by = b1y; cache2.bz = b1z; cache2.ptr = p1; }
-      // The corner loads are UNCONDITIONAL (a missing block reads block 0 and the value is replaced afterwards): one load
-      // per `if (ptr >= 0)` made every load its own basic block with its own s_waitcnt vmcnt(0) — 4 or 8 SERIALISED round
-      // trips for this sample, paid by the whole wave whenever one of its 64 rays took this path (round 3, found in the ISA).
-      const uint8_t *vb = s.vba + kOffSdf;
-      float v[8];
-      if (!fx) {
-        // the straddle is in y or z: the x-pairs of corners stay inside one block each -> four dword loads
-        uint32_t w[4];
-        bool have[4];
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-          const int dy = (k >> 1) & 1, dz = k >> 2;
-          const int ptr = ((fy && dy) || (fz && dz)) ? p1 : p0;
-          const int lin = (ix & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-          have[k >> 1] = ptr >= 0;
-          w[k >> 1] = load_pair(reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes) + lin);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-          v[k] = have[k >> 1] ? (float)(short)(w[k >> 1] & 0xffffu) : 32767.0f;
-          v[k + 1] = have[k >> 1] ? (float)(short)(w[k >> 1] >> 16) : 32767.0f;
-        }
-      } else {
-        short sv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-          const int ptr = dx ? p1 : p0;  // fx is the only straddle here: the +x corners lie in the neighbour block
-          const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-          sv[k] = *reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + lin * 2);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (((k & 1) ? p1 : p0) >= 0) ? (float)sv[k] : 32767.0f;
-      }
-      res1 = (1.0f - cx) * v[0] + cx * v[1];
-      res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
-      res2 = (1.0f - cx) * v[4] + cx * v[5];
-      res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
-      return (1.0f - cz) * res1 + cz * res2;
+  for (int c = 0; c < 8; ++c) {
+    bp[c] = -1;
+    const bool needed = (!(c & 1) || fx) && (!(c & 2) || fy) && (!(c & 4) || fz);
+    const int bx = bx0 + (c & 1), by = by0 + ((c >> 1) & 1), bz = bz0 + (c >> 2);
+    if (needed) {  // a block the march is in, or one a previous sample resolved (cache2 also remembers absent blocks)
+      if (bx == cache.bx && by == cache.by && bz == cache.bz) bp[c] = cache.ptr;
+      else if (bx == cache2.bx && by == cache2.by && bz == cache2.bz) bp[c] = cache2.ptr;
+      else need |= 1u << c;
     }
   }
-  {
-    // the cell straddles 4 or 8 blocks (4 % of the samples).  The reference walks the 8 corners one
-    // after the other — lookup, voxel, lookup, voxel ...: up to 16 DEPENDENT round trips, during
-    // which the other 63 lanes of the wave wait.  Here the bucket heads of the blocks are requested two
-    // at a time (registers: the kernel must stay at 64 VGPRs), chains — rare — are then walked, and the
-    // 8 voxels are requested together: 3-5 round trips.  Lookups are pure functions of the table, so the values
-    // are the reference's.
-    const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
-    const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
-    int bptr[8];
-#pragma unroll
-    for (int pair = 0; pair < 4; ++pair) {  // blocks (ox, oy, oz) = (0|1, pair & 1, pair >> 1), two per pass
-      const int oy = pair & 1, oz = pair >> 1;
-      bptr[pair * 2] = -1; bptr[pair * 2 + 1] = -1;
-      if ((oy && !fy) || (oz && !fz)) continue;
-      int4 head[2];
-      bool want[2];
-#pragma unroll
-      for (int ox = 0; ox < 2; ++ox) {
-        want[ox] = !ox || fx;
-        if (want[ox]) {
-          const int bx = bx0 + ox, by = by0 + oy, bz = bz0 + oz;
-          if (bx == cache.bx && by == cache.by && bz == cache.bz) { bptr[pair * 2 + ox] = cache.ptr; want[ox] = false; }
-          else head[ox] = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
-        }
+  // rounds of ONE lookup per ray, all rays of the wave together: a round is one gather instruction and one wait for the whole
+  // wave; the number of rounds is the largest number of unknown blocks any ray has (0 or 1 for nearly all of them)
+  while (__any(need != 0)) {
+    if (need != 0) {
+      const int c = __ffs((int)need) - 1;
+      need &= need - 1;
+      const int bx = bx0 + (c & 1), by = by0 + ((c >> 1) & 1), bz = bz0 + (c >> 2);
+      int4 raw = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
+      int found = -1;
+      while (true) {  // ITMRepresentationAccess.h findVoxel
+        const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+        if (hx == bx && hy == by && hz == bz && raw.w >= 0) { found = raw.w; break; }
+        if (raw.z < 1) break;
+        raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
       }
 #pragma unroll
-      for (int ox = 0; ox < 2; ++ox) {
-        if (!want[ox]) continue;
-        const int bx = bx0 + ox, by = by0 + oy, bz = bz0 + oz;
-        int4 raw = head[ox];
-        while (true) {  // ITMRepresentationAccess.h findVoxel
-          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-          if (hx == bx && hy == by && hz == bz && raw.w >= 0) { bptr[pair * 2 + ox] = raw.w; break; }
-          if (raw.z < 1) break;
-          raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
-        }
-      }
+      for (int k = 0; k < 8; ++k) bp[k] = (k == c) ? found : bp[k];
+      cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
     }
-    const uint8_t *vb = s.vba + kOffSdf;
-    float v[8];
-    short sv[8];
-    bool have[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {  // unconditional loads, replaced afterwards (see the two-block path)
-      const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
-      const int ptr = bptr[((fx && dx) ? 1 : 0) | ((fy && dy) ? 2 : 0) | ((fz && dz) ? 4 : 0)];
-      const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
-      have[k] = ptr >= 0;
-      sv[k] = *reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + lin * 2);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = have[k] ? (float)sv[k] : 32767.0f;
-    res1 = (1.0f - cx) * v[0] + cx * v[1];
-    res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
-    res2 = (1.0f - cx) * v[4] + cx * v[5];
-    res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
-    return (1.0f - cz) * res1 + cz * res2;
   }
+  // corners: the two corners of an x-pair are neighbouring shorts of one block's sdf plane, so FOUR (possibly 2-byte aligned)
+  // dword loads fetch the 8 corners (half the gather instructions of 8 short loads); a ray that straddles in x takes its four
+  // +x corners from the x-neighbour blocks with four short loads more.  All loads are issued before the first is used.
+  const uint8_t *vb = s.vba + kOffSdf;
+  uint32_t w[4];
+  short hi[4] = {0, 0, 0, 0};
+  int pLo[4], pHi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int dy = k & 1, dz = k >> 1;
+    const int slotYZ = ((fy && dy) ? 2 : 0) | ((fz && dz) ? 4 : 0);
+    pLo[k] = slotYZ == 0 ? bp[0] : (slotYZ == 2 ? bp[2] : (slotYZ == 4 ? bp[4] : bp[6]));
+    pHi[k] = slotYZ == 0 ? bp[1] : (slotYZ == 2 ? bp[3] : (slotYZ == 4 ? bp[5] : bp[7]));
+    const int linYZ = (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
+    w[k] = load_pair(reinterpret_cast<const short *>(vb + (size_t)(pLo[k] >= 0 ? pLo[k] : 0) * kBlockBytes) + ((ix & 7) + linYZ));
+  }
+  if (fx) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int dy = k & 1, dz = k >> 1;
+      const int linYZ = (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);  // x = 0 of the neighbour block
+      hi[k] = *reinterpret_cast<const short *>(vb + (size_t)(pHi[k] >= 0 ? pHi[k] : 0) * kBlockBytes + linYZ * 2);
+    }
+  }
+  float v[8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    v[k * 2] = pLo[k] >= 0 ? (float)(short)(w[k] & 0xffffu) : 32767.0f;
+    const float inBlock = pLo[k] >= 0 ? (float)(short)(w[k] >> 16) : 32767.0f;
+    const float neighbour = pHi[k] >= 0 ? (float)hi[k] : 32767.0f;
+    v[k * 2 + 1] = fx ? neighbour : inBlock;
+  }
+  float res1 = (1.0f - cx) * v[0] + cx * v[1];
+  res1 = (1.0f - cy) * res1 + cy * ((1.0f - cx) * v[2] + cx * v[3]);
+  float res2 = (1.0f - cx) * v[4] + cx * v[5];
+  res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
+  return (1.0f - cz) * res1 + cz * res2;
 }
 __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
                                                        VoxCache &cache, VoxCache &cache2) {
