@@ -318,12 +318,25 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP 
   if (c.x == 0) return;
   int rank12 = tileOff.x + ex.x, rank2 = tileOff.y + ex.y;
   const int oldV = s.ctr[CTR_ALLOC_OLD_HEAD_VBA], oldE = s.ctr[CTR_ALLOC_OLD_HEAD_EXC];
+  // the group's 8 keys and 8 table pointers are requested TOGETHER (a load per loop iteration behind a `continue` is a basic
+  // block with its own wait: 16 serialised round trips for this thread, and its wave waits with it)
+  uint32_t key[kTileItems];
+  int ptrOf[kTileItems];
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j) {
+    const int t = base + j < p.noTotalEntries ? base + j : p.noTotalEntries - 1;
+    key[j] = s.allocKey[t];
+    ptrOf[j] = s.table[t].ptr;
+  }
+#pragma unroll
+  for (int j = 0; j < kTileItems; ++j)
+    if (base + j >= p.noTotalEntries) key[j] = 0u;
+#pragma unroll
   for (int j = 0; j < kTileItems; ++j) {
     const int t = base + j;
-    if (t >= p.noTotalEntries) break;
-    const uint32_t k = s.allocKey[t];
+    const uint32_t k = key[j];
     if (!k) continue;
-    const bool isExc = s.table[t].ptr >= -1;
+    const bool isExc = ptrOf[j] >= -1;
     s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
     const int vbaIdx = oldV - rank12;
     int exlIdx = 0;

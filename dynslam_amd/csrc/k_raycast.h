@@ -67,43 +67,25 @@ __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const 
   return sdf_to_float(v);
 }
 
-// returns the trilinear combination BEFORE SDF_valueToFloat (the division by 32767)
-//
-// readFromSDF_float_interpolated reads the 8 corners of the cell one after the other — lookup, voxel, lookup, voxel ...: up to
-// 16 dependent round trips.  A lookup is a pure function of the table and a voxel read of the block array, so HOW the corners
-// are fetched cannot change a value; the combination at the end is the reference's expression order.
-//
-// Round 3 (found in the ISA, confirmed by SQ counters: the kernel's duration = VMEM instructions per wave x ~1.1 us, i.e.
-// every load of a wave is waited for before the next is issued): rounds 1-2 had three separate code paths here — cell inside
-// one block (2/3 of the samples), straddling two (29 %), four or eight (4 %) — which a wave with rays in all three executes ONE
-// AFTER THE OTHER, each with its own lookups and its own waits (a band iteration cost ~10 serialised round trips, with the
-// corner loads in their own `if (ptr >= 0)` blocks ~25).  Now every ray of the wave goes through the SAME two phases:
-//   1. resolve the blocks the cell touches — slot c = (ox, oy, oz) in {0,1}^3, needed iff the cell straddles in every axis
-//      where o = 1; blocks the march already knows (cache, cache2) cost nothing, the others are looked up in rounds of one
-//      bucket head per ray for all rays together;
-//   2. all corner loads of all rays issued back to back, unconditionally (a missing block reads block 0 and the value is
-//      replaced afterwards), ONE wait.
-__device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                           VoxCache &cache, VoxCache &cache2) {
-  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
-  const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
-  const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
-  const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
-  int bp[8];  // block index per slot (-1: no such block); only the needed slots are meaningful
+// The blocks a 2x2x2 voxel cell with base block (bx0, by0, bz0) touches: slot c = (ox, oy, oz) in {0,1}^3 is needed iff the
+// cell straddles (f*) in every axis where o = 1.  Blocks the caller already knows (cache, cache2 — which also remembers
+// absent blocks) cost nothing; the others are looked up in ROUNDS of one bucket head per ray for all rays of the wave
+// together: a round is one gather instruction and one wait for the whole wave, and the number of rounds is the largest
+// number of unknown blocks any ray has (0 or 1 for nearly all of them).  bp[c] = block index or -1.
+__device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const FrameP &p, int bx0, int by0, int bz0, bool fx, bool fy,
+                                                    bool fz, const VoxCache &cache, VoxCache &cache2, int (&bp)[8]) {
   uint32_t need = 0;  // bit c: slot c has to be looked up
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     bp[c] = -1;
     const bool needed = (!(c & 1) || fx) && (!(c & 2) || fy) && (!(c & 4) || fz);
     const int bx = bx0 + (c & 1), by = by0 + ((c >> 1) & 1), bz = bz0 + (c >> 2);
-    if (needed) {  // a block the march is in, or one a previous sample resolved (cache2 also remembers absent blocks)
+    if (needed) {
       if (bx == cache.bx && by == cache.by && bz == cache.bz) bp[c] = cache.ptr;
       else if (bx == cache2.bx && by == cache2.by && bz == cache2.bz) bp[c] = cache2.ptr;
       else need |= 1u << c;
     }
   }
-  // rounds of ONE lookup per ray, all rays of the wave together: a round is one gather instruction and one wait for the whole
-  // wave; the number of rounds is the largest number of unknown blocks any ray has (0 or 1 for nearly all of them)
   while (__any(need != 0)) {
     if (need != 0) {
       const int c = __ffs((int)need) - 1;
@@ -122,6 +104,30 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
       cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
     }
   }
+}
+
+// returns the trilinear combination BEFORE SDF_valueToFloat (the division by 32767)
+//
+// readFromSDF_float_interpolated reads the 8 corners of the cell one after the other — lookup, voxel, lookup, voxel ...: up to
+// 16 dependent round trips.  A lookup is a pure function of the table and a voxel read of the block array, so HOW the corners
+// are fetched cannot change a value; the combination at the end is the reference's expression order.
+//
+// Round 3 (found in the ISA, confirmed by SQ counters: the kernel's duration = VMEM instructions per wave x ~1.1 us, i.e.
+// every load of a wave is waited for before the next is issued): rounds 1-2 had three separate code paths here — cell inside
+// one block (2/3 of the samples), straddling two (29 %), four or eight (4 %) — which a wave with rays in all three executes ONE
+// AFTER THE OTHER, each with its own lookups and its own waits (a band iteration cost ~10 serialised round trips, with the
+// corner loads in their own `if (ptr >= 0)` blocks ~25).  Now every ray of the wave goes through the SAME two phases:
+//   1. resolve the blocks the cell touches (resolve_cell_blocks above: rounds of one bucket head per ray, all rays together);
+//   2. all corner loads of all rays issued back to back, unconditionally (a missing block reads block 0 and the value is
+//      replaced afterwards), ONE wait.
+__device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                           VoxCache &cache, VoxCache &cache2) {
+  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+  const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
+  const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
+  const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
+  int bp[8];  // block index per slot (-1: no such block); only the needed slots are meaningful
+  resolve_cell_blocks(s, p, bx0, by0, bz0, fx, fy, fz, cache, cache2, bp);
   // corners: the two corners of an x-pair are neighbouring shorts of one block's sdf plane, so FOUR (possibly 2-byte aligned)
   // dword loads fetch the 8 corners (half the gather instructions of 8 short loads); a ray that straddles in x takes its four
   // +x corners from the x-neighbour blocks with four short loads more.  All loads are issued before the first is used.
@@ -634,8 +640,10 @@ __device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP 
   auto rd = [&](int dx, int dy, int dz) -> float {  // readVoxel(...).sdf as float; missing voxel: TVoxel() => 32767
     const int vx = ix + dx, vy = iy + dy, vz = iz + dz;
     const int ptr = bptr[((vx >> 3) - b0x) | (((vy >> 3) - b0y) << 1) | (((vz >> 3) - b0z) << 2)];
-    if (ptr < 0) return 32767.0f;
-    return (float)*reinterpret_cast<const short *>(vb + (size_t)ptr * kBlockBytes + (((vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6)) * 2));
+    // unconditional load (a missing block reads block 0, replaced below): a load per `if` is a basic block with its own wait,
+    // and the 32 reads of this function would be 32 serialised round trips
+    const short v = *reinterpret_cast<const short *>(vb + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + (((vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6)) * 2));
+    return ptr >= 0 ? (float)v : 32767.0f;
   };
 #define RD(dx, dy, dz) rd((dx), (dy), (dz))
   float4 front, back, tmp;
@@ -674,27 +682,44 @@ __device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP 
   return ret;
 }
 
-// ITMRepresentationAccess.h readFromSDF_color4u_interpolated (missing voxels: colour 0)
+// ITMRepresentationAccess.h readFromSDF_color4u_interpolated (missing voxels: colour 0).  The reference reads the 8 corners
+// one after the other (8 dependent lookup + load pairs); here the cell's blocks are resolved first (resolve_cell_blocks) and
+// the 8 colour words are loaded together, unconditionally (a missing block reads block 0 and contributes 0): the sums below
+// are the reference's, in its order.
 __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z) {
   VoxCache cache; cache_init(cache);
+  VoxCache cache2; cache_init(cache2);
   const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
+  const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
+  int bp[8];
+  resolve_cell_blocks(s, p, ix >> 3, iy >> 3, iz >> 3, fx, fy, fz, cache, cache2, bp);
+  uchar4 c[8];
+  bool have[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int dx = k & 1, dy = (k >> 1) & 1, dz = k >> 2;
+    const int slot = ((fx && dx) ? 1 : 0) | ((fy && dy) ? 2 : 0) | ((fz && dz) ? 4 : 0);
+    int ptr = bp[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) ptr = (slot == q) ? bp[q] : ptr;
+    const int lin = ((ix + dx) & 7) + (((iy + dy) & 7) << 3) + (((iz + dz) & 7) << 6);
+    have[k] = ptr >= 0;
+    c[k] = *reinterpret_cast<const uchar4 *>(s.vba + (size_t)(ptr >= 0 ? ptr : 0) * kBlockBytes + kOffClr + lin * 4);
+  }
   float rx = 0.0f, ry = 0.0f, rz = 0.0f;
-  auto acc = [&](int dx, int dy, int dz, float w) {
-    int lin;
-    int ptr = find_block(s, p, ix + dx, iy + dy, iz + dz, lin, cache);
-    uchar4 c = make_uchar4(0, 0, 0, 0);
-    if (ptr >= 0) c = *reinterpret_cast<const uchar4 *>(s.vba + (size_t)ptr * kBlockBytes + kOffClr + lin * 4);
-    rx += w * (float)c.x; ry += w * (float)c.y; rz += w * (float)c.z;
+  auto acc = [&](int k, float w) {
+    const uchar4 v = have[k] ? c[k] : make_uchar4(0, 0, 0, 0);
+    rx += w * (float)v.x; ry += w * (float)v.y; rz += w * (float)v.z;
   };
-  acc(0, 0, 0, (1.0f - cx) * (1.0f - cy) * (1.0f - cz));
-  acc(1, 0, 0, (cx) * (1.0f - cy) * (1.0f - cz));
-  acc(0, 1, 0, (1.0f - cx) * (cy) * (1.0f - cz));
-  acc(1, 1, 0, (cx) * (cy) * (1.0f - cz));
-  acc(0, 0, 1, (1.0f - cx) * (1.0f - cy) * cz);
-  acc(1, 0, 1, (cx) * (1.0f - cy) * cz);
-  acc(0, 1, 1, (1.0f - cx) * (cy) * cz);
-  acc(1, 1, 1, (cx) * (cy) * cz);
+  acc(0, (1.0f - cx) * (1.0f - cy) * (1.0f - cz));
+  acc(1, (cx) * (1.0f - cy) * (1.0f - cz));
+  acc(2, (1.0f - cx) * (cy) * (1.0f - cz));
+  acc(3, (cx) * (cy) * (1.0f - cz));
+  acc(4, (1.0f - cx) * (1.0f - cy) * cz);
+  acc(5, (cx) * (1.0f - cy) * cz);
+  acc(6, (1.0f - cx) * (cy) * cz);
+  acc(7, (cx) * (cy) * cz);
   return make_float3(rx / 255.0f, ry / 255.0f, rz / 255.0f);
 }
 
