@@ -155,6 +155,10 @@ __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const fl
       if (i0 + k < r.noSteps) head[k] = load_entry(s.table, ch[k]);
       px += r.dx; py += r.dy; pz += r.dz;
     }
+    // what each of the four steps marks for allocation: entry index (kNoTarget: nothing) and whether it is a chain append
+    constexpr uint32_t kNoTarget = 0xffffffffu;
+    uint32_t tgt[4] = {kNoTarget, kNoTarget, kNoTarget, kNoTarget};
+    bool exc[4] = {false, false, false, false};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k;
@@ -184,16 +188,27 @@ __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const fl
           const bool isExcess = firstFree < 0;
           const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
           if (!isExcess) visType[target] = 1;
-          const uint32_t step = (uint32_t)i;  // < maxSteps (checked above)
-          // the first writer of an entry in this frame (its key is still 0) also counts it: per group
-          // of 8 entries and per sweep tile, so that the commit finds the ~1 % marked entries
-          // without reading all the keys
-          if (atomicMax(&s.allocKey[target], keyBase + step) == 0u) {
-            const uint32_t one = isExcess ? 0x11u : 0x01u;
-            atomicAdd(&s.allocGrp[target >> 5], one << (((target >> 3) & 3u) * 8u));
-            atomicAdd(&s.allocTile[target / (uint32_t)kTile], isExcess ? 0x100000001ull : 1ull);
-          }
+          tgt[k] = target; exc[k] = isExcess;
         }
+      }
+    }
+    // The order keys of the (up to) four steps go out TOGETHER and their results are looked at afterwards: an atomic whose
+    // result is used inside its own `if` is a basic block with its own wait — four serialised round trips per batch for the
+    // wave.  Atomics of one lane on one address are performed in program order, so when two steps of a ray name the same
+    // entry the first still sees 0 and counts it, the second does not.  (Sending the idle steps to one spare word instead of
+    // predicating them was tried: 16 ms of same-address contention.)
+    uint32_t old[4] = {1u, 1u, 1u, 1u};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tgt[k] != kNoTarget) old[k] = atomicMax(&s.allocKey[tgt[k]], keyBase + (uint32_t)(i0 + k));  // step < maxSteps (checked above)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // the first writer of an entry in this frame (its key was still 0) also counts it: per group of 8 entries and per sweep
+      // tile, so that the commit finds the ~1 % marked entries without reading all the keys
+      if (tgt[k] != kNoTarget && old[k] == 0u) {
+        const uint32_t one = exc[k] ? 0x11u : 0x01u;
+        atomicAdd(&s.allocGrp[tgt[k] >> 5], one << (((tgt[k] >> 3) & 3u) * 8u));
+        atomicAdd(&s.allocTile[tgt[k] / (uint32_t)kTile], exc[k] ? 0x100000001ull : 1ull);
       }
     }
   }

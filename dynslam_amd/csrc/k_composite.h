@@ -41,19 +41,32 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
     }
   }
   const double colStrength = 1.0 + (double)0.50f - (double)c.tintStrength;
-  for (int l = 0; l < c.nLayers; ++l) {
-    const float s = PTRS ? lp.depth[l][i] : lDepth[(size_t)l * c.nPixels + i];
-    const bool onTop = (s != 0.0f) && (t == 0.0f || t > s);
-    if (!onTop) continue;
-    t = s;
-    if (tRgba) {
-      const uchar4 sc = PTRS ? lp.rgba[l][i] : lRgba[(size_t)l * c.nPixels + i];
-      const uchar4 tint = c.tint[l];
-      const double r = fmin(255.0, (double)sc.x * colStrength + (double)((float)tint.x * c.tintStrength));
-      const double g = fmin(255.0, (double)sc.y * colStrength + (double)((float)tint.y * c.tintStrength));
-      const double b = fmin(255.0, (double)sc.z * colStrength + (double)((float)tint.z * c.tintStrength));
-      col.x = (unsigned char)r; col.y = (unsigned char)g; col.z = (unsigned char)b;
+  // The serial loop overwrites the colour every time a layer wins the pixel, so the result is the colour of the LAST winner:
+  // the depth walk (four layers' depths requested together: a load per loop iteration is waited for before the next is issued)
+  // only has to remember which layer that was, and ONE colour read follows it.
+  int winner = -1;
+  for (int l0 = 0; l0 < c.nLayers; l0 += 4) {
+    float s4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int l = l0 + k < c.nLayers ? l0 + k : c.nLayers - 1;
+      s4[k] = PTRS ? lp.depth[l][i] : lDepth[(size_t)l * c.nPixels + i];
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (l0 + k >= c.nLayers) break;
+      const float s = s4[k];
+      const bool onTop = (s != 0.0f) && (t == 0.0f || t > s);
+      if (onTop) { t = s; winner = l0 + k; }
+    }
+  }
+  if (tRgba && winner >= 0) {
+    const uchar4 sc = PTRS ? lp.rgba[winner][i] : lRgba[(size_t)winner * c.nPixels + i];
+    const uchar4 tint = c.tint[winner];
+    const double r = fmin(255.0, (double)sc.x * colStrength + (double)((float)tint.x * c.tintStrength));
+    const double g = fmin(255.0, (double)sc.y * colStrength + (double)((float)tint.y * c.tintStrength));
+    const double b = fmin(255.0, (double)sc.z * colStrength + (double)((float)tint.z * c.tintStrength));
+    col.x = (unsigned char)r; col.y = (unsigned char)g; col.z = (unsigned char)b;
   }
   tDepth[i] = t;
   if (tRgba) tRgba[i] = col;
