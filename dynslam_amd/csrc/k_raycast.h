@@ -19,7 +19,7 @@ struct VoxCache {  // ITMVoxelBlockHash::IndexCache
   int bx, by, bz;
   int ptr;  // block index
 };
-__device__ __forceinline__ void cache_init(VoxCache &c) { c.bx = c.by = c.bz = 0x7fffffff; c.ptr = -1; }
+__host__ __device__ __forceinline__ void cache_init(VoxCache &c) { c.bx = c.by = c.bz = 0x7fffffff; c.ptr = -1; }
 
 // ITMRepresentationAccess.h readVoxel (with per-thread cache): returns the block index
 // holding voxel (x,y,z) or -1; linearIdx is the offset inside the block.
@@ -53,13 +53,13 @@ __device__ __forceinline__ float read_sdf_raw(const SceneP &s, const FrameP &p, 
 
 // two neighbouring shorts of an sdf plane with ONE load (the address is only 2-byte aligned: unaligned dword
 // access is supported for global memory on gfx9 and the compiler emits a single global_load_dword)
-__device__ __forceinline__ uint32_t load_pair(const short *p) {
+__host__ __device__ __forceinline__ uint32_t load_pair(const short *p) {
   uint32_t w;
   __builtin_memcpy(&w, p, 4);
   return w;
 }
 
-__device__ __forceinline__ float roundf_itm(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }  // ROUND()
+__host__ __device__ __forceinline__ float roundf_itm(float x) { return (x < 0) ? (x - 0.5f) : (x + 0.5f); }  // ROUND()
 
 __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
                                                          bool &found, VoxCache &cache) {
@@ -67,13 +67,49 @@ __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const 
   return sdf_to_float(v);
 }
 
+// How the march converts float -> int, rounds down and asks "any ray of the wave": the device's instructions here, a one-ray
+// host stand-in in tests/hostsim (which runs cast_ray on the CPU against the oracle's raycast).
+struct DeviceOps {
+  static __device__ __forceinline__ int f2i(float f) { return dsr::f2i(f); }
+  static __device__ __forceinline__ bool any(bool b) { return __any(b) != 0; }
+  static __device__ __forceinline__ float sqrt(float f) { return sqrtf(f); }
+  static __device__ __forceinline__ float floor(float f) { return floorf(f); }
+};
+
+constexpr uint32_t kMapIdx = 0x80000000u;  // marks a block-map index (table indices are < 2^31)
+
+// One step of "which block holds (bx, by, bz)": look at the 16-byte entry `raw` read from `idx` (kMapIdx | slot of the block
+// map, or a table index).  Returns true when the question is answered (ptr = block or -1), else idx = the next entry to read.
+__host__ __device__ __forceinline__ bool lookup_step(const FrameP &p, const int4 &raw, int bx, int by, int bz, uint32_t &idx, int &ptr) {
+  if (idx & kMapIdx) {
+    const int ans = occ_answer(raw, bx, by, bz);
+    if (ans != -2) { ptr = ans; return true; }
+    idx = hash_index(bx, by, bz, p.hashMask);  // conflicted slot: the table knows
+    return false;
+  }
+  // ITMRepresentationAccess.h findVoxel
+  const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+  if (hx == bx && hy == by && hz == bz && raw.w >= 0) { ptr = raw.w; return true; }
+  if (raw.z < 1) { ptr = -1; return true; }
+  idx = (uint32_t)(p.noBuckets + raw.z - 1);
+  return false;
+}
+__host__ __device__ __forceinline__ uint32_t lookup_start(const FrameP &p, const SceneP &s, int bx, int by, int bz) {
+  return s.occ ? (kMapIdx | occ_index(bx, by, bz, s.occMask)) : hash_index(bx, by, bz, p.hashMask);
+}
+__host__ __device__ __forceinline__ const int4 *lookup_entry(const SceneP &s, uint32_t idx) {
+  return (idx & kMapIdx) ? reinterpret_cast<const int4 *>(s.occ) + (idx & ~kMapIdx) : reinterpret_cast<const int4 *>(s.table) + idx;
+}
+
 // The blocks a 2x2x2 voxel cell with base block (bx0, by0, bz0) touches: slot c = (ox, oy, oz) in {0,1}^3 is needed iff the
 // cell straddles (f*) in every axis where o = 1.  Blocks the caller already knows (cache, cache2 — which also remembers
-// absent blocks) cost nothing; the others are looked up in ROUNDS of one bucket head per ray for all rays of the wave
-// together: a round is one gather instruction and one wait for the whole wave, and the number of rounds is the largest
-// number of unknown blocks any ray has (0 or 1 for nearly all of them).  bp[c] = block index or -1.
-__device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const FrameP &p, int bx0, int by0, int bz0, bool fx, bool fy,
-                                                    bool fz, const VoxCache &cache, VoxCache &cache2, int (&bp)[8]) {
+// absent blocks) cost nothing; the others are looked up in ROUNDS of one 16-byte entry per ray for all rays of the wave
+// together (block map first, dsr_device.h; table and its chains only behind a conflicted slot): a round is one gather
+// instruction and one wait for the whole wave, and the number of rounds is the largest number of entries any ray needs
+// (0 or 1 for nearly all of them).  bp[c] = block index or -1.
+template <class Ops>
+__host__ __device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const FrameP &p, int bx0, int by0, int bz0, bool fx, bool fy,
+                                                             bool fz, const VoxCache &cache, VoxCache &cache2, int (&bp)[8]) {
   uint32_t need = 0;  // bit c: slot c has to be looked up
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
@@ -86,22 +122,22 @@ __device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const Frame
       else need |= 1u << c;
     }
   }
-  while (__any(need != 0)) {
+  uint32_t idx = 0u;
+  bool walking = false;  // idx is an entry of the current slot's walk
+  while (Ops::any(need != 0)) {
     if (need != 0) {
-      const int c = __ffs((int)need) - 1;
-      need &= need - 1;
+      const int c = __builtin_ctz(need);
       const int bx = bx0 + (c & 1), by = by0 + ((c >> 1) & 1), bz = bz0 + (c >> 2);
-      int4 raw = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
+      if (!walking) { idx = lookup_start(p, s, bx, by, bz); walking = true; }
+      const int4 raw = *lookup_entry(s, idx);
       int found = -1;
-      while (true) {  // ITMRepresentationAccess.h findVoxel
-        const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-        if (hx == bx && hy == by && hz == bz && raw.w >= 0) { found = raw.w; break; }
-        if (raw.z < 1) break;
-        raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
-      }
+      if (lookup_step(p, raw, bx, by, bz, idx, found)) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) bp[k] = (k == c) ? found : bp[k];
-      cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
+        for (int k = 0; k < 8; ++k) bp[k] = (k == c) ? found : bp[k];
+        cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
+        need &= need - 1;
+        walking = false;
+      }
     }
   }
 }
@@ -120,14 +156,15 @@ __device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const Frame
 //   1. resolve the blocks the cell touches (resolve_cell_blocks above: rounds of one bucket head per ray, all rays together);
 //   2. all corner loads of all rays issued back to back, unconditionally (a missing block reads block 0 and the value is
 //      replaced afterwards), ONE wait.
-__device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                           VoxCache &cache, VoxCache &cache2) {
-  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+template <class Ops>
+__host__ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                                    VoxCache &cache, VoxCache &cache2) {
+  const int ix = Ops::f2i(Ops::floor(x)), iy = Ops::f2i(Ops::floor(y)), iz = Ops::f2i(Ops::floor(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
   const int bx0 = ix >> 3, by0 = iy >> 3, bz0 = iz >> 3;
   int bp[8];  // block index per slot (-1: no such block); only the needed slots are meaningful
-  resolve_cell_blocks(s, p, bx0, by0, bz0, fx, fy, fz, cache, cache2, bp);
+  resolve_cell_blocks<Ops>(s, p, bx0, by0, bz0, fx, fy, fz, cache, cache2, bp);
   // corners: the two corners of an x-pair are neighbouring shorts of one block's sdf plane, so FOUR (possibly 2-byte aligned)
   // dword loads fetch the 8 corners (half the gather instructions of 8 short loads); a ray that straddles in x takes its four
   // +x corners from the x-neighbour blocks with four short loads more.  All loads are issued before the first is used.
@@ -168,7 +205,7 @@ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP &s, cons
 }
 __device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
                                                        VoxCache &cache, VoxCache &cache2) {
-  return sdf_to_float(read_sdf_interpolated_raw(s, p, x, y, z, cache, cache2));
+  return sdf_to_float(read_sdf_interpolated_raw<DeviceOps>(s, p, x, y, z, cache, cache2));
 }
 
 // --------------------------------------------------------- K6: expected depths
@@ -394,25 +431,35 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
 #define DSR_RAYCAST_PREFETCH 1
 #endif
 
+// -DDSR_RAYCAST_STATS (tools/raycast_wave_stats.py, never the product build): per-wave clocks and stage counts of the march
+#ifdef DSR_RAYCAST_STATS
+__device__ unsigned int *g_rcStats;  // 12 words per wave
+struct RcStats { unsigned nIter = 0, nLook = 0, nVox = 0, nBand = 0, wLook = 0, wBand = 0, wHead = 0, wChain = 0; };
+#define RC_STAT(...) __VA_ARGS__
+#else
+#define RC_STAT(...)
+#endif
+
 // ITMVisualisationEngine.h castRay
-__device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int x, int y, float2 mm) {
+template <class Ops>
+__host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int x, int y, float2 mm RC_STAT(, RcStats &st)) {
   const float oneOverVoxelSize = 1.0f / p.voxelSize;
   const float invFx = 1.0f / p.proj.x, invFy = 1.0f / p.proj.y;
   const float stepScale = p.mu * oneOverVoxelSize;
   float cz = mm.x;
   float cx = cz * (((float)x - p.proj.z) * invFx);
   float cy = cz * (((float)y - p.proj.w) * invFy);
-  float totalLength = sqrtf(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
+  float totalLength = Ops::sqrt(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
   float3 t = mat_mul3(p.invM, cx, cy, cz, 1.0f);
   float sx = t.x * oneOverVoxelSize, sy = t.y * oneOverVoxelSize, sz = t.z * oneOverVoxelSize;
   cz = mm.y;
   cx = cz * (((float)x - p.proj.z) * invFx);
   cy = cz * (((float)y - p.proj.w) * invFy);
-  float totalLengthMax = sqrtf(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
+  float totalLengthMax = Ops::sqrt(cx * cx + cy * cy + cz * cz) * oneOverVoxelSize;
   t = mat_mul3(p.invM, cx, cy, cz, 1.0f);
   float ex = t.x * oneOverVoxelSize, ey = t.y * oneOverVoxelSize, ez = t.z * oneOverVoxelSize;
   float dx = ex - sx, dy = ey - sy, dz = ez - sz;
-  float direction_norm = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  float direction_norm = 1.0f / Ops::sqrt(dx * dx + dy * dy + dz * dz);
   dx *= direction_norm; dy *= direction_norm; dz *= direction_norm;
 
   float rx = sx, ry = sy, rz = sz;
@@ -421,7 +468,7 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
   float sdfValue = 1.0f, stepLength;
   bool hash_found;
 #if DSR_RAYCAST_PREFETCH
-  uint32_t pfIdx = 0xffffffffu;  // table index of the prefetched entry
+  uint32_t pfIdx = 0xffffffffu;  // index of the entry in the look-ahead slot: a table index, or kMapIdx | a block-map slot
   int4 pfRaw = make_int4(0, 0, 0, -2);
 #endif
   while (totalLength < totalLengthMax) {
@@ -430,38 +477,45 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
     //  phases, so the single uninterpolated load per far step stays.)
 #if DSR_RAYCAST_PREFETCH
     {
-      // readFromSDF_float_uninterpolated with a one-step look-ahead on the hash table: the bucket
-      // head the NEXT sample will need (guessing the usual step: 8 voxels after a miss, mu/voxel
-      // when the block is in front of the surface, sdf = 1) is requested together with this
-      // sample's voxel, so a correct guess turns lookup -> voxel into one round trip per step.
-      // A wrong guess costs one unused 16-byte read; values are never affected.
-      const int vx = f2i(roundf_itm(rx)), vy = f2i(roundf_itm(ry)), vz = f2i(roundf_itm(rz));
+      // readFromSDF_float_uninterpolated.  Which block holds the sample is answered by the ray's one-block cache, else by
+      // the block map (dsr_device.h: one 16-byte read says "this block" or "no such block"), else — behind a conflicted slot
+      // of the map, or without a map — by the table and its chains.  The entries a ray reads are all 16 bytes, and every ray
+      // of the wave issues whichever one it needs next from ONE load instruction per round, so a round costs the wave one
+      // wait however its rays are spread over the cases.
+      // One-step look-ahead: the entry the NEXT sample will need (guessing the usual step: 8 voxels after a miss, mu/voxel
+      // when the block is in front of the surface, sdf = 1) is requested together with this sample's voxel, so a correct
+      // guess turns lookup -> voxel into one round trip per step.  A wrong guess costs one unused 16-byte read; values are
+      // never affected.
+      const int vx = Ops::f2i(roundf_itm(rx)), vy = Ops::f2i(roundf_itm(ry)), vz = Ops::f2i(roundf_itm(rz));
       const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
-      int ptr;
+      int ptr = -1;
+      uint32_t idx = 0u;
+      bool want = false;  // an entry has to be looked at
+      RC_STAT(++st.nIter;)
       if (bx == cache.bx && by == cache.by && bz == cache.bz) ptr = cache.ptr;
-      else {
-        uint32_t h = hash_index(bx, by, bz, p.hashMask);
-        int4 raw = (h == pfIdx) ? pfRaw : *reinterpret_cast<const int4 *>(s.table + h);
-        ptr = -1;
-        while (true) {
-          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-          if (hx == bx && hy == by && hz == bz && raw.w >= 0) {
-            cache.bx = bx; cache.by = by; cache.bz = bz; cache.ptr = raw.w; ptr = raw.w;
-            break;
+      else { want = true; idx = lookup_start(p, s, bx, by, bz); }
+      while (Ops::any(want)) {
+        RC_STAT(st.wLook += __any(want && idx != pfIdx) ? 1u : 0u;
+                st.wHead += __any(want && idx != pfIdx && ((idx & kMapIdx) || idx < (uint32_t)p.noBuckets)) ? 1u : 0u;
+                st.wChain += __any(want && idx != pfIdx && !(idx & kMapIdx) && idx >= (uint32_t)p.noBuckets) ? 1u : 0u;)
+        if (want) {
+          RC_STAT(if (idx != pfIdx) ++st.nLook;)
+          const int4 raw = (idx == pfIdx) ? pfRaw : *lookup_entry(s, idx);
+          if (lookup_step(p, raw, bx, by, bz, idx, ptr)) {
+            want = false;
+            if (ptr >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.ptr = ptr; }
           }
-          if (raw.z < 1) break;
-          h = (uint32_t)(p.noBuckets + raw.z - 1);
-          raw = *reinterpret_cast<const int4 *>(s.table + h);
         }
       }
       hash_found = ptr >= 0;
+      RC_STAT(st.nVox += hash_found ? 1u : 0u;)
       {
         const float g = hash_found ? stepScale : (float)kBlockSize;
-        const int nx = f2i(roundf_itm(rx + g * dx)) >> 3, ny = f2i(roundf_itm(ry + g * dy)) >> 3,
-                  nz = f2i(roundf_itm(rz + g * dz)) >> 3;
+        const int nx = Ops::f2i(roundf_itm(rx + g * dx)) >> 3, ny = Ops::f2i(roundf_itm(ry + g * dy)) >> 3,
+                  nz = Ops::f2i(roundf_itm(rz + g * dz)) >> 3;
         if (nx != bx || ny != by || nz != bz) {
-          pfIdx = hash_index(nx, ny, nz, p.hashMask);
-          pfRaw = *reinterpret_cast<const int4 *>(s.table + pfIdx);
+          pfIdx = lookup_start(p, s, nx, ny, nz);
+          pfRaw = *lookup_entry(s, pfIdx);
         }
         // (measured and rejected: a second look-ahead slot during runs of misses, 580 us vs 515 us;
         //  four bucket heads at once after 8 misses in a row, 631 us; a fire-and-forget prefetch
@@ -477,9 +531,12 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
         //  step's own voxel load whenever the previous step was inside the interpolation band (one round trip per band
         //  step instead of two, no extra loads when the guess holds), 441-443 vs 429 us, and requesting the NEXT step's
         //  voxel one iteration ahead in saturated space, 518 us (7 spilled registers at the 64-VGPR limit), both 543 us
-        //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact).  Every variant
-        //  that adds requests or iterations loses: the march is bound by gather-request
-        //  throughput and by the per-wave chain of dependent round trips.)
+        //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact); an occupancy BITMAP per 4x4x4-block cell in
+        //  front of the table (a clear bit = no such block, no read at all: -21 % bytes fetched, but one more dependent
+        //  round for every block that exists: 536 vs 461 us); rays advancing independently through a per-ray state
+        //  machine, one read per ray and round instead of the lockstep loop (a wave needs as many rounds as its neediest
+        //  ray has reads, 35 instead of 105 stages — and ~4x the instructions: 798 vs 461 us;
+        //  profiles/r03_raycast_rounds_variant.h.txt, r03_raycast_rounds_ab.log).)
       }
       float raw16 = 32767.0f;
       if (hash_found) {
@@ -491,12 +548,13 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
 #else
     sdfValue = read_sdf_uninterpolated(s, p, rx, ry, rz, hash_found, cache);
 #endif
+    RC_STAT(const bool inBand = hash_found && (sdfValue <= 0.1f) && (sdfValue >= -0.5f); st.nBand += inBand ? 1u : 0u; st.wBand += __any(inBand) ? 1u : 0u;)
     if (!hash_found) {
       stepLength = (float)kBlockSize;
     } else {
       // (experiment, round 3: without this interpolated read the kernel takes 331 instead of 404 us — the band phases are 18 %
       //  of it; the rest is the plain march: one or two dependent gathers per step at ~3.6 TB/s of scattered 128-byte fetches)
-      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = sdf_to_float_short(read_sdf_interpolated_raw(s, p, rx, ry, rz, cache, cache2));
+      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f)) sdfValue = sdf_to_float_short(read_sdf_interpolated_raw<Ops>(s, p, rx, ry, rz, cache, cache2));
       if (sdfValue <= 0.0f) break;
       float ss = sdfValue * stepScale;
       stepLength = (ss > 1.0f) ? ss : 1.0f;  // MAX(sdfValue * stepScale, 1.0f)
@@ -508,7 +566,7 @@ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int
   if (sdfValue <= 0.0f) {
     stepLength = sdfValue * stepScale;
     rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
-    sdfValue = sdf_to_float_short(read_sdf_interpolated_raw(s, p, rx, ry, rz, cache, cache2));
+    sdfValue = sdf_to_float_short(read_sdf_interpolated_raw<Ops>(s, p, rx, ry, rz, cache, cache2));
     stepLength = sdfValue * stepScale;
     rx += stepLength * dx; ry += stepLength * dy; rz += stepLength * dz;
     out.w = 1.0f;
@@ -531,7 +589,29 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
   if (x >= p.W || y >= p.H) return;
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];
-  raycastResult[x + y * p.W] = cast_ray(p, s, x, y, mm);
+#ifdef DSR_RAYCAST_STATS
+  const unsigned long long t0 = wall_clock64();
+  RcStats st;
+  raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm, st);
+  const unsigned long long t1 = wall_clock64();
+  // own stages of a lane, were the lanes decoupled: one per table read, voxel read and band read
+  unsigned own = st.nLook + st.nVox + st.nBand, iter = st.nIter, look = st.nLook, vox = st.nVox, band = st.nBand, sumIter = st.nIter;
+  for (int d = 1; d < 64; d <<= 1) {
+    own = max(own, (unsigned)__shfl_xor((int)own, d)); iter = max(iter, (unsigned)__shfl_xor((int)iter, d));
+    st.wLook = max(st.wLook, (unsigned)__shfl_xor((int)st.wLook, d)); st.wBand = max(st.wBand, (unsigned)__shfl_xor((int)st.wBand, d));
+    st.wHead = max(st.wHead, (unsigned)__shfl_xor((int)st.wHead, d)); st.wChain = max(st.wChain, (unsigned)__shfl_xor((int)st.wChain, d));
+    look = max(look, (unsigned)__shfl_xor((int)look, d)); vox = max(vox, (unsigned)__shfl_xor((int)vox, d));
+    band = max(band, (unsigned)__shfl_xor((int)band, d)); sumIter += (unsigned)__shfl_xor((int)sumIter, d);
+  }
+  const unsigned nLanes = (unsigned)__popcll(__ballot(1));
+  if (lane == 0) {
+    unsigned int *o = g_rcStats + 12u * ((blockIdx.x + blockIdx.y * gridDim.x) * 4u + wave);
+    o[0] = (unsigned)t0; o[1] = (unsigned)(t0 >> 32); o[2] = (unsigned)t1; o[3] = (unsigned)(t1 >> 32);
+    o[4] = iter; o[5] = st.wLook; o[6] = own; o[7] = look; o[8] = st.wHead; o[9] = st.wChain; (void)vox; (void)band; o[10] = sumIter; o[11] = nLanes | (st.wBand << 8);
+  }
+#else
+  raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm);
+#endif
 }
 
 // ---------------------------------------------------------------- K8: ICP maps
@@ -693,7 +773,7 @@ __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const Fram
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
   int bp[8];
-  resolve_cell_blocks(s, p, ix >> 3, iy >> 3, iz >> 3, fx, fy, fz, cache, cache2, bp);
+  resolve_cell_blocks<DeviceOps>(s, p, ix >> 3, iy >> 3, iz >> 3, fx, fy, fz, cache, cache2, bp);
   uchar4 c[8];
   bool have[8];
 #pragma unroll
