@@ -134,7 +134,6 @@ SIGNATURES = {
     "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "dump_hash_table": (C.c_int, [_H, _P]),
-    "check_block_map": (C.c_int, [_H, C.POINTER(C.c_int64)]),
     "dump_visible_list": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int32)]),
     "dump_visible_types": (C.c_int, [_H, _P]),
     "dump_voxel_blocks": (C.c_int, [_H, C.c_int, C.c_int, _P]),

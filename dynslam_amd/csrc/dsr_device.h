@@ -96,8 +96,6 @@ struct SceneP {
   int32_t *swapSlot;      // ... in this slot of it (most recent copy)
   uint8_t **hostSlabs;    // device-visible table of the pinned host slabs (slabBlocks blocks each)
   int slabBlocks;
-  uint4 *occ;             // block map (below), null = off
-  uint32_t occMask;       // its size - 1
 };
 
 // ------------------------------------------------------------------ conversions
@@ -165,50 +163,6 @@ __host__ __device__ __forceinline__ float3 mat_mul3(const Mat4 &a, float x, floa
 
 __host__ __device__ __forceinline__ uint32_t hash_index(int bx, int by, int bz, uint32_t mask) {
   return (((uint32_t)bx * 73856093u) ^ ((uint32_t)by * 19349669u) ^ ((uint32_t)bz * 83492791u)) & mask;
-}
-
-// ---- block map (round 3) ----------------------------------------------------------------------------------------------
-// What the ray march asks the table is "which voxel block holds (bx, by, bz), if any", millions of times per frame, and the
-// table answers through chains: a bucket head and then excess-list entries, one dependent 16-byte read each — also, and
-// mostly, to find that there is NO such block (the empty space in front of a surface is crossed in block-sized steps;
-// profiles/r03_raycast_wave_stats*.json: 18 of the 33 table rounds a wave waits for are chain hops, 69 of 90 in the slowest
-// waves).  The block map answers the same question with ONE read: a direct-mapped array of 16-byte entries {block position,
-// flags, ptr}, indexed by the table's hash function over 8 x as many slots as there are voxel blocks.  It mirrors the table
-// exactly — "entry of this position with ptr >= 0" <=> "slot owned by this position with the same ptr" — and is written by
-// the five kernels that change that (k_alloc_apply, k_visible_write's swap-in re-allocation, k_decay_commit,
-// k_swapout_move, reset).  Two positions that map to one slot: the first keeps it, the second sets the slot's CONFLICT flag,
-// and readers of a conflicted slot learn nothing from it and ask the table — so a reader never needs the map to be
-// collision free and results cannot depend on it; a slot owned by another position and not conflicted proves that this
-// position was never inserted.  The table itself (its hash function, chains, order) is the reference's and is untouched.
-constexpr uint32_t kOccClaimed = 1u << 16, kOccConflict = 1u << 17;
-
-__host__ __device__ __forceinline__ uint32_t occ_key_xy(int bx, int by) { return ((uint32_t)bx & 0xffffu) | ((uint32_t)by << 16); }
-__host__ __device__ __forceinline__ uint32_t occ_key_z(int bz) { return ((uint32_t)bz & 0xffffu) | kOccClaimed; }
-__host__ __device__ __forceinline__ uint32_t occ_index(int bx, int by, int bz, uint32_t mask) { return hash_index(bx, by, bz, mask); }
-// what a map entry says about block (bx, by, bz): its ptr (>= 0), -1 = no such block, -2 = nothing (conflicted slot: ask the table)
-__host__ __device__ __forceinline__ int occ_answer(const int4 &r, int bx, int by, int bz) {
-  if ((uint32_t)r.y & kOccConflict) return -2;
-  const bool mine = (uint32_t)r.x == occ_key_xy(bx, by) && (uint32_t)r.y == occ_key_z(bz);
-  return (mine && r.z >= 0) ? r.z : -1;
-}
-
-// the block (bx, by, bz) now has an entry with this ptr (>= 0)
-__device__ __forceinline__ void occ_set(const SceneP &s, int bx, int by, int bz, int ptr) {
-  if (!s.occ) return;
-  uint4 *slot = s.occ + occ_index(bx, by, bz, s.occMask);
-  unsigned long long *e = reinterpret_cast<unsigned long long *>(slot);
-  const unsigned long long tag = (unsigned long long)occ_key_xy(bx, by) | ((unsigned long long)occ_key_z(bz) << 32);
-  const unsigned long long old = atomicCAS(e, 0ull, tag);
-  if (old == 0ull || (old & ~((unsigned long long)kOccConflict << 32)) == tag) atomicExch(reinterpret_cast<int *>(slot) + 2, ptr);
-  else atomicOr(reinterpret_cast<unsigned int *>(slot) + 1, kOccConflict);
-}
-// ... no longer (freed by the voxel GC, swapped out)
-__device__ __forceinline__ void occ_clear(const SceneP &s, int bx, int by, int bz) {
-  if (!s.occ) return;
-  uint4 *slot = s.occ + occ_index(bx, by, bz, s.occMask);
-  const unsigned long long tag = (unsigned long long)occ_key_xy(bx, by) | ((unsigned long long)occ_key_z(bz) << 32);
-  if ((*reinterpret_cast<unsigned long long *>(slot) & ~((unsigned long long)kOccConflict << 32)) == tag)
-    atomicExch(reinterpret_cast<int *>(slot) + 2, -1);
 }
 
 // 16-byte load of one hash entry

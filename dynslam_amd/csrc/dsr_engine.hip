@@ -134,7 +134,6 @@ struct dsr_engine {
   hipStream_t sideStream = nullptr;
   hipEvent_t evList = nullptr, evExpected = nullptr;
   bool overlapExpected = true;
-  size_t occEntries = 0;  // slots of the block map (dsr_device.h), 0 = off
   unsigned long long listVersion = 0;  // bumped by every call that rewrites the live visible list
   struct { bool valid = false; unsigned long long version = 0; Mat4 M; float proj[4] = {0, 0, 0, 0}; } liveExp;
   int W = 0, H = 0, Wr = 0, Hr = 0, P = 0;
@@ -335,7 +334,6 @@ int reset_scene(dsr_engine *e) {
   LAUNCH(e, "reset", k_reset_vba, dim3(4096), dim3(256), reinterpret_cast<uint4 *>(e->scene.vba),
          (size_t)e->noBlocks * (kBlockBytes / 16));
   LAUNCH(e, "reset", k_reset_counters, dim3(1), dim3(64), e->scene.ctr, e->scene.work, e->noBlocks, e->noExcess);
-  if (e->scene.occ) HIP_TRY(hipMemsetAsync(e->scene.occ, 0, e->occEntries * sizeof(uint4), e->stream));
   if (e->scene.swapState) {
     HIP_TRY(hipMemsetAsync(e->scene.swapState, 0, (size_t)e->E, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.swapStored, 0, (size_t)e->E, e->stream));
@@ -356,7 +354,7 @@ int reset_scene(dsr_engine *e) {
 void free_all(dsr_engine *e) {
   auto F = [](void *p) { if (p) (void)hipFree(p); };
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
-  F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile); F(e->scene.occ);
+  F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
@@ -800,20 +798,6 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->scene.allocKey, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.allocGrp, (size_t)e->numTilesE * (kTile / 32)));
   ALLOC(dmalloc(&e->scene.allocTile, (size_t)e->numTilesE + 1));
-  {  // block map (dsr_device.h): 8 slots of 16 B per voxel block (3 % of the voxel array), a power of two; DSR_OCC=0 turns it off
-    const char *oc = getenv("DSR_OCC");
-    if (!oc || atoi(oc) != 0) {
-      size_t n = 1024;
-      while (n < 8 * (size_t)e->noBlocks) n <<= 1;
-      if (const char *oe = getenv("DSR_OCC_ENTRIES")) {  // tests: a tiny map, nearly every slot conflicted
-        n = 1;
-        while (n < (size_t)std::max(1, atoi(oe))) n <<= 1;
-      }
-      e->occEntries = n;
-      ALLOC(dmalloc(&e->scene.occ, n));
-      e->scene.occMask = (uint32_t)(n - 1);
-    }
-  }
   ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
@@ -1963,24 +1947,6 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));
-  return DSR_OK;
-}
-
-int dsr_check_block_map(dsr_engine *e, int64_t out[6]) {
-  CHECK_E(e);
-  if (!out) return fail(DSR_E_ARG, "null");
-  for (int k = 0; k < 6; ++k) out[k] = 0;
-  if (!e->scene.occ) return DSR_OK;
-  unsigned long long *d = nullptr;
-  HIP_TRY(hipMalloc((void **)&d, 6 * sizeof(unsigned long long)));
-  hipError_t err = hipMemsetAsync(d, 0, 6 * sizeof(unsigned long long), e->stream);
-  if (err == hipSuccess) {
-    hipLaunchKernelGGL(k_occ_check, dim3(1024), dim3(256), 0, e->stream, e->scene, e->E, e->occEntries, d);
-    err = hipMemcpyAsync(out, d, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream);
-  }
-  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
-  (void)hipFree(d);
-  if (err != hipSuccess) return fail(DSR_E_DEVICE, "block map check failed to run");
   return DSR_OK;
 }
 

@@ -385,7 +385,6 @@ __global__ __launch_bounds__(256) void k_alloc_apply(FrameP p, SceneP s, const f
       *reinterpret_cast<int4 *>(s.table + p.noBuckets + exlOffset) = make_int4(px, pz, 0, ptr);
       visType[p.noBuckets + exlOffset] = 1;
     }
-    occ_set(s, bx, by, bz, ptr);
   }
 }
 
@@ -545,41 +544,11 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntri
       if (re[j]) {
         const int vbaIdx = oldHead - rrank;
         rrank++;
-        if (vbaIdx >= 0) {
-          raw.w = s.voxelAllocList[vbaIdx];
-          s.table[base + j].ptr = raw.w;
-          occ_set(s, (short)(raw.x & 0xffff), (short)((uint32_t)raw.x >> 16), (short)(raw.y & 0xffff), raw.w);
-        }
+        if (vbaIdx >= 0) { raw.w = s.voxelAllocList[vbaIdx]; s.table[base + j].ptr = raw.w; }
       }
       if (rank < capacity) { visibleIDs[rank] = base + j; visBlocks[rank] = make_vis_record(raw, base + j); }
       rank++;
     }
-}
-
-// dsr_check_block_map: does the block map (dsr_device.h) mirror the table?  out[0] entries with a block the map does not
-// answer with the same ptr, [1] entries with a block, [2] of those on a conflicted slot (readers ask the table), [3] slots
-// answering with a block — which must equal [1] - [2] (no answer without an entry), [4] slots in use, [5] conflicted slots
-__global__ __launch_bounds__(256) void k_occ_check(SceneP s, int noTotalEntries, size_t occEntries, unsigned long long *__restrict__ out) {
-  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-  unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
-  for (size_t t = tid; t < (size_t)noTotalEntries; t += stride) {
-    const dsr_hash_entry he = load_entry(s.table, (uint32_t)t);
-    if (he.ptr < 0) continue;
-    c[1]++;
-    const int4 r = *reinterpret_cast<const int4 *>(s.occ + occ_index(he.pos[0], he.pos[1], he.pos[2], s.occMask));
-    const int ans = occ_answer(r, he.pos[0], he.pos[1], he.pos[2]);
-    if (ans == -2) c[2]++;
-    else if (ans != he.ptr) c[0]++;
-  }
-  for (size_t i = tid; i < occEntries; i += stride) {
-    const uint4 r = s.occ[i];
-    if (!(r.y & kOccClaimed)) continue;
-    c[4]++;
-    if (r.y & kOccConflict) c[5]++;
-    else if ((int)r.z >= 0) c[3]++;
-  }
-  for (int k = 0; k < 6; ++k)
-    if (c[k]) atomicAdd(out + k, c[k]);
 }
 
 }  // namespace dsr

@@ -211,7 +211,6 @@ __global__ __launch_bounds__(kTileThreads) void k_decay_commit(SceneP s, const i
       dsr_hash_entry *he = s.table + t;
       s.voxelAllocList[oldHead + 1 + rank] = he->ptr;
       he->ptr = -2;
-      occ_clear(s, he->pos[0], he->pos[1], he->pos[2]);
       visType[t] = 0;
       if (s.swapState) { s.swapState[t] = 0; s.swapStored[t] = 0; }
       rank++;

@@ -68,7 +68,7 @@ __device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const 
 }
 
 // How the march converts float -> int, rounds down and asks "any ray of the wave": the device's instructions here, a one-ray
-// host stand-in in tests/hostsim (which runs cast_ray on the CPU against the oracle's raycast).
+// host stand-in in tests/hostsim (which runs cast_ray on the CPU against the oracle's raycast, tests/test_raycast_host.py).
 struct DeviceOps {
   static __device__ __forceinline__ int f2i(float f) { return dsr::f2i(f); }
   static __device__ __forceinline__ bool any(bool b) { return __any(b) != 0; }
@@ -76,37 +76,11 @@ struct DeviceOps {
   static __device__ __forceinline__ float floor(float f) { return floorf(f); }
 };
 
-constexpr uint32_t kMapIdx = 0x80000000u;  // marks a block-map index (table indices are < 2^31)
-
-// One step of "which block holds (bx, by, bz)": look at the 16-byte entry `raw` read from `idx` (kMapIdx | slot of the block
-// map, or a table index).  Returns true when the question is answered (ptr = block or -1), else idx = the next entry to read.
-__host__ __device__ __forceinline__ bool lookup_step(const FrameP &p, const int4 &raw, int bx, int by, int bz, uint32_t &idx, int &ptr) {
-  if (idx & kMapIdx) {
-    const int ans = occ_answer(raw, bx, by, bz);
-    if (ans != -2) { ptr = ans; return true; }
-    idx = hash_index(bx, by, bz, p.hashMask);  // conflicted slot: the table knows
-    return false;
-  }
-  // ITMRepresentationAccess.h findVoxel
-  const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-  if (hx == bx && hy == by && hz == bz && raw.w >= 0) { ptr = raw.w; return true; }
-  if (raw.z < 1) { ptr = -1; return true; }
-  idx = (uint32_t)(p.noBuckets + raw.z - 1);
-  return false;
-}
-__host__ __device__ __forceinline__ uint32_t lookup_start(const FrameP &p, const SceneP &s, int bx, int by, int bz) {
-  return s.occ ? (kMapIdx | occ_index(bx, by, bz, s.occMask)) : hash_index(bx, by, bz, p.hashMask);
-}
-__host__ __device__ __forceinline__ const int4 *lookup_entry(const SceneP &s, uint32_t idx) {
-  return (idx & kMapIdx) ? reinterpret_cast<const int4 *>(s.occ) + (idx & ~kMapIdx) : reinterpret_cast<const int4 *>(s.table) + idx;
-}
-
 // The blocks a 2x2x2 voxel cell with base block (bx0, by0, bz0) touches: slot c = (ox, oy, oz) in {0,1}^3 is needed iff the
 // cell straddles (f*) in every axis where o = 1.  Blocks the caller already knows (cache, cache2 — which also remembers
-// absent blocks) cost nothing; the others are looked up in ROUNDS of one 16-byte entry per ray for all rays of the wave
-// together (block map first, dsr_device.h; table and its chains only behind a conflicted slot): a round is one gather
-// instruction and one wait for the whole wave, and the number of rounds is the largest number of entries any ray needs
-// (0 or 1 for nearly all of them).  bp[c] = block index or -1.
+// absent blocks) cost nothing; the others are looked up in ROUNDS of one bucket head per ray for all rays of the wave
+// together: a round is one gather instruction and one wait for the whole wave, and the number of rounds is the largest
+// number of unknown blocks any ray has (0 or 1 for nearly all of them).  bp[c] = block index or -1.
 template <class Ops>
 __host__ __device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, const FrameP &p, int bx0, int by0, int bz0, bool fx, bool fy,
                                                              bool fz, const VoxCache &cache, VoxCache &cache2, int (&bp)[8]) {
@@ -122,22 +96,22 @@ __host__ __device__ __forceinline__ void resolve_cell_blocks(const SceneP &s, co
       else need |= 1u << c;
     }
   }
-  uint32_t idx = 0u;
-  bool walking = false;  // idx is an entry of the current slot's walk
   while (Ops::any(need != 0)) {
     if (need != 0) {
       const int c = __builtin_ctz(need);
+      need &= need - 1;
       const int bx = bx0 + (c & 1), by = by0 + ((c >> 1) & 1), bz = bz0 + (c >> 2);
-      if (!walking) { idx = lookup_start(p, s, bx, by, bz); walking = true; }
-      const int4 raw = *lookup_entry(s, idx);
+      int4 raw = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
       int found = -1;
-      if (lookup_step(p, raw, bx, by, bz, idx, found)) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) bp[k] = (k == c) ? found : bp[k];
-        cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
-        need &= need - 1;
-        walking = false;
+      while (true) {  // ITMRepresentationAccess.h findVoxel
+        const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+        if (hx == bx && hy == by && hz == bz && raw.w >= 0) { found = raw.w; break; }
+        if (raw.z < 1) break;
+        raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
       }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) bp[k] = (k == c) ? found : bp[k];
+      cache2.bx = bx; cache2.by = by; cache2.bz = bz; cache2.ptr = found;
     }
   }
 }
@@ -440,7 +414,7 @@ struct RcStats { unsigned nIter = 0, nLook = 0, nVox = 0, nBand = 0, wLook = 0, 
 #define RC_STAT(...)
 #endif
 
-// ITMVisualisationEngine.h castRay
+// ITMVisualisationEngine.h castRay.  (A template over Ops only so that tests/ can run this very function on the CPU.)
 template <class Ops>
 __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const SceneP &s, int x, int y, float2 mm RC_STAT(, RcStats &st)) {
   const float oneOverVoxelSize = 1.0f / p.voxelSize;
@@ -468,7 +442,7 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
   float sdfValue = 1.0f, stepLength;
   bool hash_found;
 #if DSR_RAYCAST_PREFETCH
-  uint32_t pfIdx = 0xffffffffu;  // index of the entry in the look-ahead slot: a table index, or kMapIdx | a block-map slot
+  uint32_t pfIdx = 0xffffffffu;  // table index of the prefetched entry
   int4 pfRaw = make_int4(0, 0, 0, -2);
 #endif
   while (totalLength < totalLengthMax) {
@@ -477,45 +451,43 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
     //  phases, so the single uninterpolated load per far step stays.)
 #if DSR_RAYCAST_PREFETCH
     {
-      // readFromSDF_float_uninterpolated.  Which block holds the sample is answered by the ray's one-block cache, else by
-      // the block map (dsr_device.h: one 16-byte read says "this block" or "no such block"), else — behind a conflicted slot
-      // of the map, or without a map — by the table and its chains.  The entries a ray reads are all 16 bytes, and every ray
-      // of the wave issues whichever one it needs next from ONE load instruction per round, so a round costs the wave one
-      // wait however its rays are spread over the cases.
-      // One-step look-ahead: the entry the NEXT sample will need (guessing the usual step: 8 voxels after a miss, mu/voxel
-      // when the block is in front of the surface, sdf = 1) is requested together with this sample's voxel, so a correct
-      // guess turns lookup -> voxel into one round trip per step.  A wrong guess costs one unused 16-byte read; values are
-      // never affected.
+      // readFromSDF_float_uninterpolated with a one-step look-ahead on the hash table: the bucket
+      // head the NEXT sample will need (guessing the usual step: 8 voxels after a miss, mu/voxel
+      // when the block is in front of the surface, sdf = 1) is requested together with this
+      // sample's voxel, so a correct guess turns lookup -> voxel into one round trip per step.
+      // A wrong guess costs one unused 16-byte read; values are never affected.
       const int vx = Ops::f2i(roundf_itm(rx)), vy = Ops::f2i(roundf_itm(ry)), vz = Ops::f2i(roundf_itm(rz));
       const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
-      int ptr = -1;
-      uint32_t idx = 0u;
-      bool want = false;  // an entry has to be looked at
-      RC_STAT(++st.nIter;)
+      int ptr;
+      RC_STAT(++st.nIter; bool didHead = false, didChain = false;)
       if (bx == cache.bx && by == cache.by && bz == cache.bz) ptr = cache.ptr;
-      else { want = true; idx = lookup_start(p, s, bx, by, bz); }
-      while (Ops::any(want)) {
-        RC_STAT(st.wLook += __any(want && idx != pfIdx) ? 1u : 0u;
-                st.wHead += __any(want && idx != pfIdx && ((idx & kMapIdx) || idx < (uint32_t)p.noBuckets)) ? 1u : 0u;
-                st.wChain += __any(want && idx != pfIdx && !(idx & kMapIdx) && idx >= (uint32_t)p.noBuckets) ? 1u : 0u;)
-        if (want) {
-          RC_STAT(if (idx != pfIdx) ++st.nLook;)
-          const int4 raw = (idx == pfIdx) ? pfRaw : *lookup_entry(s, idx);
-          if (lookup_step(p, raw, bx, by, bz, idx, ptr)) {
-            want = false;
-            if (ptr >= 0) { cache.bx = bx; cache.by = by; cache.bz = bz; cache.ptr = ptr; }
+      else {
+        uint32_t h = hash_index(bx, by, bz, p.hashMask);
+        RC_STAT(if (h != pfIdx) { ++st.nLook; didHead = true; })
+        int4 raw = (h == pfIdx) ? pfRaw : *reinterpret_cast<const int4 *>(s.table + h);
+        ptr = -1;
+        while (true) {
+          const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
+          if (hx == bx && hy == by && hz == bz && raw.w >= 0) {
+            cache.bx = bx; cache.by = by; cache.bz = bz; cache.ptr = raw.w; ptr = raw.w;
+            break;
           }
+          if (raw.z < 1) break;
+          h = (uint32_t)(p.noBuckets + raw.z - 1);
+          raw = *reinterpret_cast<const int4 *>(s.table + h);
+          RC_STAT(++st.nLook; didChain = true;)
         }
       }
       hash_found = ptr >= 0;
-      RC_STAT(st.nVox += hash_found ? 1u : 0u;)
+      RC_STAT(st.wLook += __any(didHead || didChain) ? 1u : 0u; st.wHead += __any(didHead) ? 1u : 0u; st.wChain += __any(didChain) ? 1u : 0u;
+              st.nVox += hash_found ? 1u : 0u;)
       {
         const float g = hash_found ? stepScale : (float)kBlockSize;
         const int nx = Ops::f2i(roundf_itm(rx + g * dx)) >> 3, ny = Ops::f2i(roundf_itm(ry + g * dy)) >> 3,
                   nz = Ops::f2i(roundf_itm(rz + g * dz)) >> 3;
         if (nx != bx || ny != by || nz != bz) {
-          pfIdx = lookup_start(p, s, nx, ny, nz);
-          pfRaw = *lookup_entry(s, pfIdx);
+          pfIdx = hash_index(nx, ny, nz, p.hashMask);
+          pfRaw = *reinterpret_cast<const int4 *>(s.table + pfIdx);
         }
         // (measured and rejected: a second look-ahead slot during runs of misses, 580 us vs 515 us;
         //  four bucket heads at once after 8 misses in a row, 631 us; a fire-and-forget prefetch
@@ -531,12 +503,25 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
         //  step's own voxel load whenever the previous step was inside the interpolation band (one round trip per band
         //  step instead of two, no extra loads when the guess holds), 441-443 vs 429 us, and requesting the NEXT step's
         //  voxel one iteration ahead in saturated space, 518 us (7 spilled registers at the 64-VGPR limit), both 543 us
-        //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact); an occupancy BITMAP per 4x4x4-block cell in
-        //  front of the table (a clear bit = no such block, no read at all: -21 % bytes fetched, but one more dependent
-        //  round for every block that exists: 536 vs 461 us); rays advancing independently through a per-ray state
-        //  machine, one read per ray and round instead of the lockstep loop (a wave needs as many rounds as its neediest
-        //  ray has reads, 35 instead of 105 stages — and ~4x the instructions: 798 vs 461 us;
-        //  profiles/r03_raycast_rounds_variant.h.txt, r03_raycast_rounds_ab.log).)
+        //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact).
+        //  Round 3, after measuring what a launch is made of (tools/raycast_wave_stats.py, profiles/r03_raycast_wave_stats*.json:
+        //  all 7.3 k waves are resident at once; a wave runs 105 dependent memory stages where its neediest single ray needs 35;
+        //  for its first half the launch is bound by instruction issue — 7 waves per SIMD x ~160 instructions per stage —
+        //  and its last third runs with a few per cent of the waves, the ones with 200+ iterations of absent blocks), all
+        //  verified bit-exact on the CPU first (tests/test_raycast_host.py) and then on the GPU:
+        //   * an occupancy BITMAP per 4x4x4-block cell in front of the table (clear bit = no such block, no read at all):
+        //     -21 % bytes fetched, one more dependent round for every block that exists: 536 vs 461 us;
+        //   * rays advancing independently through a per-ray state machine, one read per ray and round (a wave needs as many
+        //     rounds as its neediest ray has reads) — and ~4x the instructions of this loop: 798 vs 461 us
+        //     (profiles/r03_raycast_rounds_variant.h.txt, r03_raycast_rounds_ab.log);
+        //   * this table walk as wave-wide rounds (`while (__any(...))`, every ray issues the entry it needs next from ONE
+        //     load instruction per round): 500-507 vs 405-411 us (profiles/r03_raycast_lookup_rounds_ab.log);
+        //   * a direct-mapped BLOCK MAP (position -> ptr, one read instead of head + chain, conflicts fall back to the table)
+        //     maintained by the allocation / GC / swap kernels: chain rounds 18 -> 6 per wave, but every conflict is one
+        //     more round, and a wave has 64 rays: 1 % (profiles/r03_block_map_variant.diff, r03_block_map_*_ab.log);
+        //   * on top of it, probing runs of absent blocks four blocks at a time from iteration N of a wave on: 717-835 vs
+        //     650 us with the code present and never taken, ~500 without it (profiles/r03_raycast_probe_variant.h.txt).
+        //  Every variant that adds requests, instructions or iterations loses.)
       }
       float raw16 = 32767.0f;
       if (hash_found) {
@@ -594,20 +579,19 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
   RcStats st;
   raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm, st);
   const unsigned long long t1 = wall_clock64();
-  // own stages of a lane, were the lanes decoupled: one per table read, voxel read and band read
-  unsigned own = st.nLook + st.nVox + st.nBand, iter = st.nIter, look = st.nLook, vox = st.nVox, band = st.nBand, sumIter = st.nIter;
+  // own stages of a ray, were the rays decoupled: one per table read, voxel read and band read
+  unsigned own = st.nLook + st.nVox + st.nBand, iter = st.nIter, look = st.nLook, sumIter = st.nIter;
   for (int d = 1; d < 64; d <<= 1) {
     own = max(own, (unsigned)__shfl_xor((int)own, d)); iter = max(iter, (unsigned)__shfl_xor((int)iter, d));
     st.wLook = max(st.wLook, (unsigned)__shfl_xor((int)st.wLook, d)); st.wBand = max(st.wBand, (unsigned)__shfl_xor((int)st.wBand, d));
     st.wHead = max(st.wHead, (unsigned)__shfl_xor((int)st.wHead, d)); st.wChain = max(st.wChain, (unsigned)__shfl_xor((int)st.wChain, d));
-    look = max(look, (unsigned)__shfl_xor((int)look, d)); vox = max(vox, (unsigned)__shfl_xor((int)vox, d));
-    band = max(band, (unsigned)__shfl_xor((int)band, d)); sumIter += (unsigned)__shfl_xor((int)sumIter, d);
+    look = max(look, (unsigned)__shfl_xor((int)look, d)); sumIter += (unsigned)__shfl_xor((int)sumIter, d);
   }
   const unsigned nLanes = (unsigned)__popcll(__ballot(1));
   if (lane == 0) {
     unsigned int *o = g_rcStats + 12u * ((blockIdx.x + blockIdx.y * gridDim.x) * 4u + wave);
     o[0] = (unsigned)t0; o[1] = (unsigned)(t0 >> 32); o[2] = (unsigned)t1; o[3] = (unsigned)(t1 >> 32);
-    o[4] = iter; o[5] = st.wLook; o[6] = own; o[7] = look; o[8] = st.wHead; o[9] = st.wChain; (void)vox; (void)band; o[10] = sumIter; o[11] = nLanes | (st.wBand << 8);
+    o[4] = iter; o[5] = st.wLook; o[6] = own; o[7] = look; o[8] = st.wHead; o[9] = st.wChain; o[10] = sumIter; o[11] = nLanes | (st.wBand << 8);
   }
 #else
   raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm);

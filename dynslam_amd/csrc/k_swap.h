@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256) void k_swapout_move(SceneP s, const int32_t *_
     if (lane == 0) {
       s.voxelAllocList[oldHead + 1 + i] = ptr;
       s.table[id].ptr = -1;
-      occ_clear(s, s.table[id].pos[0], s.table[id].pos[1], s.table[id].pos[2]);
       s.swapState[id] = 0;
       s.swapStored[id] = 1;
     }

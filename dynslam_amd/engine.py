@@ -255,13 +255,6 @@ class EngineCore:
         self._check(self.api.dump_hash_table(self._h, _ptr(out)))
         return out
 
-    def check_block_map(self):
-        """Self-check of the ray march's block map against the table (include/dsr.h): dict of the six counters."""
-        out = (C.c_int64 * 6)()
-        self._check(self.api.check_block_map(self._h, out))
-        keys = ("wrong_answers", "entries_with_block", "entries_on_conflicted_slots", "slots_with_block", "slots_in_use", "conflicted_slots")
-        return dict(zip(keys, (int(v) for v in out)))
-
     def dump_visible_list(self, freeview=False):
         ids = np.empty(self.no_blocks, np.int32)
         n = C.c_int32(0)

@@ -388,12 +388,6 @@ int dsr_get_stats(dsr_engine *e, dsr_stats *out);
  *   allocation lists  : sdf_local_block_num int32, excess_list_size int32
  */
 int dsr_dump_hash_table(dsr_engine *e, dsr_hash_entry *out);
-/* Self-check of the block map the ray march asks before the table (an acceleration structure of this implementation, no
- * counterpart upstream): out[0] = table entries holding a block that the map does not answer with the
- * same ptr (must be 0), [1] = entries holding a block, [2] = of those, on a conflicted slot (their rays ask the table),
- * [3] = slots answering with a block (must equal [1] - [2]), [4] = slots in use, [5] = conflicted slots.  All zero when the
- * map is off (environment DSR_OCC=0 at engine creation) and in the oracle, which has no such structure.  Synchronises. */
-int dsr_check_block_map(dsr_engine *e, int64_t out[6]);
 int dsr_dump_visible_list(dsr_engine *e, int freeview, int32_t *ids_out, int32_t *n);
 int dsr_dump_visible_types(dsr_engine *e, uint8_t *out);
 int dsr_dump_voxel_blocks(dsr_engine *e, int first_block, int n_blocks, dsr_voxel *out);

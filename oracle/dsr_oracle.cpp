@@ -1666,11 +1666,6 @@ int orc_get_view_previews(dsr_engine *h, uint8_t *bgr_out, int16_t *depth_mm_out
   if (st == DSR_OK && depth_mm_out) st = orc_depth_m_to_mm(E.depth.data(), depth_mm_out, E.W * E.H);
   return st;
 }
-int orc_check_block_map(dsr_engine *h, int64_t out[6]) {  // the HIP engine's acceleration structure: nothing to check here
-  if (!h || !out) return fail(DSR_E_ARG, "null");
-  for (int k = 0; k < 6; ++k) out[k] = 0;
-  return DSR_OK;
-}
 int orc_get_no_visible_blocks(dsr_engine *h, int32_t *out) {
   if (!h || !out) return fail(DSR_E_ARG, "null");
   *out = E.live.noVisibleBlocks;

@@ -360,10 +360,7 @@ def test_free_view_cache(hip_api):
                                  dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768"),
                                  # the small-volume paths (expected depths by one workgroup, free-view list by one sweep) forced
                                  # onto this 40000-block volume; the large-volume paths are what the other cases run
-                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5"),
-                                 # the ray march without its block map, and with maps so small that most / some of their
-                                 # slots are conflicted (those rays ask the table)
-                                 dict(DSR_OCC="0"), dict(DSR_OCC_ENTRIES="64"), dict(DSR_OCC_ENTRIES="2048")])
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
@@ -385,32 +382,6 @@ def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env)
     assert np.array_equal(gd, od) and np.array_equal(gc, oc)
     assert np.array_equal(g.dump_visible_list(True), o.dump_visible_list(True))
     assert_render_equal(g, o, freeview=True)
-
-
-def test_block_map_in_use_and_emptied_by_reset(hip_api, monkeypatch):
-    """The block map (include/dsr.h dsr_check_block_map) at its default size: in use, a few per cent of its slots conflicted
-    at most, emptied by a reset; DSR_OCC=0 turns it off (all counters zero)."""
-    sc, g, o = make_pair()
-    for i in range(3):
-        feed((g, o), sc, i)
-    c = g.check_block_map()
-    assert c["wrong_answers"] == 0 and c["entries_with_block"] > 1000 and c["slots_in_use"] > 1000, c
-    assert c["slots_with_block"] == c["entries_with_block"] - c["entries_on_conflicted_slots"], c
-    assert c["conflicted_slots"] <= 0.1 * c["slots_in_use"], c
-    for e in (g, o):
-        e.reset_scene()
-    c = g.check_block_map()
-    assert c["entries_with_block"] == 0 and c["slots_in_use"] == 0 and c["slots_with_block"] == 0, c
-    for i in range(2):
-        feed((g, o), sc, i)
-        assert_scene_equal(g, o, voxels=False)
-        assert_render_equal(g, o)
-    g.close(); o.close()
-    monkeypatch.setenv("DSR_OCC", "0")
-    sc, g, o = make_pair()
-    feed((g, o), sc, 0)
-    assert all(v == 0 for v in g.check_block_map().values())
-    assert_render_equal(g, o)
 
 
 def test_non_finite_depth_in_a_float_view(hip_api):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# block map: how much is there to gain?  default size (8 slots per voxel block), 64 per block (conflicts ~0.5 %), off
+# same-box A/B: the library as of the previous commit (libdsr_hip_prev.so) against the current one with the block map on / off
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-for cfg in "1 0" "1 536870912" "0 0" "1 0" "1 536870912" "0 0"; do
-  set -- $cfg
-  if [ "$2" = 0 ]; then unset DSR_OCC_ENTRIES; else export DSR_OCC_ENTRIES=$2; fi
-  DSR_OCC=$1 timeout 200 python tools/bench_variants.py "" 2>/dev/null | sed "s/^/map=$1 slots=$2 /" | tee -a gpurun_out/map_size_ab.log
+for i in 1 2; do
+  DSR_HIP_LIB=$PWD/dynslam_amd/csrc/libdsr_hip_prev.so timeout 200 python tools/bench_variants.py "" 2>/dev/null | sed "s/^/prev /" | tee -a gpurun_out/prev_ab.log
+  DSR_OCC=1 timeout 200 python tools/bench_variants.py "" 2>/dev/null | sed "s/^/cur map=1 /" | tee -a gpurun_out/prev_ab.log
+  DSR_OCC=0 timeout 200 python tools/bench_variants.py "" 2>/dev/null | sed "s/^/cur map=0 /" | tee -a gpurun_out/prev_ab.log
 done
