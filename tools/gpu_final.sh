@@ -1,9 +1,9 @@
-# r03o: the complete GPU suite on the round's final code + the standing lines.  bash tools/gpu_r03o.sh
+# The complete GPU suite on the final code of a round + the standing bench lines.  bash tools/gpu_final.sh <tag>
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $O
-T=r03o
+T=${1:-final}
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/${T}_gpu_suite.log 2>&1; echo "suite rc=$?" >> $O/${T}_gpu_suite.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/${T}_smoke.log 2>&1; echo "smoke rc=$?" >> $O/${T}_smoke.log
 timeout 300 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_line.json 2> $O/${T}_bench.err
