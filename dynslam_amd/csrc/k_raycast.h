@@ -509,8 +509,8 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
         //  (profiles/r03e_raycast_speculation_variants.log; all bit-exact).
         //  Round 3, after measuring what a launch is made of (tools/raycast_wave_stats.py, profiles/r03_raycast_wave_stats*.json:
         //  all 7.3 k waves are resident at once; a wave runs 105 dependent memory stages where its neediest single ray needs 35;
-        //  for its first half the launch is bound by instruction issue — 7 waves per SIMD x ~160 instructions per stage —
-        //  and its last third runs with a few per cent of the waves, the ones with 200+ iterations of absent blocks), all
+        //  while all waves run, a stage costs its round trip plus the wave's share of a half-busy SIMD (~160 instructions),
+        //  and the launch's last third runs with a few per cent of the waves, the ones with 200+ iterations of absent blocks), all
         //  verified bit-exact on the CPU first (tests/test_raycast_host.py) and then on the GPU:
         //   * an occupancy BITMAP per 4x4x4-block cell in front of the table (clear bit = no such block, no read at all):
         //     -21 % bytes fetched, one more dependent round for every block that exists: 536 vs 461 us;
