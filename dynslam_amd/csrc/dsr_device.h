@@ -147,7 +147,7 @@ __host__ __device__ __forceinline__ float div_short(float a, float b, float yRN)
   return __builtin_fmaf(r, yRN, q);
 }
 
-__device__ __forceinline__ float sdf_to_float(float v) { return v / 32767.0f; }
+__host__ __device__ __forceinline__ float sdf_to_float(float v) { return v / 32767.0f; }
 // same value for every v that is not -0 (div_short)
 __host__ __device__ __forceinline__ float sdf_to_float_short(float v) { return div_short(v, 32767.0f, 1.0f / 32767.0f); }
 __device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f * 32767.0f); }
@@ -166,7 +166,7 @@ __host__ __device__ __forceinline__ uint32_t hash_index(int bx, int by, int bz, 
 }
 
 // 16-byte load of one hash entry
-__device__ __forceinline__ dsr_hash_entry load_entry(const dsr_hash_entry *table, uint32_t idx) {
+__host__ __device__ __forceinline__ dsr_hash_entry load_entry(const dsr_hash_entry *table, uint32_t idx) {
   int4 raw = *reinterpret_cast<const int4 *>(table + idx);
   dsr_hash_entry e;
   e.pos[0] = (short)(raw.x & 0xffff);

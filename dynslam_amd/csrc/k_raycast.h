@@ -23,7 +23,7 @@ __host__ __device__ __forceinline__ void cache_init(VoxCache &c) { c.bx = c.by =
 
 // ITMRepresentationAccess.h readVoxel (with per-thread cache): returns the block index
 // holding voxel (x,y,z) or -1; linearIdx is the offset inside the block.
-__device__ __forceinline__ int find_block(const SceneP &s, const FrameP &p, int x, int y, int z, int &linearIdx,
+__host__ __device__ __forceinline__ int find_block(const SceneP &s, const FrameP &p, int x, int y, int z, int &linearIdx,
                                           VoxCache &cache) {
   const int bx = x >> 3, by = y >> 3, bz = z >> 3;  // == pointToVoxelBlockPos for negatives too
   linearIdx = (x & 7) + ((y & 7) << 3) + ((z & 7) << 6);
@@ -603,19 +603,18 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
 
 // ---------------------------------------------------------------- K8: ICP maps
 
-__device__ __forceinline__ uchar4 grey_px(float angle) {  // drawPixelGrey
+template <class Ops>
+__host__ __device__ __forceinline__ uchar4 grey_px(float angle) {  // drawPixelGrey
   float outRes = (0.8f * angle + 0.2f) * 255.0f;
-  uint8_t g = (uint8_t)f2i(outRes);
+  uint8_t g = (uint8_t)Ops::f2i(outRes);
   return make_uchar4(g, g, g, g);
 }
 
-// ITMVisualisationEngine.h processPixelICP<true> + computeNormalAndAngle<true> (image space)
-__global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const float4 *__restrict__ pointsRay,
-                                                  float4 *__restrict__ pointsMap, float4 *__restrict__ normalsMap,
-                                                  uchar4 *__restrict__ outRendering) {
-  if (s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (x >= p.W || y >= p.H) return;
+// ITMVisualisationEngine.h processPixelICP<true> + computeNormalAndAngle<true> (image space), one pixel.  (Like cast_ray a
+// template over Ops so that tests/test_raycast_host.py runs it on the CPU against the oracle.)
+template <class Ops>
+__host__ __device__ __forceinline__ void icp_pixel(const FrameP &p, const float4 *__restrict__ pointsRay, int x, int y,
+                                                   float4 &pointOut, float4 &normalOut, uchar4 &greyOut) {
   const int W = p.W, H = p.H;
   const int locId = x + y * W;
   const float lsx = -p.invM.m[8], lsy = -p.invM.m[9], lsz = -p.invM.m[10];
@@ -649,7 +648,7 @@ __global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const floa
         nx = -(diff_x.y * diff_y.z - diff_x.z * diff_y.y);
         ny = -(diff_x.z * diff_y.x - diff_x.x * diff_y.z);
         nz = -(diff_x.x * diff_y.y - diff_x.y * diff_y.x);
-        float normScale = 1.0f / sqrtf(nx * nx + ny * ny + nz * nz);
+        float normScale = 1.0f / Ops::sqrt(nx * nx + ny * ny + nz * nz);
         nx *= normScale; ny *= normScale; nz *= normScale;
         angle = nx * lsx + ny * lsy + nz * lsz;
         if (!(angle > 0.0f)) foundPoint = false;
@@ -657,14 +656,28 @@ __global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const floa
     }
   }
   if (foundPoint) {
-    outRendering[locId] = grey_px(angle);
-    pointsMap[locId] = make_float4(point.x * p.voxelSize, point.y * p.voxelSize, point.z * p.voxelSize, 1.0f);
-    normalsMap[locId] = make_float4(nx, ny, nz, 0.0f);
+    greyOut = grey_px<Ops>(angle);
+    pointOut = make_float4(point.x * p.voxelSize, point.y * p.voxelSize, point.z * p.voxelSize, 1.0f);
+    normalOut = make_float4(nx, ny, nz, 0.0f);
   } else {
-    float4 out4 = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    pointsMap[locId] = out4; normalsMap[locId] = out4;
-    outRendering[locId] = make_uchar4(0, 0, 0, 0);
+    pointOut = normalOut = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    greyOut = make_uchar4(0, 0, 0, 0);
   }
+}
+
+__global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const float4 *__restrict__ pointsRay,
+                                                  float4 *__restrict__ pointsMap, float4 *__restrict__ normalsMap,
+                                                  uchar4 *__restrict__ outRendering) {
+  if (s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  float4 point, normal;
+  uchar4 grey;
+  icp_pixel<DeviceOps>(p, pointsRay, x, y, point, normal, grey);
+  const int locId = x + y * p.W;
+  outRendering[locId] = grey;
+  pointsMap[locId] = point;
+  normalsMap[locId] = normal;
 }
 
 // ------------------------------------------------------- free-view shading (K8)
@@ -675,9 +688,10 @@ __global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const floa
 // across a block boundary keeps evicting (76 % of the pixels): up to 32 dependent lookups.  Here
 // the <= 8 blocks are resolved first (bucket heads requested two at a time, chains then walked;
 // their indices kept in a per-thread LDS row), after which the 32 loads are independent.
-__device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                  int *__restrict__ bptr /* [8], per thread */) {
-  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+template <class Ops>
+__host__ __device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP &p, float x, float y, float z,
+                                                           int *__restrict__ bptr /* [8], per thread */) {
+  const int ix = Ops::f2i(Ops::floor(x)), iy = Ops::f2i(Ops::floor(y)), iz = Ops::f2i(Ops::floor(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   const float nx = 1.0f - cx, ny = 1.0f - cy, nz = 1.0f - cz;
   const int b0x = (ix - 1) >> 3, b0y = (iy - 1) >> 3, b0z = (iz - 1) >> 3;
@@ -753,14 +767,15 @@ __device__ __forceinline__ float3 normal_from_sdf(const SceneP &s, const FrameP 
 // one after the other (8 dependent lookup + load pairs); here the cell's blocks are resolved first (resolve_cell_blocks) and
 // the 8 colour words are loaded together, unconditionally (a missing block reads block 0 and contributes 0): the sums below
 // are the reference's, in its order.
-__device__ __forceinline__ float3 color_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z) {
+template <class Ops>
+__host__ __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z) {
   VoxCache cache; cache_init(cache);
   VoxCache cache2; cache_init(cache2);
-  const int ix = f2i(floorf(x)), iy = f2i(floorf(y)), iz = f2i(floorf(z));
+  const int ix = Ops::f2i(Ops::floor(x)), iy = Ops::f2i(Ops::floor(y)), iz = Ops::f2i(Ops::floor(z));
   const float cx = x - (float)ix, cy = y - (float)iy, cz = z - (float)iz;
   const bool fx = (ix & 7) == 7, fy = (iy & 7) == 7, fz = (iz & 7) == 7;
   int bp[8];
-  resolve_cell_blocks<DeviceOps>(s, p, ix >> 3, iy >> 3, iz >> 3, fx, fy, fz, cache, cache2, bp);
+  resolve_cell_blocks<Ops>(s, p, ix >> 3, iy >> 3, iz >> 3, fx, fy, fz, cache, cache2, bp);
   uchar4 c[8];
   bool have[8];
 #pragma unroll
@@ -791,24 +806,17 @@ __device__ __forceinline__ float3 color_interpolated(const SceneP &s, const Fram
 }
 
 // RenderImage_common shading + the fork's FREECAMERA_DEPTH / COLOUR_FROM_DEPTH_WEIGHT
-// (definitions adopted in oracle/dsr_oracle.cpp render_image()).
-// outRgba2: a second destination of the colour image (the caller's HBM buffer: no copy kernel after the shading)
-__global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, const float4 *__restrict__ pointsRay,
-                                                uchar4 *__restrict__ outRgba, float *__restrict__ outDepth,
-                                                uchar4 *__restrict__ outRgba2) {
-  __shared__ int s_blocks[256][9];  // normal_from_sdf: the <= 8 blocks of a pixel's neighbourhood (row padded)
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (x >= p.W || y >= p.H) return;
-  const int locId = x + y * p.W;
+// (definitions adopted in oracle/dsr_oracle.cpp render_image()), one pixel: pt = its raycast result, bptr = 8 ints of scratch
+template <class Ops>
+__host__ __device__ __forceinline__ uchar4 render_pixel(const FrameP &p, const SceneP &s, int type, const float4 &pt, int *__restrict__ bptr) {
   const float lsx = -p.invM.m[8], lsy = -p.invM.m[9], lsz = -p.invM.m[10];
-  const float4 pt = pointsRay[locId];
   bool foundPoint = pt.w > 0;
   uchar4 out = make_uchar4(0, 0, 0, 0);
   switch (type) {
     case DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME:
       if (foundPoint) {
-        float3 c = color_interpolated(s, p, pt.x, pt.y, pt.z);
-        out.x = (uint8_t)f2i(c.x * 255.0f); out.y = (uint8_t)f2i(c.y * 255.0f); out.z = (uint8_t)f2i(c.z * 255.0f);
+        float3 c = color_interpolated<Ops>(s, p, pt.x, pt.y, pt.z);
+        out.x = (uint8_t)Ops::f2i(c.x * 255.0f); out.y = (uint8_t)Ops::f2i(c.y * 255.0f); out.z = (uint8_t)Ops::f2i(c.z * 255.0f);
         out.w = 255;
       }
       break;
@@ -817,18 +825,18 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
       float3 n = make_float3(0, 0, 0);
       float angle = 0;
       if (foundPoint) {
-        n = normal_from_sdf(s, p, pt.x, pt.y, pt.z, s_blocks[threadIdx.x]);
-        float normScale = 1.0f / sqrtf(n.x * n.x + n.y * n.y + n.z * n.z);
+        n = normal_from_sdf<Ops>(s, p, pt.x, pt.y, pt.z, bptr);
+        float normScale = 1.0f / Ops::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
         n.x *= normScale; n.y *= normScale; n.z *= normScale;
         angle = n.x * lsx + n.y * lsy + n.z * lsz;
         if (!(angle > 0.0f)) foundPoint = false;
       }
       if (foundPoint) {
-        if (type == DSR_IMAGE_FREECAMERA_SHADED) out = grey_px(angle);
+        if (type == DSR_IMAGE_FREECAMERA_SHADED) out = grey_px<Ops>(angle);
         else {
-          out.x = (uint8_t)f2i((0.3f + (-n.x + 1.0f) * 0.35f) * 255.0f);
-          out.y = (uint8_t)f2i((0.3f + (-n.y + 1.0f) * 0.35f) * 255.0f);
-          out.z = (uint8_t)f2i((0.3f + (-n.z + 1.0f) * 0.35f) * 255.0f);
+          out.x = (uint8_t)Ops::f2i((0.3f + (-n.x + 1.0f) * 0.35f) * 255.0f);
+          out.y = (uint8_t)Ops::f2i((0.3f + (-n.y + 1.0f) * 0.35f) * 255.0f);
+          out.z = (uint8_t)Ops::f2i((0.3f + (-n.z + 1.0f) * 0.35f) * 255.0f);
           out.w = 0;
         }
       }
@@ -837,27 +845,42 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
       if (foundPoint) {
         VoxCache cache; cache_init(cache);
         int lin;
-        int ptr = find_block(s, p, f2i(roundf_itm(pt.x)), f2i(roundf_itm(pt.y)), f2i(roundf_itm(pt.z)), lin, cache);
+        int ptr = find_block(s, p, Ops::f2i(roundf_itm(pt.x)), Ops::f2i(roundf_itm(pt.y)), Ops::f2i(roundf_itm(pt.z)), lin, cache);
         float w = 0.0f;
         if (ptr >= 0) w = (float)s.vba[(size_t)ptr * kBlockBytes + kOffWDepth + lin];
         float t = w / (float)p.maxW;
         t = (t > 0.0f) ? t : 0.0f;   // max(0, t)
         t = (1.0f < t) ? 1.0f : t;   // min(1, .)
-        out.x = (uint8_t)f2i(255.0f * (1.0f - t)); out.y = 0; out.z = (uint8_t)f2i(255.0f * t); out.w = 255;
+        out.x = (uint8_t)Ops::f2i(255.0f * (1.0f - t)); out.y = 0; out.z = (uint8_t)Ops::f2i(255.0f * t); out.w = 255;
       }
       break;
     default: break;
   }
+  return out;
+}
+// ... and its depth along the camera's z axis (FREECAMERA_DEPTH; 0 where the ray found nothing)
+__host__ __device__ __forceinline__ float render_depth(const FrameP &p, const float4 &pt) {
+  float d = 0.0f;
+  if (pt.w > 0) {
+    const float mx = pt.x * p.voxelSize, my = pt.y * p.voxelSize, mz = pt.z * p.voxelSize;
+    d = p.M.m[2] * mx + p.M.m[6] * my + p.M.m[10] * mz + p.M.m[14] * 1.0f;
+  }
+  return d;
+}
+
+// outRgba2: a second destination of the colour image (the caller's HBM buffer: no copy kernel after the shading)
+__global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, const float4 *__restrict__ pointsRay,
+                                                uchar4 *__restrict__ outRgba, float *__restrict__ outDepth,
+                                                uchar4 *__restrict__ outRgba2) {
+  __shared__ int s_blocks[256][9];  // normal_from_sdf: the <= 8 blocks of a pixel's neighbourhood (row padded)
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  const int locId = x + y * p.W;
+  const float4 pt = pointsRay[locId];
+  const uchar4 out = render_pixel<DeviceOps>(p, s, type, pt, s_blocks[threadIdx.x]);
   if (outRgba) outRgba[locId] = out;
   if (outRgba2) outRgba2[locId] = out;
-  if (outDepth) {
-    float d = 0.0f;
-    if (pt.w > 0) {
-      const float mx = pt.x * p.voxelSize, my = pt.y * p.voxelSize, mz = pt.z * p.voxelSize;
-      d = p.M.m[2] * mx + p.M.m[6] * my + p.M.m[10] * mz + p.M.m[14] * 1.0f;
-    }
-    outDepth[locId] = d;
-  }
+  if (outDepth) outDepth[locId] = render_depth(p, pt);
 }
 
 }  // namespace dsr

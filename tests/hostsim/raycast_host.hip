@@ -1,6 +1,8 @@
-// Host stand-in for ONE lane of k_raycast: the device function cast_ray<Ops> (dynslam_amd/csrc/k_raycast.h) compiled for
-// the CPU with a one-ray Ops, so that tests/test_raycast_host.py can check the march — its table walk, its look-ahead slot, the
-// trilinear reads with their block rounds — against the oracle's raycast WITHOUT a GPU.
+// Host stand-in for ONE lane of k_raycast / k_icp_maps / k_render: the per-pixel device functions cast_ray<Ops>, icp_pixel<Ops>
+// and render_pixel<Ops> (dynslam_amd/csrc/k_raycast.h) compiled for the CPU with a one-ray Ops, so that
+// tests/test_raycast_host.py can check the march — its table walk, its look-ahead slot, the trilinear reads with their block
+// rounds — and the shading (image-space normals, SDF-gradient normals, interpolated colours, the depth-weight map) against the
+// oracle WITHOUT a GPU.
 // Test infrastructure: built by the test with hipcc (host code only is run), never part of libdsr_hip.so.
 #include <cmath>
 #include <cstring>
@@ -45,3 +47,51 @@ extern "C" int rr_cast_all(const float *invM, const float *proj, float voxelSize
     }
   return 0;
 }
+
+// k_icp_maps: points / normals / grey image of the tracking view from its raycast result (pointsRay: W*H float4, voxel units)
+extern "C" int rr_icp_all(const float *invM, float voxelSize, int W, int H, const float *pointsRay, float *pointsOut, float *normalsOut,
+                          unsigned char *greyOut) {
+  using namespace dsr;
+  FrameP p;
+  std::memset(&p, 0, sizeof p);
+  std::memcpy(p.invM.m, invM, sizeof p.invM.m);
+  p.voxelSize = voxelSize; p.W = W; p.H = H;
+  const float4 *pr = reinterpret_cast<const float4 *>(pointsRay);
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      float4 pt, nm;
+      uchar4 g;
+      icp_pixel<HostOps>(p, pr, x, y, pt, nm, g);
+      const size_t i = (size_t)x + (size_t)y * W;
+      std::memcpy(pointsOut + 4 * i, &pt, 16); std::memcpy(normalsOut + 4 * i, &nm, 16); std::memcpy(greyOut + 4 * i, &g, 4);
+    }
+  return 0;
+}
+
+// k_render: one free-view image type from that view's raycast result; vba in the library's full block layout
+extern "C" int rr_render_all(int type, const float *M, const float *invM, float voxelSize, int maxW, int W, int H, int noBuckets,
+                             int noTotalEntries, const dsr_hash_entry *table, const unsigned char *vba, const float *pointsRay,
+                             unsigned char *rgbaOut, float *depthOut) {
+  using namespace dsr;
+  FrameP p;
+  std::memset(&p, 0, sizeof p);
+  std::memcpy(p.M.m, M, sizeof p.M.m);
+  std::memcpy(p.invM.m, invM, sizeof p.invM.m);
+  p.voxelSize = voxelSize; p.maxW = maxW; p.W = W; p.H = H;
+  p.noBuckets = noBuckets; p.noTotalEntries = noTotalEntries; p.hashMask = (uint32_t)noBuckets - 1u;
+  SceneP s;
+  std::memset(&s, 0, sizeof s);
+  s.table = const_cast<dsr_hash_entry *>(table);
+  s.vba = const_cast<uint8_t *>(vba);
+  const float4 *pr = reinterpret_cast<const float4 *>(pointsRay);
+  int scratch[9];
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      const size_t i = (size_t)x + (size_t)y * W;
+      const uchar4 c = render_pixel<HostOps>(p, s, type, pr[i], scratch);
+      std::memcpy(rgbaOut + 4 * i, &c, 4);
+      depthOut[i] = render_depth(p, pr[i]);
+    }
+  return 0;
+}
+

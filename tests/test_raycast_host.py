@@ -1,4 +1,5 @@
-"""The ray march of k_raycast (dynslam_amd/csrc/k_raycast.h cast_ray) against the oracle — on the CPU.
+"""The ray march of k_raycast and the shading of k_icp_maps / k_render (dynslam_amd/csrc/k_raycast.h cast_ray, icp_pixel,
+render_pixel) against the oracle — on the CPU.
 
 cast_ray is written against a small `Ops` policy (float -> int conversion, "any ray of the wave"), so the very function the
 kernel runs can be compiled for the host with a one-ray Ops (tests/hostsim/raycast_host.hip) and driven over the oracle's
@@ -100,3 +101,64 @@ def test_march_with_fine_voxels():
     sc, o, settings = _oracle_scene(2, voxel_size=0.02, mu=0.08, sdf_local_block_num=150000, hash_bucket_num=0x40000)
     _assert_same(*_cast(lib, sc, o, settings))
     o.close()
+
+
+def _full_vba(o):
+    """The oracle's voxels (array of structs) in the library's plane-wise block layout (dsr_device.h): sdf, w_depth, colour + w_color."""
+    vox = o.dump_voxel_blocks()
+    vba = np.zeros((o.no_blocks, 4096), np.uint8)
+    vba[:, :1024] = np.ascontiguousarray(vox["sdf"]).view(np.uint8).reshape(o.no_blocks, 1024)
+    vba[:, 1024:1536] = vox["w_depth"]
+    clr = np.zeros((o.no_blocks, 512, 4), np.uint8)
+    clr[..., :3] = vox["clr"]
+    clr[..., 3] = vox["w_color"]
+    vba[:, 2048:] = clr.reshape(o.no_blocks, 2048)
+    return vba
+
+
+def test_icp_maps_equal_oracle():
+    """k_icp_maps' per-pixel function: points, normals and the grey image of the tracking view from its raycast result."""
+    lib = _lib()
+    sc, o, settings = _oracle_scene(4)
+    rs = o.dump_render_state()
+    _, inv_m = o.get_pose()
+    inv_m = np.ascontiguousarray(inv_m.T.astype(np.float32)).ravel()
+    pts, nrm = np.zeros((o.H, o.W, 4), np.float32), np.zeros((o.H, o.W, 4), np.float32)
+    grey = np.zeros((o.H, o.W, 4), np.uint8)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert lib.rr_icp_all(p(inv_m), C.c_float(settings["voxel_size"]), o.W, o.H, p(np.ascontiguousarray(rs["raycast_result"])),
+                          p(pts), p(nrm), p(grey)) == 0
+    assert (rs["points"][..., 3] > 0).sum() > 0.2 * o.W * o.H
+    _assert_same(pts, rs["points"])
+    _assert_same(nrm, rs["normals"])
+    assert np.array_equal(grey, rs["raycast_image"])
+    o.close()
+
+
+@pytest.mark.parametrize("image_type", ["SHADED", "COLOUR_FROM_VOLUME", "COLOUR_FROM_NORMAL", "COLOUR_FROM_DEPTH_WEIGHT", "DEPTH"])
+def test_free_view_shading_equals_oracle(image_type):
+    """k_render's per-pixel function on the oracle's free-view raycast: every image type + the float depth."""
+    from dynslam_amd import _capi
+    lib = _lib()
+    sc, o, settings = _oracle_scene(4)
+    t = getattr(_capi, "IMAGE_FREECAMERA_" + image_type)
+    M = np.linalg.inv(sc.pose(2).astype(np.float64)).astype(np.float32)
+    want_rgba, want_depth = o.get_image(t, pose_m=M, want_rgba=True, want_depth=True)
+    rs = o.dump_render_state(True)
+    table, vba = o.dump_hash_table(), _full_vba(o)
+    o.set_pose_m(M)  # (done with the live view) -> get_pose() hands back the engine's own cofactor inverse of M, the one it shaded with
+    _, inv = o.get_pose()
+    rgba = np.zeros((o.H, o.W, 4), np.uint8)
+    depth = np.zeros((o.H, o.W), np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    Mc = np.ascontiguousarray(M.T).ravel()
+    invc = np.ascontiguousarray(inv.T.astype(np.float32)).ravel()
+    assert lib.rr_render_all(int(t), p(Mc), p(invc), C.c_float(settings["voxel_size"]), settings["max_w"], o.W, o.H,
+                             settings["hash_bucket_num"], o.no_total_entries, p(table), p(vba),
+                             p(np.ascontiguousarray(rs["raycast_result"])), p(rgba), p(depth)) == 0
+    assert (rs["raycast_result"][..., 3] > 0).sum() > 0.2 * o.W * o.H
+    assert np.array_equal(depth.view(np.uint32), want_depth.view(np.uint32))
+    if image_type != "DEPTH":
+        assert np.array_equal(rgba, want_rgba), f"{(rgba != want_rgba).any(axis=-1).sum()} pixels differ"
+    o.close()
+
