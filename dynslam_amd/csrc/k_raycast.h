@@ -41,16 +41,6 @@ __host__ __device__ __forceinline__ int find_block(const SceneP &s, const FrameP
   return -1;
 }
 
-// sdf of a voxel as float(short); missing voxels read as TVoxel() => 32767
-__device__ __forceinline__ float read_sdf_raw(const SceneP &s, const FrameP &p, int x, int y, int z, bool &found,
-                                              VoxCache &cache) {
-  int lin;
-  int ptr = find_block(s, p, x, y, z, lin, cache);
-  found = ptr >= 0;
-  if (!found) return 32767.0f;
-  return (float)*reinterpret_cast<const short *>(s.vba + (size_t)ptr * kBlockBytes + kOffSdf + lin * 2);
-}
-
 // two neighbouring shorts of an sdf plane with ONE load (the address is only 2-byte aligned: unaligned dword
 // access is supported for global memory on gfx9 and the compiler emits a single global_load_dword)
 __host__ __device__ __forceinline__ uint32_t load_pair(const short *p) {
@@ -62,12 +52,6 @@ __host__ __device__ __forceinline__ uint32_t load_pair(const short *p) {
 // ROUND() = (x < 0) ? (x - 0.5f) : (x + 0.5f), always followed by the conversion to int.  x + copysign(0.5, x) is the same float
 // except for x = -0 (-0.5 instead of +0.5: both convert to 0) and saves a compare + select per coordinate (six per iteration).
 __host__ __device__ __forceinline__ float roundf_itm(float x) { return x + __builtin_copysignf(0.5f, x); }
-
-__device__ __forceinline__ float read_sdf_uninterpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                         bool &found, VoxCache &cache) {
-  float v = read_sdf_raw(s, p, f2i(roundf_itm(x)), f2i(roundf_itm(y)), f2i(roundf_itm(z)), found, cache);
-  return sdf_to_float(v);
-}
 
 // How the march converts float -> int, rounds down and asks "any ray of the wave": the device's instructions here, a one-ray
 // host stand-in in tests/hostsim (which runs cast_ray on the CPU against the oracle's raycast, tests/test_raycast_host.py).
@@ -179,11 +163,6 @@ __host__ __device__ __forceinline__ float read_sdf_interpolated_raw(const SceneP
   res2 = (1.0f - cy) * res2 + cy * ((1.0f - cx) * v[6] + cx * v[7]);
   return (1.0f - cz) * res1 + cz * res2;
 }
-__device__ __forceinline__ float read_sdf_interpolated(const SceneP &s, const FrameP &p, float x, float y, float z,
-                                                       VoxCache &cache, VoxCache &cache2) {
-  return sdf_to_float(read_sdf_interpolated_raw<DeviceOps>(s, p, x, y, z, cache, cache2));
-}
-
 // --------------------------------------------------------- K6: expected depths
 
 __global__ __launch_bounds__(256) void k_minmax_init(float2 *__restrict__ minmax, int n, const int32_t *__restrict__ ctr,
@@ -403,10 +382,6 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
 
 // ----------------------------------------------------------------- K7: raycast
 
-#ifndef DSR_RAYCAST_PREFETCH
-#define DSR_RAYCAST_PREFETCH 1
-#endif
-
 // -DDSR_RAYCAST_STATS (tools/raycast_wave_stats.py, never the product build): per-wave clocks and stage counts of the march
 #ifdef DSR_RAYCAST_STATS
 __device__ unsigned int *g_rcStats;  // 12 words per wave
@@ -443,15 +418,12 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
   VoxCache cache2; cache_init(cache2);  // neighbour block of two-block trilinear cells
   float sdfValue = 1.0f, stepLength;
   bool hash_found;
-#if DSR_RAYCAST_PREFETCH
   uint32_t pfIdx = 0xffffffffu;  // table index of the prefetched entry
   int4 pfRaw = make_int4(0, 0, 0, -2);
-#endif
   while (totalLength < totalLengthMax) {
     // (sample_sdf_march — one lookup + the 8 corner loads for every step — was measured: 937 us vs
     //  666 us.  The march is bound by gather-request throughput, not by the number of dependent
     //  phases, so the single uninterpolated load per far step stays.)
-#if DSR_RAYCAST_PREFETCH
     {
       // readFromSDF_float_uninterpolated with a one-step look-ahead on the hash table: the bucket
       // head the NEXT sample will need (guessing the usual step: 8 voxels after a miss, mu/voxel
@@ -533,9 +505,6 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
       }
       sdfValue = sdf_to_float_short(raw16);
     }
-#else
-    sdfValue = read_sdf_uninterpolated(s, p, rx, ry, rz, hash_found, cache);
-#endif
     RC_STAT(const bool inBand = hash_found && (sdfValue <= 0.1f) && (sdfValue >= -0.5f); st.nBand += inBand ? 1u : 0u; st.wBand += __any(inBand) ? 1u : 0u;)
     if (!hash_found) {
       stepLength = (float)kBlockSize;
