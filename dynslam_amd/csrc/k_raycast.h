@@ -60,6 +60,10 @@ struct DeviceOps {
   static __device__ __forceinline__ bool any(bool b) { return __any(b) != 0; }
   static __device__ __forceinline__ float sqrt(float f) { return sqrtf(f); }
   static __device__ __forceinline__ float floor(float f) { return floorf(f); }
+  static __device__ __forceinline__ float ceil(float f) { return ceilf(f); }
+  // a / b for "tame" operands (dsr_device.h): the refined reciprocal of b, shared by the divisions by one divisor
+  static __device__ __forceinline__ float rcp(float b) { return rcp_refined(b); }
+  static __device__ __forceinline__ float div(float a, float b, float y) { return div_with_rcp(a, b, y); }
 };
 
 // The blocks a 2x2x2 voxel cell with base block (bx0, by0, bz0) touches: slot c = (ox, oy, oz) in {0,1}^3 is needed iff the
@@ -173,8 +177,9 @@ __global__ __launch_bounds__(256) void k_minmax_init(float2 *__restrict__ minmax
 }
 
 // ITMVisualisationEngine.h ProjectSingleBlock on the compact ceil(W/8) x ceil(H/8) image
-__device__ __forceinline__ bool project_single_block(const short pos[3], const FrameP &p, int imgW, int imgH, int2 &ul,
-                                                     int2 &lr, float2 &zr) {
+template <class Ops>
+__host__ __device__ __forceinline__ bool project_single_block(const short pos[3], const FrameP &p, int imgW, int imgH, int2 &ul,
+                                                              int2 &lr, float2 &zr) {
   ul = make_int2(imgW, imgH);
   lr = make_int2(-1, -1);
   zr = make_float2(kFarAway, kVeryClose);
@@ -187,13 +192,13 @@ __device__ __forceinline__ bool project_single_block(const short pos[3], const F
                         (float)tz * (float)kBlockSize * p.voxelSize, 1.0f);
     if (q.z < 1e-6f) continue;
     // q.z >= 1e-6: tame divisor, the two divisions share the refined reciprocal (dsr_device.h)
-    const float yz = rcp_refined(q.z);
-    float px = (div_with_rcp(p.proj.x * q.x, q.z, yz) + p.proj.z) / (float)kMinmaxSubsample;
-    float py = (div_with_rcp(p.proj.y * q.y, q.z, yz) + p.proj.w) / (float)kMinmaxSubsample;
-    if ((float)ul.x > floorf(px)) ul.x = f2i(floorf(px));
-    if ((float)lr.x < ceilf(px)) lr.x = f2i(ceilf(px));
-    if ((float)ul.y > floorf(py)) ul.y = f2i(floorf(py));
-    if ((float)lr.y < ceilf(py)) lr.y = f2i(ceilf(py));
+    const float yz = Ops::rcp(q.z);
+    float px = (Ops::div(p.proj.x * q.x, q.z, yz) + p.proj.z) / (float)kMinmaxSubsample;
+    float py = (Ops::div(p.proj.y * q.y, q.z, yz) + p.proj.w) / (float)kMinmaxSubsample;
+    if ((float)ul.x > Ops::floor(px)) ul.x = Ops::f2i(Ops::floor(px));
+    if ((float)lr.x < Ops::ceil(px)) lr.x = Ops::f2i(Ops::ceil(px));
+    if ((float)ul.y > Ops::floor(py)) ul.y = Ops::f2i(Ops::floor(py));
+    if ((float)lr.y < Ops::ceil(py)) lr.y = Ops::f2i(Ops::ceil(py));
     if (zr.x > q.z) zr.x = q.z;
     if (zr.y < q.z) zr.y = q.z;
   }
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, cons
     float2 zr = make_float2(0.f, 0.f);
     if (i < n) {
       const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the visible-block stream: 16 B per lane, coalesced
-      if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
+      if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
     float2 zr = make_float2(0.f, 0.f);
     if (i < n) {
       const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the visible-block stream: 16 B per lane, coalesced
-      if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
+      if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
     float2 zr = make_float2(0.f, 0.f);
     if (i < n) {
       const dsr_hash_entry he = entry_of_record(visBlocks[i]);
-      if (he.ptr >= 0) valid = project_single_block(he.pos, p, mw, mh, ul, lr, zr);
+      if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
     }
     const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
     const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;

@@ -20,6 +20,9 @@ struct HostOps {
   static bool any(bool b) { return b; }
   static float sqrt(float f) { return sqrtf(f); }
   static float floor(float f) { return floorf(f); }
+  static float ceil(float f) { return ceilf(f); }
+  static float rcp(float) { return 0.0f; }                       // the device shares a refined reciprocal between two divisions ...
+  static float div(float a, float b, float) { return a / b; }    // ... whose results are the correctly rounded quotients (dsr_selftest_division)
 };
 }  // namespace
 
@@ -92,6 +95,30 @@ extern "C" int rr_render_all(int type, const float *M, const float *invM, float 
       std::memcpy(rgbaOut + 4 * i, &c, 4);
       depthOut[i] = render_depth(p, pr[i]);
     }
+  return 0;
+}
+
+// K6 (k_expected_depth*): the range image of a view from the blocks of its visible list (pos: n x 3 int16, block coordinates)
+extern "C" int rr_range_image(const float *M, const float *proj, float voxelSize, int W, int H, const short *pos, int n, float *minmaxOut) {
+  using namespace dsr;
+  FrameP p;
+  std::memset(&p, 0, sizeof p);
+  std::memcpy(p.M.m, M, sizeof p.M.m);
+  p.proj = make_float4(proj[0], proj[1], proj[2], proj[3]);
+  p.voxelSize = voxelSize; p.W = W; p.H = H;
+  const int mw = (W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (H + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  for (int c = 0; c < mw * mh; ++c) { minmaxOut[2 * c] = kFarAway; minmaxOut[2 * c + 1] = kVeryClose; }
+  for (int i = 0; i < n; ++i) {
+    int2 ul, lr;
+    float2 zr;
+    if (!project_single_block<HostOps>(pos + 3 * i, p, mw, mh, ul, lr, zr)) continue;
+    for (int y = ul.y; y <= lr.y; ++y)
+      for (int x = ul.x; x <= lr.x; ++x) {
+        float *c = minmaxOut + 2 * (x + y * mw);
+        if (zr.x < c[0]) c[0] = zr.x;
+        if (zr.y > c[1]) c[1] = zr.y;
+      }
+  }
   return 0;
 }
 

@@ -162,3 +162,34 @@ def test_free_view_shading_equals_oracle(image_type):
         assert np.array_equal(rgba, want_rgba), f"{(rgba != want_rgba).any(axis=-1).sum()} pixels differ"
     o.close()
 
+
+@pytest.mark.parametrize("kw", [{}, dict(voxel_size=0.02, mu=0.08, sdf_local_block_num=150000, hash_bucket_num=0x40000)])
+def test_range_image_equals_oracle(kw):
+    """K6: project_single_block (the function all three range-image kernels call) folded over the visible list on the CPU
+    equals the oracle's range image — for the tracking view and for a free view."""
+    from dynslam_amd import _capi
+    lib = _lib()
+    sc, o, settings = _oracle_scene(3, **kw)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    proj = np.array(sc.intrinsics(), np.float32)
+    mw, mh = (o.W + 7) // 8, (o.H + 7) // 8
+
+    def check(M, freeview):
+        table = o.dump_hash_table()
+        ids = o.dump_visible_list(freeview)
+        ids = ids[table["ptr"][ids] >= 0]
+        pos = np.ascontiguousarray(table["pos"][ids].astype(np.int16))
+        got = np.zeros((mh, mw, 2), np.float32)
+        Mc = np.ascontiguousarray(M.T.astype(np.float32)).ravel()
+        assert lib.rr_range_image(p(Mc), p(proj), C.c_float(settings["voxel_size"]), o.W, o.H, p(pos), len(ids), p(got)) == 0
+        want = o.dump_render_state(freeview)["minmax"]
+        assert (want[..., 0] < want[..., 1]).sum() > 0.2 * mw * mh
+        _assert_same(got, want)
+
+    M_live, _ = o.get_pose()
+    check(M_live, False)
+    M = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
+    o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=M)
+    check(M, True)
+    o.close()
+
