@@ -152,6 +152,21 @@ __host__ __device__ __forceinline__ float sdf_to_float(float v) { return v / 327
 __host__ __device__ __forceinline__ float sdf_to_float_short(float v) { return div_short(v, 32767.0f, 1.0f / 32767.0f); }
 __device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f * 32767.0f); }
 
+// The per-pixel / per-block functions of the range-image, visibility, raycast and shading kernels are templates over an Ops
+// policy — how to convert float -> int, round down / up, divide by a tame divisor, ask "any ray of the wave" —: the device's
+// instructions here, a one-ray host stand-in in tests/hostsim, under which tests/test_raycast_host.py runs those very functions
+// on the CPU against the oracle.
+struct DeviceOps {
+  static __device__ __forceinline__ int f2i(float f) { return dsr::f2i(f); }
+  static __device__ __forceinline__ bool any(bool b) { return __any(b) != 0; }
+  static __device__ __forceinline__ float sqrt(float f) { return sqrtf(f); }
+  static __device__ __forceinline__ float floor(float f) { return floorf(f); }
+  static __device__ __forceinline__ float ceil(float f) { return ceilf(f); }
+  // a / b for "tame" operands (dsr_device.h): the refined reciprocal of b, shared by the divisions by one divisor
+  static __device__ __forceinline__ float rcp(float b) { return rcp_refined(b); }
+  static __device__ __forceinline__ float div(float a, float b, float y) { return div_with_rcp(a, b, y); }
+};
+
 // ORUtils Matrix4 * Vector4, the three rows the kernels use (w explicit)
 __host__ __device__ __forceinline__ float3 mat_mul3(const Mat4 &a, float x, float y, float z, float w) {
   float3 r;

@@ -392,15 +392,15 @@ __global__ __launch_bounds__(256) void k_alloc_apply(FrameP p, SceneP s, const f
 
 // ITMSceneReconstructionEngine.h checkPointVisibility / checkBlockVisibility (corner
 // order and the incremental +=factor arithmetic are part of the result).
-template <bool useSwapping>
-__device__ __forceinline__ void check_point_visibility(bool &isVisible, bool &isVisibleEnlarged, float x, float y, float z,
-                                                       const Mat4 &M, const float4 &proj, int W, int H) {
+template <bool useSwapping, class Ops = DeviceOps>
+__host__ __device__ __forceinline__ void check_point_visibility(bool &isVisible, bool &isVisibleEnlarged, float x, float y, float z,
+                                                                const Mat4 &M, const float4 &proj, int W, int H) {
   float3 b = mat_mul3(M, x, y, z, 1.0f);
   if (b.z < 1e-10f) return;
   // b.z >= 1e-10: tame divisor, the two divisions share the refined reciprocal (dsr_device.h)
-  const float yz = rcp_refined(b.z);
-  float u = div_with_rcp(proj.x * b.x, b.z, yz) + proj.z;
-  float v = div_with_rcp(proj.y * b.y, b.z, yz) + proj.w;
+  const float yz = Ops::rcp(b.z);
+  float u = Ops::div(proj.x * b.x, b.z, yz) + proj.z;
+  float v = Ops::div(proj.y * b.y, b.z, yz) + proj.w;
   if (u >= 0 && u < (float)W && v >= 0 && v < (float)H) {
     isVisible = true; isVisibleEnlarged = true;
   } else if (useSwapping) {
@@ -408,27 +408,27 @@ __device__ __forceinline__ void check_point_visibility(bool &isVisible, bool &is
     if (u >= (float)lx && u < (float)ly && v >= (float)lz && v < (float)lw) isVisibleEnlarged = true;
   }
 }
-template <bool useSwapping>
-__device__ __forceinline__ void check_block_visibility(bool &isVisible, bool &isVisibleEnlarged, const short pos[3],
-                                                       const Mat4 &M, const float4 &proj, float voxelSize, int W, int H) {
+template <bool useSwapping, class Ops = DeviceOps>
+__host__ __device__ __forceinline__ void check_block_visibility(bool &isVisible, bool &isVisibleEnlarged, const short pos[3],
+                                                                const Mat4 &M, const float4 &proj, float voxelSize, int W, int H) {
   const float factor = (float)kBlockSize * voxelSize;
   isVisible = false; isVisibleEnlarged = false;
   float x = (float)pos[0] * factor, y = (float)pos[1] * factor, z = (float)pos[2] * factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   z += factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   y += factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   x += factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   z -= factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   y -= factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   x -= factor; y += factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H); if (isVisible) return;
   x += factor; y -= factor; z += factor;
-  check_point_visibility<useSwapping>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H);
+  check_point_visibility<useSwapping, Ops>(isVisible, isVisibleEnlarged, x, y, z, M, proj, W, H);
 }
 
 // K0b: the "visible at the previous frame" pass.  The serial engine marks last frame's visible

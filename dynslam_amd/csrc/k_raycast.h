@@ -53,19 +53,6 @@ __host__ __device__ __forceinline__ uint32_t load_pair(const short *p) {
 // except for x = -0 (-0.5 instead of +0.5: both convert to 0) and saves a compare + select per coordinate (six per iteration).
 __host__ __device__ __forceinline__ float roundf_itm(float x) { return x + __builtin_copysignf(0.5f, x); }
 
-// How the march converts float -> int, rounds down and asks "any ray of the wave": the device's instructions here, a one-ray
-// host stand-in in tests/hostsim (which runs cast_ray on the CPU against the oracle's raycast, tests/test_raycast_host.py).
-struct DeviceOps {
-  static __device__ __forceinline__ int f2i(float f) { return dsr::f2i(f); }
-  static __device__ __forceinline__ bool any(bool b) { return __any(b) != 0; }
-  static __device__ __forceinline__ float sqrt(float f) { return sqrtf(f); }
-  static __device__ __forceinline__ float floor(float f) { return floorf(f); }
-  static __device__ __forceinline__ float ceil(float f) { return ceilf(f); }
-  // a / b for "tame" operands (dsr_device.h): the refined reciprocal of b, shared by the divisions by one divisor
-  static __device__ __forceinline__ float rcp(float b) { return rcp_refined(b); }
-  static __device__ __forceinline__ float div(float a, float b, float y) { return div_with_rcp(a, b, y); }
-};
-
 // The blocks a 2x2x2 voxel cell with base block (bx0, by0, bz0) touches: slot c = (ox, oy, oz) in {0,1}^3 is needed iff the
 // cell straddles (f*) in every axis where o = 1.  Blocks the caller already knows (cache, cache2 — which also remembers
 // absent blocks) cost nothing; the others are looked up in ROUNDS of one bucket head per ray for all rays of the wave

@@ -25,7 +25,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _lib():
-    deps = [SRC] + [os.path.join(CSRC, h) for h in ("k_raycast.h", "dsr_device.h")]
+    deps = [SRC] + [os.path.join(CSRC, h) for h in ("k_raycast.h", "k_alloc.h", "dsr_device.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
             pytest.skip("hipcc not available to build the host stand-in")
@@ -191,5 +191,30 @@ def test_range_image_equals_oracle(kw):
     M = np.linalg.inv(sc.pose(1).astype(np.float64)).astype(np.float32)
     o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=M)
     check(M, True)
+    o.close()
+
+
+def test_free_view_visible_list_equals_oracle():
+    """K5: check_block_visibility (also the previous-frame re-test of K0b) over the whole table on the CPU == the oracle's
+    free-view visible list, for a camera that sees only part of the map."""
+    from dynslam_amd import _capi
+    lib = _lib()
+    sc, o, settings = _oracle_scene(5)
+    T = sc.pose(1).astype(np.float64)
+    yaw = np.eye(4)
+    a = np.deg2rad(25.0)
+    yaw[0, 0], yaw[0, 2], yaw[2, 0], yaw[2, 2] = np.cos(a), np.sin(a), -np.sin(a), np.cos(a)
+    M = np.linalg.inv(T @ yaw).astype(np.float32)
+    o.get_image(_capi.IMAGE_FREECAMERA_SHADED, pose_m=M)
+    want = o.dump_visible_list(True)
+    table = o.dump_hash_table()
+    ids = np.zeros(o.no_total_entries, np.int32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    Mc = np.ascontiguousarray(M.T).ravel()
+    proj = np.array(sc.intrinsics(), np.float32)
+    n = lib.rr_freeview_visible(p(Mc), p(proj), C.c_float(settings["voxel_size"]), o.W, o.H, p(table), o.no_total_entries, p(ids))
+    allocated = int((table["ptr"] >= 0).sum())
+    assert 100 < len(want) < allocated, (len(want), allocated)  # part of the map, not all of it
+    assert n == len(want) and np.array_equal(ids[:n], want)
     o.close()
 
