@@ -154,7 +154,7 @@ __device__ __forceinline__ short sdf_from_float(float f) { return (short)f2i(f *
 
 // The per-pixel / per-block functions of the range-image, visibility, raycast and shading kernels are templates over an Ops
 // policy — how to convert float -> int, round down / up, divide by a tame divisor, ask "any ray of the wave" —: the device's
-// instructions here, a one-ray host stand-in in tests/hostsim, under which tests/test_raycast_host.py runs those very functions
+// instructions here, a one-ray host stand-in in tests/hostsim, under which tests/test_device_functions_host.py runs those very functions
 // on the CPU against the oracle.
 struct DeviceOps {
   static __device__ __forceinline__ int f2i(float f) { return dsr::f2i(f); }

@@ -99,7 +99,8 @@ struct AllocRay {
 };
 
 // First half of buildHashAllocAndVisibleTypePP: the ray segment [d-mu, d+mu] in block units.
-__device__ __forceinline__ bool alloc_ray(const FrameP &p, const float *__restrict__ depth, int x, int y, AllocRay &r) {
+template <class Ops = DeviceOps>
+__host__ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float *__restrict__ depth, int x, int y, AllocRay &r) {
   float depth_measure = depth[x + y * p.W];
   if (depth_measure <= 0 || (depth_measure - p.mu) < 0 || (depth_measure - p.mu) < p.vfMin ||
       (depth_measure + p.mu) > p.vfMax)
@@ -109,7 +110,7 @@ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float *__restri
   float cz = depth_measure;
   float cx = cz * (((float)x - p.proj.z) * invFx);
   float cy = cz * (((float)y - p.proj.w) * invFy);
-  float norm = sqrtf(cx * cx + cy * cy + cz * cz);
+  float norm = Ops::sqrt(cx * cx + cy * cy + cz * cz);
   float f1 = 1.0f - p.mu / norm;
   float3 t = mat_mul3(p.invM, cx * f1, cy * f1, cz * f1, 1.0f);
   r.px = t.x * oneOverVoxelSize; r.py = t.y * oneOverVoxelSize; r.pz = t.z * oneOverVoxelSize;
@@ -117,8 +118,8 @@ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float *__restri
   t = mat_mul3(p.invM, cx * f2, cy * f2, cz * f2, 1.0f);
   float ex = t.x * oneOverVoxelSize, ey = t.y * oneOverVoxelSize, ez = t.z * oneOverVoxelSize;
   float dx = ex - r.px, dy = ey - r.py, dz = ez - r.pz;
-  norm = sqrtf(dx * dx + dy * dy + dz * dz);
-  r.noSteps = f2i(ceilf(2.0f * norm));
+  norm = Ops::sqrt(dx * dx + dy * dy + dz * dz);
+  r.noSteps = Ops::f2i(Ops::ceil(2.0f * norm));
   float denom = (float)(r.noSteps - 1);
   r.dx = dx / denom; r.dy = dy / denom; r.dz = dz / denom;
   return true;

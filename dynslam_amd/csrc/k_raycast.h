@@ -475,7 +475,7 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
         //  all 7.3 k waves are resident at once; a wave runs 105 dependent memory stages where its neediest single ray needs 35;
         //  while all waves run, a stage costs its round trip plus the wave's share of a half-busy SIMD (~160 instructions),
         //  and the launch's last third runs with a few per cent of the waves, the ones with 200+ iterations of absent blocks), all
-        //  verified bit-exact on the CPU first (tests/test_raycast_host.py) and then on the GPU:
+        //  verified bit-exact on the CPU first (tests/test_device_functions_host.py) and then on the GPU:
         //   * an occupancy BITMAP per 4x4x4-block cell in front of the table (clear bit = no such block, no read at all):
         //     -21 % bytes fetched, one more dependent round for every block that exists: 536 vs 461 us;
         //   * rays advancing independently through a per-ray state machine, one read per ray and round (a wave needs as many
@@ -572,7 +572,7 @@ __host__ __device__ __forceinline__ uchar4 grey_px(float angle) {  // drawPixelG
 }
 
 // ITMVisualisationEngine.h processPixelICP<true> + computeNormalAndAngle<true> (image space), one pixel.  (Like cast_ray a
-// template over Ops so that tests/test_raycast_host.py runs it on the CPU against the oracle.)
+// template over Ops so that tests/test_device_functions_host.py runs it on the CPU against the oracle.)
 template <class Ops>
 __host__ __device__ __forceinline__ void icp_pixel(const FrameP &p, const float4 *__restrict__ pointsRay, int x, int y,
                                                    float4 &pointOut, float4 &normalOut, uchar4 &greyOut) {

@@ -1,11 +1,13 @@
 // Host stand-in for ONE lane of k_raycast / k_icp_maps / k_render: the per-pixel device functions cast_ray<Ops>, icp_pixel<Ops>
 // and render_pixel<Ops> (dynslam_amd/csrc/k_raycast.h) compiled for the CPU with a one-ray Ops, so that
-// tests/test_raycast_host.py can check the march — its table walk, its look-ahead slot, the trilinear reads with their block
+// tests/test_device_functions_host.py can check the march — its table walk, its look-ahead slot, the trilinear reads with their block
 // rounds — and the shading (image-space normals, SDF-gradient normals, interpolated colours, the depth-weight map) against the
 // oracle WITHOUT a GPU.
 // Test infrastructure: built by the test with hipcc (host code only is run), never part of libdsr_hip.so.
 #include <cmath>
 #include <cstring>
+#include <set>
+#include <tuple>
 
 #include "../../dynslam_amd/csrc/k_alloc.h"
 #include "../../dynslam_amd/csrc/k_raycast.h"
@@ -136,6 +138,35 @@ extern "C" int rr_freeview_visible(const float *M, const float *proj, float voxe
     bool vis, visEnlarged;
     check_block_visibility<false, HostOps>(vis, visEnlarged, table[t].pos, m, pr, voxelSize, W, H);
     if (vis) idsOut[n++] = t;
+  }
+  return n;
+}
+
+// K1 (buildHashAllocAndVisibleTypePP): the blocks the depth rays of a frame ask for — alloc_ray's segment [d - mu, d + mu] walked
+// with the kernel's running additions.  out: up to cap (x, y, z) int16 triples, sorted; returns the number of distinct blocks.
+extern "C" int rr_alloc_blocks(const float *invM, const float *proj, float voxelSize, float mu, float vfMin, float vfMax, int W, int H,
+                               const float *depth, short *out, int cap) {
+  using namespace dsr;
+  FrameP p;
+  std::memset(&p, 0, sizeof p);
+  std::memcpy(p.invM.m, invM, sizeof p.invM.m);
+  p.proj = make_float4(proj[0], proj[1], proj[2], proj[3]);
+  p.voxelSize = voxelSize; p.mu = mu; p.vfMin = vfMin; p.vfMax = vfMax; p.W = W; p.H = H;
+  std::set<std::tuple<short, short, short>> blocks;
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+      AllocRay r;
+      if (!alloc_ray<HostOps>(p, depth, x, y, r)) continue;
+      float px = r.px, py = r.py, pz = r.pz;
+      for (int i = 0; i < r.noSteps; ++i) {
+        blocks.emplace((short)HostOps::f2i(floorf(px)), (short)HostOps::f2i(floorf(py)), (short)HostOps::f2i(floorf(pz)));
+        px += r.dx; py += r.dy; pz += r.dz;
+      }
+    }
+  int n = 0;
+  for (const auto &b : blocks) {
+    if (n < cap) { out[3 * n] = std::get<0>(b); out[3 * n + 1] = std::get<1>(b); out[3 * n + 2] = std::get<2>(b); }
+    ++n;
   }
   return n;
 }

@@ -2,7 +2,7 @@
 render_pixel) against the oracle — on the CPU.
 
 cast_ray is written against a small `Ops` policy (float -> int conversion, "any ray of the wave"), so the very function the
-kernel runs can be compiled for the host with a one-ray Ops (tests/hostsim/raycast_host.hip) and driven over the oracle's
+kernel runs can be compiled for the host with a one-ray Ops (tests/hostsim/device_functions_host.hip) and driven over the oracle's
 table, voxels and range image: the table walk, the look-ahead slot and the trilinear reads with their block rounds must
 reproduce the oracle's raycast bit for bit.  Here, without a GPU; the same comparison runs on the device in the -m gpu suite.
 (It is also how variants of the march were verified before any GPU time was spent on them: profiles/r03_raycast_*_variant*.)
@@ -18,8 +18,8 @@ import pytest
 from tests.common import SMALL
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "hostsim", "raycast_host.hip")
-LIB = os.path.join(HERE, "hostsim", "_build", "libraycast_host.so")
+SRC = os.path.join(HERE, "hostsim", "device_functions_host.hip")
+LIB = os.path.join(HERE, "hostsim", "_build", "libdevice_functions_host.so")
 CSRC = os.path.join(os.path.dirname(HERE), "dynslam_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -216,5 +216,43 @@ def test_free_view_visible_list_equals_oracle():
     allocated = int((table["ptr"] >= 0).sum())
     assert 100 < len(want) < allocated, (len(want), allocated)  # part of the map, not all of it
     assert n == len(want) and np.array_equal(ids[:n], want)
+    o.close()
+
+
+def test_allocation_ray_walk_equals_oracle():
+    """K1: the blocks the depth rays of a frame ask for (alloc_ray + the kernel's running additions, on the CPU) are exactly
+    the blocks the oracle ends up allocating for that view from an empty scene."""
+    from dynslam_amd.engine import make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, oracle_settings
+    lib = _lib()
+    W, H = 320, 96
+    sc = StreetScene(W, H)
+    o = OracleEngine(oracle_settings(**SMALL), make_calib(*sc.intrinsics(), W, H))
+    rgba, d, T, _ = sc.frame(0)
+    o.update_view(rgba, d)
+    o.set_pose_inv_m(T)
+    # one entry per bucket / chain tail and frame (the last writer wins): blocks that collide wait for the next frame.  Repeating
+    # the allocation from the same view converges to everything the rays ask for.
+    counts = []
+    for _ in range(12):
+        o.allocate_scene_from_depth()
+        table = o.dump_hash_table()
+        counts.append(int((table["ptr"] >= 0).sum()))
+        if len(counts) > 1 and counts[-1] == counts[-2]:
+            break
+    assert counts[0] < counts[-1] and counts[-1] == counts[-2], counts
+    want = np.unique(table["pos"][table["ptr"] >= 0].astype(np.int16), axis=0)
+    depth = np.ascontiguousarray(o.get_view()[1].astype(np.float32))
+    _, inv_m = o.get_pose()
+    inv_c = np.ascontiguousarray(inv_m.T.astype(np.float32)).ravel()
+    proj = np.array(sc.intrinsics(), np.float32)
+    out = np.zeros((SMALL["sdf_local_block_num"], 3), np.int16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = lib.rr_alloc_blocks(p(inv_c), p(proj), C.c_float(SMALL["voxel_size"]), C.c_float(SMALL["mu"]), C.c_float(SMALL["view_frustum_min"]),
+                            C.c_float(SMALL["view_frustum_max"]), W, H, p(depth), p(out), len(out))
+    assert 1000 < n <= len(out)
+    got = out[:n]  # sorted lexicographically by the harness, like np.unique's rows
+    assert len(want) == n and np.array_equal(got, want)
     o.close()
 
