@@ -1,8 +1,9 @@
-// Host stand-in for ONE lane of k_raycast / k_icp_maps / k_render: the per-pixel device functions cast_ray<Ops>, icp_pixel<Ops>
-// and render_pixel<Ops> (dynslam_amd/csrc/k_raycast.h) compiled for the CPU with a one-ray Ops, so that
-// tests/test_device_functions_host.py can check the march — its table walk, its look-ahead slot, the trilinear reads with their block
-// rounds — and the shading (image-space normals, SDF-gradient normals, interpolated colours, the depth-weight map) against the
-// oracle WITHOUT a GPU.
+// Host stand-ins for ONE lane of the kernels: their per-pixel / per-block device functions — alloc_ray, check_block_visibility
+// (k_alloc.h), project_single_block, cast_ray, icp_pixel, render_pixel (k_raycast.h), all templates over an Ops policy —
+// compiled for the CPU with a one-ray Ops, so that tests/test_device_functions_host.py can check the allocation ray walk, the
+// frustum test, the range image, the march (table walk, look-ahead slot, trilinear reads with their block rounds) and the
+// shading (image-space normals, SDF-gradient normals, interpolated colours, the depth-weight map) against the oracle
+// WITHOUT a GPU.
 // Test infrastructure: built by the test with hipcc (host code only is run), never part of libdsr_hip.so.
 #include <cmath>
 #include <cstring>

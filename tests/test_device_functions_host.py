@@ -1,11 +1,12 @@
-"""The ray march of k_raycast and the shading of k_icp_maps / k_render (dynslam_amd/csrc/k_raycast.h cast_ray, icp_pixel,
-render_pixel) against the oracle — on the CPU.
+"""Device functions of the HIP kernels, run on the CPU against the oracle.
 
-cast_ray is written against a small `Ops` policy (float -> int conversion, "any ray of the wave"), so the very function the
-kernel runs can be compiled for the host with a one-ray Ops (tests/hostsim/device_functions_host.hip) and driven over the oracle's
-table, voxels and range image: the table walk, the look-ahead slot and the trilinear reads with their block rounds must
-reproduce the oracle's raycast bit for bit.  Here, without a GPU; the same comparison runs on the device in the -m gpu suite.
-(It is also how variants of the march were verified before any GPU time was spent on them: profiles/r03_raycast_*_variant*.)
+The per-pixel / per-block functions of the allocation, visibility, range-image, raycast and shading kernels (alloc_ray,
+check_block_visibility, project_single_block, cast_ray, icp_pixel, render_pixel in dynslam_amd/csrc/k_alloc.h / k_raycast.h) are
+templates over a small `Ops` policy (float -> int conversion, floor / ceil / sqrt, division by a tame divisor, "any ray of the
+wave"), so the very functions the kernels run can be compiled for the host with a one-ray Ops
+(tests/hostsim/device_functions_host.hip) and driven over the oracle's table, voxels, views and range images: they must
+reproduce the oracle bit for bit.  Here, without a GPU; the same comparisons run on the device in the -m gpu suite.
+(It is also how variants of the ray march were verified before any GPU time was spent on them: profiles/r03_raycast_*_variant*.)
 """
 import ctypes as C
 import os
