@@ -1539,21 +1539,6 @@ int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, 
 
 // ---- instance compositing
 
-static const unsigned char kMatplotlib2Palette[10][3] = {  // InstanceReconstructor.cpp:44-55
-    {0x1f, 0x77, 0xb4}, {0xff, 0x7f, 0x0e}, {0x2c, 0xa0, 0x2c}, {0xd6, 0x27, 0x28}, {0x94, 0x67, 0xbd},
-    {0x8c, 0x56, 0x4b}, {0xe3, 0x77, 0xc2}, {0x71, 0x71, 0x71}, {0xbc, 0xbd, 0x22}, {0x17, 0xbe, 0xcf}};
-
-static CompositeP composite_params(const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength, int dim_background) {
-  CompositeP c;
-  memset(&c, 0, sizeof c);
-  c.nLayers = n_layers; c.nPixels = n_pixels; c.dimBackground = dim_background; c.tintStrength = tint_strength;
-  for (int l = 0; l < n_layers; ++l) {
-    const unsigned char *t = kMatplotlib2Palette[((track_ids[l] % 10) + 10) % 10];
-    c.tint[l] = make_uchar4(t[0], t[1], t[2], 255);
-  }
-  return c;
-}
-
 int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
                                 const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
                                 int n_layers, int n_pixels, float tint_strength, int dim_background) {

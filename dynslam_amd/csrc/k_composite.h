@@ -7,6 +7,8 @@
 // Colour arithmetic follows the reference's C++ promotions: uchar * double for the colour
 // term, int * float (then widened) for the tint term.
 #pragma once
+#include <cstring>
+
 #include "dsr_device.h"
 
 namespace dsr {
@@ -23,12 +25,27 @@ struct CompositeLayers {  // one (colour, depth) pointer pair per layer: the lay
   const float *depth[kMaxCompositeLayers];
 };
 
+// kMatplotlib2Palette (InstanceReconstructor.cpp:44-55) and the parameter block of a composite
+static const unsigned char kMatplotlib2Palette[10][3] = {
+    {0x1f, 0x77, 0xb4}, {0xff, 0x7f, 0x0e}, {0x2c, 0xa0, 0x2c}, {0xd6, 0x27, 0x28}, {0x94, 0x67, 0xbd},
+    {0x8c, 0x56, 0x4b}, {0xe3, 0x77, 0xc2}, {0x71, 0x71, 0x71}, {0xbc, 0xbd, 0x22}, {0x17, 0xbe, 0xcf}};
+inline CompositeP composite_params(const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength, int dim_background) {
+  CompositeP c;
+  memset(&c, 0, sizeof c);
+  c.nLayers = n_layers; c.nPixels = n_pixels; c.dimBackground = dim_background; c.tintStrength = tint_strength;
+  for (int l = 0; l < n_layers; ++l) {
+    const unsigned char *t = kMatplotlib2Palette[((track_ids[l] % 10) + 10) % 10];
+    c.tint[l] = make_uchar4(t[0], t[1], t[2], 255);
+  }
+  return c;
+}
+
+// one pixel of the composite (a __host__ __device__ function: tests/test_reference_edges.py also runs it on the CPU against the
+// reference's own CompositeColor / CompositeDepth)
 template <bool PTRS>
-__global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
-                                                   const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth,
-                                                   CompositeLayers lp) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c.nPixels) return;
+__host__ __device__ __forceinline__ void composite_px(int i, const CompositeP &c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
+                                                      const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth,
+                                                      const CompositeLayers &lp) {
   float t = tDepth[i];
   uchar4 col = make_uchar4(0, 0, 0, 0);
   if (tRgba) {
@@ -70,6 +87,15 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
   }
   tDepth[i] = t;
   if (tRgba) tRgba[i] = col;
+}
+
+template <bool PTRS>
+__global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
+                                                   const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth,
+                                                   CompositeLayers lp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.nPixels) return;
+  composite_px<PTRS>(i, c, tRgba, tDepth, lRgba, lDepth, lp);
 }
 
 }  // namespace dsr

@@ -1,5 +1,6 @@
 // Host stand-ins for ONE lane of the kernels: their per-pixel / per-block device functions — alloc_ray, check_block_visibility
-// (k_alloc.h), project_single_block, cast_ray, icp_pixel, render_pixel (k_raycast.h), all templates over an Ops policy —
+// (k_alloc.h), project_single_block, cast_ray, icp_pixel, render_pixel (k_raycast.h), the per-element functions of k_edges.h and
+// k_composite.h (checked against the REFERENCE'S OWN code by tests/test_reference_edges.py), templates over an Ops policy —
 // compiled for the CPU with a one-ray Ops, so that tests/test_device_functions_host.py can check the allocation ray walk, the
 // frustum test, the range image, the march (table walk, look-ahead slot, trilinear reads with their block rounds) and the
 // shading (image-space normals, SDF-gradient normals, interpolated colours, the depth-weight map) against the oracle
@@ -11,6 +12,8 @@
 #include <tuple>
 
 #include "../../dynslam_amd/csrc/k_alloc.h"
+#include "../../dynslam_amd/csrc/k_composite.h"
+#include "../../dynslam_amd/csrc/k_edges.h"
 #include "../../dynslam_amd/csrc/k_raycast.h"
 
 namespace {
@@ -170,5 +173,52 @@ extern "C" int rr_alloc_blocks(const float *invM, const float *proj, float voxel
     ++n;
   }
   return n;
+}
+
+// ---- the edges of the path (k_edges.h, k_composite.h): same arguments as the dsr_* entry points of include/dsr.h
+
+extern "C" int hs_depth_from_disparity(const float *disparity, int16_t *depth_mm_out, int n, float baseline_m, float focal_px, float scale,
+                                       float min_depth_m, float max_depth_m) {
+  const int minMm = (int)(min_depth_m * 1000.0f), maxMm = (int)(max_depth_m * 1000.0f);  // dsr_depth_from_disparity_dev
+  if (maxMm >= 32767) return 1;
+  for (int i = 0; i < n; ++i) dsr::depth_from_disparity_px<HostOps>(i, disparity, depth_mm_out, baseline_m, focal_px, scale, minMm, maxMm);
+  return 0;
+}
+extern "C" int hs_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n) {
+  for (int i = 0; i < n; ++i) dsr::bgr_to_rgba_px(i, bgr, reinterpret_cast<uchar4 *>(rgba_out));
+  return 0;
+}
+extern "C" int hs_rgba_to_bgr(const uint8_t *rgba, uint8_t *bgr_out, int n) {
+  for (int i = 0; i < n; ++i) dsr::rgba_to_bgr_px(i, reinterpret_cast<const uchar4 *>(rgba), bgr_out);
+  return 0;
+}
+extern "C" int hs_depth_m_to_mm(const float *depth_m, int16_t *depth_mm_out, int n) {
+  for (int i = 0; i < n; ++i) dsr::depth_m_to_mm_px<HostOps>(i, depth_m, depth_mm_out);
+  return 0;
+}
+extern "C" int hs_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba, const float *layers_depth,
+                                      const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength, int dim_background) {
+  using namespace dsr;
+  if (n_layers > kMaxCompositeLayers) return 1;
+  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  CompositeLayers none;
+  std::memset(&none, 0, sizeof none);
+  for (int i = 0; i < n_pixels; ++i)
+    composite_px<false>(i, c, reinterpret_cast<uchar4 *>(target_rgba), target_depth, reinterpret_cast<const uchar4 *>(layers_rgba), layers_depth, none);
+  return 0;
+}
+// ProcessSilhouette_CPU / RemoveSilhouette_CPU on plain buffers (the dsr_view_* entry points apply them to two engines' views)
+extern "C" int hs_extract_silhouette(const uint8_t *src_rgba, const float *src_depth, uint8_t *dst_rgba, float *dst_depth, int W, int H,
+                                     const uint8_t *mask, int x0, int y0, int bw, int bh) {
+  for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x)
+      dsr::extract_silhouette_px(x, y, reinterpret_cast<const uchar4 *>(src_rgba), src_depth, reinterpret_cast<uchar4 *>(dst_rgba), dst_depth, W, mask,
+                                 x0, y0, bw, bh);
+  return 0;
+}
+extern "C" int hs_remove_silhouette(uint8_t *rgba, float *depth, int W, int H, const uint8_t *mask, int x0, int y0, int bw, int bh) {
+  for (int row = 0; row < bh; ++row)
+    for (int col = 0; col < bw; ++col) dsr::remove_silhouette_px(col, row, reinterpret_cast<uchar4 *>(rgba), depth, W, H, mask, x0, y0, bw);
+  return 0;
 }
 

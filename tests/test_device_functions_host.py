@@ -26,7 +26,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
 def _lib():
-    deps = [SRC] + [os.path.join(CSRC, h) for h in ("k_raycast.h", "k_alloc.h", "dsr_device.h")]
+    deps = [SRC] + [os.path.join(CSRC, h) for h in ("k_raycast.h", "k_alloc.h", "k_edges.h", "k_composite.h", "dsr_device.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         if not (os.path.exists(HIPCC) or shutil.which(HIPCC)):
             pytest.skip("hipcc not available to build the host stand-in")

@@ -242,3 +242,59 @@ def test_oracle_edges_equal_reference_code_on_special_values(oracle_lib, ref):
 @pytest.mark.gpu
 def test_hip_edges_equal_reference_code_on_special_values(hip_api, ref):
     check_special_values(hip_api, ref, 20)
+
+
+# --- the HIP kernels' per-element device functions, compiled for the CPU (tests/hostsim), against the reference's own code ----
+# (k_edges.h / k_composite.h: one thread per element around a __host__ __device__ function; here those functions run on the
+#  host — the same source the GPU runs, pinned by the reference itself without a GPU.)
+
+class _DeviceFunctionsOnHost:
+    """The five buffer-level entry points the checks above call, bound to the host stand-in library."""
+
+    def __init__(self, lib):
+        F, I, P = C.c_float, C.c_int, C.c_void_p
+        sig = {"depth_from_disparity": [P, P, I, F, F, F, F, F], "bgr_to_rgba": [P, P, I], "rgba_to_bgr": [P, P, I],
+               "depth_m_to_mm": [P, P, I], "composite_instances": [P, P, P, P, P, I, I, F, I]}
+        for name, args in sig.items():
+            fn = getattr(lib, "hs_" + name)
+            fn.restype, fn.argtypes = I, args
+            setattr(self, name, fn)
+        self.lib = lib
+
+
+@pytest.fixture(scope="module")
+def devfn_host():
+    from tests.test_device_functions_host import _lib
+    return _DeviceFunctionsOnHost(_lib())
+
+
+def test_device_functions_composite_equals_reference_code(devfn_host, ref):
+    check_composite(devfn_host, ref)
+
+
+def test_device_functions_disparity_and_conversions_equal_reference_code(devfn_host, ref):
+    check_disparity_and_conversions(devfn_host, ref)
+
+
+def test_device_functions_equal_reference_code_on_special_values(devfn_host, ref):
+    check_special_values(devfn_host, ref, 60)
+
+
+def test_device_functions_silhouettes_equal_reference_code(devfn_host, ref):
+    """k_extract_silhouette / k_remove_silhouette's per-pixel functions on plain buffers == ProcessSilhouette_CPU /
+    RemoveSilhouette_CPU, over boxes sticking out of the frame on every side and masks with values other than 0 / 1."""
+    lib = devfn_host.lib
+    rgba, depth = frame(1)
+    cur_rgba, cur_depth = rgba.copy(), depth.copy()      # the reference's main view
+    our_rgba, our_depth = rgba.copy(), depth.copy()      # ours
+    for x0, y0, mask in boxes(2):
+        bh, bw = mask.shape
+        got_rgba, got_depth = np.empty_like(rgba), np.empty_like(depth)
+        assert lib.hs_extract_silhouette(vp(our_rgba), vp(our_depth), vp(got_rgba), vp(got_depth), W, H, vp(mask), x0, y0, bw, bh) == 0
+        want_rgba, want_depth = np.empty_like(rgba), np.empty_like(depth)
+        assert ref.ref_process_silhouette(vp(cur_rgba), vp(cur_depth), vp(want_rgba), vp(want_depth), W, H, vp(mask), x0, y0, bw, bh) == 0
+        assert np.array_equal(got_depth, want_depth) and np.array_equal(got_rgba, want_rgba), (x0, y0)
+        assert lib.hs_remove_silhouette(vp(our_rgba), vp(our_depth), W, H, vp(mask), x0, y0, bw, bh) == 0
+        assert ref.ref_remove_silhouette(vp(cur_rgba), vp(cur_depth), W, H, vp(mask), x0, y0, bw, bh) == 0
+        assert np.array_equal(our_depth, cur_depth) and np.array_equal(our_rgba, cur_rgba), (x0, y0)
+
