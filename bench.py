@@ -8,13 +8,15 @@ At N = 1 the workload is BASELINE.json configs[1]: static map only, 1242x375, 5 
 
 `python bench.py --gpus N` (N > 1, as the driver starts it — no launcher) forks its N ranks itself, one per GPU, RCCL process
 group over 127.0.0.1; under `python -m torch.distributed.run` it uses the ranks it is given.  The N > 1 line measures what
-north_star names: N CONCURRENT INSTANCE VOLUMES (0.035 m voxels, mu 1.0, 7142 blocks), one per GPU — silhouette split, fusion
-(allocate + integrate + raycast) and, inside the timed step, the one real exchange of the path: every rank raycasts its volume
-from the shared camera, the per-volume depth + colour layers are ALL-GATHERED over RCCL (one collective) and rank 0
-z-composites them (dynslam_amd/multigpu.py ShardedScene).  value = volume-frames/s = N*K / max-rank time (weak scaling: one
-volume per GPU); the line also carries, measured on rank 0 after the timed region, the same N volumes TIME-SLICED ON ONE GPU
-(north_star's denominator) and their ratio.  Nested under "configs3": the same measurement for BASELINE configs[3] — the 5 mm
-static map on rank 0 + N-1 instance volumes on the other ranks.
+north_star names: 8 CONCURRENT INSTANCE VOLUMES (0.035 m voxels, mu 1.0, 7142 blocks) — the SAME eight volumes for every N,
+instance k on rank k mod N (N = 2: four per GPU, N = 8: one per GPU; strong scaling) — silhouette split, fusion (allocate +
+integrate + raycast) and, inside the timed step, the one real exchange of the path: every rank raycasts its volumes from the
+shared camera, the per-volume depth + colour layers are ALL-GATHERED over RCCL (one collective, issued by the library's own
+dsr_exchange_*) and rank 0 z-composites them (dynslam_amd/multigpu.py ShardedScene).  value = volume-frames/s = 8*K /
+max-rank time; the line also carries, measured on rank 0 after the timed region, the same 8 volumes TIME-SLICED ON ONE GPU
+(`value_same_workload_1gpu`, north_star's denominator), their ratio (`speedup_vs_1gpu`) and the CPU oracle fusing + previewing
+the same volumes on the host cores (`cpu_baseline`).  Nested under "configs3": the same measurement for BASELINE configs[3] — the
+5 mm static map on rank 0 + 7 instance volumes on the other ranks.
 `--instance-volumes V` / `--volumes V` run either leg alone with V volumes on any number of GPUs (N = 1: all time-sliced);
 `--replicas` runs N independent copies of configs[1] (no collective).
 
@@ -35,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+SCALING_VOLUMES = 8   # north_star: "8 concurrent instance volumes" — the SAME workload at 1 / 2 / 4 / 8 GPUs (strong scaling)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_GUIDE_COPY_GBS = 6290.0  # ... and the 6.29 TB/s its float4 copy kernel measures (79 %)
 
@@ -157,6 +160,51 @@ def cpu_baseline(frames, w, h, preset, budget_s):
                       f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {tn:.1f} s; single thread: first {d1} frames, {t1:.1f} s"}
 
 
+def cpu_baseline_volumes(frames, w, h, n_volumes, has_static, preset, budget_s):
+    """The CPU oracle on the multi-volume workload: the same silhouette split, fusion and fused preview of the same V volumes,
+    one after the other on the host cores (what the reference's _CPU engines would do: InstanceReconstructor.cpp:315-361 is a
+    sequential loop over the volumes), OpenMP inside each engine on all cores; bounded by budget_s."""
+    import torch
+    from dynslam_amd.engine import make_calib
+    from dynslam_amd.multigpu import ShardedScene
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, load_api, oracle_settings
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    kinds = volume_settings(preset)
+    for kind in ("static", "view"):  # the oracle keeps the voxel array in host RAM: size the map for the sample only
+        kinds[kind] = dict(kinds[kind], sdf_local_block_num=min(kinds[kind]["sdf_local_block_num"], 1 << 20),
+                           hash_bucket_num=min(kinds[kind]["hash_bucket_num"], 1 << 22),
+                           excess_list_size=min(kinds[kind]["excess_list_size"], 1 << 20))
+    n_inst = n_volumes - 1 if has_static else n_volumes
+    calib = make_calib(*StreetScene(w, h).intrinsics(), w, h)
+    scene = ShardedScene(lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib, threads=cores), w, h, n_volumes, 1, 0,
+                         torch.device("cpu"), local_only=True, has_static=has_static)
+    scene.exchange.host_api = load_api()
+    track_ids = {k: 1 + k for k in range(n_inst)}
+    done, t_total = 0, 0.0
+    for rgba, d, T, masks in frames:
+        pose_m = np.linalg.inv(np.asarray(T, np.float64)).astype(np.float32)
+        inst_m = {k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in masks}
+        t0 = time.perf_counter()
+        try:
+            scene.step(rgba, d, T, masks)
+        except Exception:
+            break
+        scene.preview(pose_m, inst_m, track_ids)
+        t_total += time.perf_counter() - t0
+        done += 1
+        if t_total > budget_s or done >= 12:
+            break
+    scene.close()
+    if done == 0:
+        return None
+    return {"value": round(n_volumes * done / t_total, 4), "unit": "volume-frames/s", "cores": cores, "kind": "port",
+            "composited_frames_per_s": round(done / t_total, 4),
+            "sample": f"first {done} frames of the same sequence ({w}x{h}): silhouette split + fusion + fused preview of the same "
+                      f"{n_volumes} volumes ({'static map + ' if has_static else ''}{n_inst} instance volumes) one after the other, "
+                      f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {t_total:.1f} s"}
+
+
 def through_shim(frames, w, h, intr, kw, warmup):
     """SURVEY 8d "through-shim" rate: the C++ host shim/host_bench (our driver class over shim/ITMLib.h, the
     ITMLib names DynSLAM's InfiniTamDriver uses) fed with the SAME frames as pageable host buffers; per frame
@@ -254,15 +302,6 @@ class _stdout_to_stderr:
         os.close(self.saved)
 
 
-def _free_port():
-    import socket
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    port = sk.getsockname()[1]
-    sk.close()
-    return port
-
-
 def _test_backend():
     """TEST SEAM.  The product path is fixed: HIP engines (libdsr_hip.so) on cuda:<LOCAL_RANK>, RCCL.  tests/ may name a module
     in DSR_BENCH_TEST_BACKEND that stands in for the device layer — `device(local_rank)`, `DIST_BACKEND`,
@@ -273,10 +312,20 @@ def _test_backend():
     if not name:
         return None
     import importlib
-    return importlib.import_module(name)
+    mod = importlib.import_module(name)
+    where = os.path.realpath(getattr(mod, "__file__", "") or "")
+    if not where.startswith(os.path.realpath(os.path.join(ROOT, "tests")) + os.sep):
+        raise RuntimeError(f"DSR_BENCH_TEST_BACKEND={name}: the seam only loads modules under tests/ ({where} is not)")
+    return mod
+
+
+def backend_name(tb):
+    """What produced the line: "hip" = the product path; a line made through the test seam says so and names the module."""
+    return "hip" if tb is None else f"test-seam:{tb.__name__}"
 
 
 _PREGENERATED = {}  # n_instances -> frames, filled by the parent of spawn_ranks() before it forks
+_JOB_STORE = None  # this rank's handle of the job's rendezvous store when spawn_ranks() started it (rank 0 hosts the store)
 
 
 def frames_for(args, n_inst):
@@ -289,14 +338,15 @@ def frames_for(args, n_inst):
 def multi_gpu_legs(args, world):
     """-> [(n_volumes, has_static)] of a multi-volume job: the headline leg first.
     --instance-volumes V: north_star's scaling workload, V concurrent instance volumes;  --volumes V: configs[3], the static map
-    + V-1 instance volumes;  `--gpus N` alone: BOTH, N instance volumes (headline) and configs[3] with N volumes (nested)."""
+    + V-1 instance volumes;  `--gpus N` alone: BOTH with 8 volumes for EVERY N — 8 instance volumes (headline; the same workload at
+    1 / 2 / 4 / 8 GPUs) and configs[3] = the static map + 7 instance volumes (nested)."""
     legs = []
     if args.instance_volumes:
         legs.append((args.instance_volumes, False))
     if args.volumes:
         legs.append((args.volumes, True))
     if not legs and world > 1 and not args.replicas:
-        legs = [(world, False)] + ([] if args.no_configs3 else [(world, True)])
+        legs = [(SCALING_VOLUMES, False)] + ([] if args.no_configs3 else [(SCALING_VOLUMES, True)])
     return legs
 
 
@@ -311,15 +361,40 @@ def spawn_ranks(args, legs):
         frames_for(args, args.instances)
     for V, has_static in legs:
         frames_for(args, V - 1 if has_static else V)
-    port = _free_port()
+    # The rendezvous port is chosen by rank 0's OWN store (bound to port 0, i.e. by the kernel) and handed to the parent through
+    # a pipe before the other ranks are forked: a port picked here and closed again could be taken by another process before
+    # rank 0 binds it.
     sys.stdout.flush()
     pids = {}
+    port = None
+    rd, wr = os.pipe()
     for r in range(N):
+        if r == 1:
+            os.close(wr)
+            data = os.read(rd, 64)
+            os.close(rd)
+            if not data:  # rank 0 died before its store was up
+                break
+            port = int(data.decode())
         pid = os.fork()
         if pid == 0:
             rc = 1
             try:
-                os.environ.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                import faulthandler
+                faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <rank pid>`: where is it stuck?
+                os.environ.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1")
+                import datetime
+                from torch.distributed import TCPStore
+                global _JOB_STORE  # every rank hands ITS handle of the one store to init_process_group (no env:// rendezvous)
+                if r == 0:
+                    os.close(rd)
+                    _JOB_STORE = TCPStore("127.0.0.1", 0, N, is_master=True, wait_for_workers=False, timeout=datetime.timedelta(seconds=600))
+                    os.environ["MASTER_PORT"] = str(_JOB_STORE.port)
+                    os.write(wr, str(_JOB_STORE.port).encode())
+                    os.close(wr)
+                else:
+                    os.environ["MASTER_PORT"] = str(port)
+                    _JOB_STORE = TCPStore("127.0.0.1", port, N, is_master=False, timeout=datetime.timedelta(seconds=600))
                 run_rank(args)
                 rc = 0
             except BaseException:  # noqa: BLE001 - the child must never return into the parent's stack
@@ -369,11 +444,12 @@ def main_volumes(args, legs):
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store_kw = dict(store=_JOB_STORE, rank=rank, world_size=world) if _JOB_STORE is not None else {}
         with _stdout_to_stderr():
             if tb is None:
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", device_id=dev, **store_kw)
             else:
-                dist.init_process_group(tb.DIST_BACKEND)
+                dist.init_process_group(tb.DIST_BACKEND, **store_kw)
             dist.barrier()  # the first collective creates the communicator (and prints RCCL's banner)
 
     from dynslam_amd.engine import make_calib
@@ -394,13 +470,15 @@ def main_volumes(args, legs):
     for (V, has_static), frames in zip(legs, frame_sets):
         a = argparse.Namespace(**vars(args))
         a.volumes = V
-        line = run_volumes(a, frames, make_engine, dev, world, rank, use_dist, host_api=host_api, has_static=has_static)
+        line = run_volumes(a, frames, make_engine, dev, world, rank, use_dist, host_api=host_api, has_static=has_static,
+                           backend=backend_name(tb))
         if rank == 0:
             if out is None:
                 out = line
             else:  # the second leg rides along under its own key: ONE line per job
                 out["configs3" if has_static else "instance_volumes"] = {k: line[k] for k in (
-                    "value", "unit", "ms_per_step", "config", "time_sliced_1gpu", "speedup_vs_time_sliced_1gpu", "kernels")}
+                    "value", "unit", "ms_per_step", "scaling", "config", "value_same_workload_1gpu", "speedup_vs_1gpu", "time_sliced_1gpu",
+                    "cpu_baseline", "kernels")}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -417,7 +495,7 @@ def volume_settings(preset):
     return {"static": kw, "instance": inst_kw, "view": view_kw}
 
 
-def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None, has_static=True):
+def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None, has_static=True, backend="hip"):
     """The timed part of a multi-volume job, after the process group and the device are set up: returns the bench line
     (a dict) on rank 0, None elsewhere.  `dev` is this rank's torch device; with a CPU device (tests/test_bench_contract.py
     drives this function over gloo with the CPU oracle as `make_engine`) the frames are handed over as host arrays and
@@ -506,25 +584,37 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
                   "note": f"the same {V} volumes fused + previewed sequentially on rank 0's GPU, same frames"}
     if rank != 0:
         return None
+    cpu = None
+    if not getattr(args, "no_cpu_baseline", False):  # rank 0's host cores, after the timed region (the other ranks wait at the barrier)
+        try:
+            cpu = cpu_baseline_volumes(frames, W, H, V, has_static, args.preset, getattr(args, "cpu_budget_s", 12.0))
+        except Exception as ex:  # the baseline must never take the bench line down
+            cpu = {"value": None, "unit": "volume-frames/s", "cores": 1, "kind": "port", "sample": f"failed: {ex}"}
     roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's probe engine
     per_rank = [len(volumes_of_rank(r, V, world, has_static)) for r in range(world)]
     if has_static:
         what = (f"configs[3]: static map (preset {args.preset}) + {n_inst} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
-                f"sharded one volume per GPU over {world} GPU(s) (volume v on rank 1 + (v-1) mod (N-1))")
+                f"sharded by volume over {world} GPU(s) (the map on rank 0, instance k on rank 1 + k mod (N-1))")
     else:
         what = (f"north_star scaling workload: {n_inst} concurrent instance volumes (0.035 m, mu 1.0, 7142 blocks; "
-                f"InstanceReconstructor.cpp:372-379) sharded one volume per GPU over {world} GPU(s) (instance k on rank k mod N), no static map")
+                f"InstanceReconstructor.cpp:372-379) sharded by volume over {world} GPU(s) (instance k on rank k mod N), no static map")
     volume_rate = world > 1 or not has_static
+    value = round(V * K / elapsed, 3) if volume_rate else round(K / elapsed, 3)
+    same_1gpu = (sliced["value"] if volume_rate else sliced["composited_frames_per_s"]) if sliced else (value if world == 1 else None)
     return {
         "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
-        "value": round(V * K / elapsed, 3) if volume_rate else round(K / elapsed, 3),
+        "value": value,
         "unit": "volume-frames/s" if volume_rate else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        # the SAME V volumes at every N (the driver's 1 / 2 / 4 / 8 curve is one workload): total work fixed = strong scaling
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": backend,
+        # north_star: "aggregate at N GPUs over 8 concurrent instance volumes" against the same volumes on ONE GPU
+        "value_same_workload_1gpu": same_1gpu,
+        "speedup_vs_1gpu": round(value / same_1gpu, 3) if same_1gpu else None,
         "config": {"workload": f"{what}, synthetic KITTI-like street {W}x{H} with {n_inst} moving boxes, frames {Wm}..{Wm + K - 1}; "
                                f"every step = silhouette split (masks resident in HBM) + fusion (allocate, integrate, raycast) of "
                                f"every volume + fused preview: colour and depth raycast of every volume from the frame's camera, "
-                               f"ONE RCCL all-gather of the {n_inst} instance layers ({n_inst * W * H * 8 / 1e6:.1f} MB), z-composite on rank 0",
+                               f"ONE RCCL all-gather of the {n_inst} instance layers ({n_inst * W * H * 8 / 1e6:.1f} MB; dsr_exchange_*), z-composite on rank 0",
                    "volumes": V, "volumes_per_rank": per_rank, "has_static_map": bool(has_static),
                    "composited_frames_per_s": round(K / elapsed, 3),
                    "host_enqueue_ms_per_step_rank0": round(1e3 * t_enq / K, 4),
@@ -533,8 +623,7 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
                    "instance_visible_blocks_last_frame_rank0": [s_.no_visible_blocks for s_ in inst_stats],
                    "status": max([stats.sticky_status if stats else 0] + [s_.sticky_status for s_ in inst_stats])},
         "time_sliced_1gpu": sliced,
-        "speedup_vs_time_sliced_1gpu": round((K / elapsed) / sliced["composited_frames_per_s"], 3) if sliced else None,
-        "roofline": roofline, "cpu_baseline": None, "kernels": kernels,
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
     }
 
 
@@ -575,6 +664,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs3", action="store_true", help="--gpus N > 1: only the instance-volumes leg")
     ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
     ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of a multi-volume line")
+    ap.add_argument("--no-scaling-leg", action="store_true",
+                    help="N = 1: do not append north_star's scaling workload (8 instance volumes on this GPU) to the line")
     return ap.parse_args(argv)
 
 
@@ -598,6 +689,11 @@ def run_rank(args):
 
     # synthetic frames first: the worker pool forks, which must happen before HIP / RCCL start
     frames = frames_for(args, args.instances)
+    # the N = 1 line also carries north_star's scaling workload (8 instance volumes) on this one GPU: the N = 1 point of the curve
+    # whose N > 1 points are `python bench.py --gpus N`
+    scaling_leg = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_scaling_leg and args.preset == "5mm"
+                   and not (args.decay or args.swap or args.instances or args.host_views))
+    frames8 = frames_for(args, SCALING_VOLUMES) if scaling_leg else None
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -606,8 +702,9 @@ def run_rank(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store_kw = dict(store=_JOB_STORE, rank=rank, world_size=world) if _JOB_STORE is not None else {}
         with _stdout_to_stderr():
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **store_kw)
             dist.barrier()
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(local_rank)
@@ -714,7 +811,7 @@ def run_rank(args):
             "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
             "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": "hip",
             "config": {"workload": f"{'configs[2]: static map + ' + str(args.instances) + ' instance volumes' if args.instances else 'configs[1]: static map only'}"
                                    f"{' + voxel GC' if args.decay else ''}{' + host swapping' if args.swap else ''}, synthetic KITTI-like street {W}x{H}, "
                                    f"preset {args.preset} (voxel {kw['voxel_size']} m, mu {kw['mu']} m), "
@@ -725,10 +822,22 @@ def run_rank(args):
                        "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
             "roofline": roofline, "cpu_baseline": cpu, "through_shim": shim, "kernels": kernels,
         }
-        print(json.dumps(out), flush=True)
     for ie in inst_eng:
         ie.close()
     eng.close()
+    if rank == 0:
+        if scaling_leg:
+            try:
+                calib = make_calib(*sc.intrinsics(), W, H)
+                kinds = volume_settings(args.preset)
+                a = argparse.Namespace(**vars(args))
+                a.volumes, a.cpu_budget_s = SCALING_VOLUMES, args.cpu_budget_s / 2
+                line = run_volumes(a, frames8, lambda kind: EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib),
+                                   dev, 1, 0, False, has_static=False)
+                out["instance_volumes8_1gpu"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "cpu_baseline")}
+            except Exception as ex:
+                out["instance_volumes8_1gpu"] = {"value": None, "note": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 from types import SimpleNamespace
 
-ABI_VERSION = 2  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
+ABI_VERSION = 3  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
 BLOCK_SIZE = 8
 BLOCK_SIZE3 = 512
 
@@ -81,6 +81,7 @@ assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8
 
 _P = C.c_void_p
 _H = C.c_void_p  # dsr_engine*
+_X = C.c_void_p  # dsr_exchange*
 
 # name -> (restype, argtypes); exactly the entry points declared in include/dsr.h
 SIGNATURES = {
@@ -97,6 +98,7 @@ SIGNATURES = {
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "update_view": (C.c_int, [_H, _P, _P]),
     "update_view_dev": (C.c_int, [_H, _P, _P]),
+    "update_view_bgr": (C.c_int, [_H, _P, _P]),
     "set_view_float": (C.c_int, [_H, _P, _P]),
     "set_view_float_dev": (C.c_int, [_H, _P, _P]),
     "get_view": (C.c_int, [_H, _P, _P]),
@@ -132,6 +134,21 @@ SIGNATURES = {
     "composite_layer_ptrs_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "exchange_create": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_X)]),
+    "exchange_unique_id": (C.c_int, [_P]),
+    "exchange_create_rank": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_X)]),
+    "exchange_destroy": (None, [_X]),
+    "exchange_stream": (C.c_void_p, [_X, C.c_int]),
+    "exchange_slot_ptrs": (C.c_int, [_X, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
+    "exchange_layer_ptrs": (C.c_int, [_X, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
+    "exchange_render_slot": (C.c_int, [_X, C.c_int, C.c_int, _H, C.c_int, _P, _P]),
+    "exchange_gather": (C.c_int, [_X]),
+    "exchange_composite": (C.c_int, [_X, C.c_int, _H, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int]),
+    "exchange_gather_and_composite": (C.c_int, [_X, C.c_int, _H, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int]),
+    "exchange_target_ptrs": (C.c_int, [_X, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
+    "exchange_clear_target": (C.c_int, [_X, C.c_int]),
+    "exchange_read_target": (C.c_int, [_X, C.c_int, _P, _P]),
+    "exchange_sync": (C.c_int, [_X]),
     "get_stats": (C.c_int, [_H, C.POINTER(Stats)]),
     "dump_hash_table": (C.c_int, [_H, _P]),
     "dump_visible_list": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int32)]),

@@ -8,6 +8,10 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: librccl is loaded on first use (exchange_* below), the library does not link it
+
+#include <dlfcn.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <atomic>
@@ -16,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -39,6 +44,8 @@ thread_local std::string g_err;
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
 std::atomic<int> g_enginesOnDevice[64];         // live engines per device (range-image overlap policy, allocate_scene)
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+std::mutex g_ioMutex;
+hipStream_t g_ioStream[64] = {};                // per GPU: uploads, previews and view read-backs of every engine on it
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -223,6 +230,34 @@ struct dsr_engine {
   // sync_status, dsr_get_stats); valid until the next call that changes the list
   int32_t noVisibleSeen = 0;
   bool noVisibleValid = false;
+  // ---- host buffers in and out WITHOUT draining the engine's stream (DESIGN.md "through the host").  DynSLAM's host hands
+  // every frame over as pageable host buffers and wants two previews and a status word back per frame and per driver
+  // (InfiniTamDriver.cpp:211-224, InfiniTamDriver.h:137-158); waiting for the engine's stream at each of these calls exposes the
+  // integration and the raycast to the host serially.  Instead: frames are copied into a pinned slot (two, alternating) and
+  // uploaded on the GPU's I/O stream (one per device, shared by the engines of the process) into a landing buffer the ingest
+  // kernel reads; the status words are PUBLISHED by k_visible_write into a pinned, device-mapped word the host polls; previews
+  // and view read-backs run on the I/O stream after the last kernel that wrote the view (evView) — none of them waits for
+  // k_integrate or k_raycast.
+  uint8_t *upPin[2] = {nullptr, nullptr};
+  size_t upBytes = 0, upDepthOff = 0;
+  hipEvent_t upSlotFree[2] = {nullptr, nullptr};
+  bool upSlotUsed[2] = {false, false};
+  int upNext = 0;
+  uint8_t *upDev = nullptr;                    // landing buffer of the upload: colour, then depth
+  hipEvent_t evUploaded = nullptr, evIngested = nullptr;
+  bool ingestPending = false;
+  hipEvent_t evView = nullptr;                 // recorded after the last kernel that wrote this engine's view
+  bool viewEventValid = false;
+  hipEvent_t evViewRead = nullptr;             // the I/O stream's last read of the view (previews, dsr_get_view)
+  bool viewReadEver = false;
+  uint8_t *pvPin = nullptr, *pvDev = nullptr;  // previews: packed BGR (3 B / pixel), then int16 millimetres
+  size_t pvMmOff = 0;
+  int32_t *statusHost = nullptr, *statusDev = nullptr;  // {noVisibleBlocks, status, sequence number}, pinned + mapped
+  int statusSeq = 0;
+  // cross-GPU view split (main engine on one GPU, the instance volume on another): the cut-out is produced here, then peer-copied
+  uchar4 *xferRgb = nullptr;
+  float *xferDepth = nullptr;
+  bool sidePending = false;          // evExpected has been recorded and not been waited for by the main stream since
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
   hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
@@ -255,6 +290,7 @@ void prof_resolve(dsr_engine *e) {
   if (e->profPending.empty()) return;
   (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
+  if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
   for (auto &p : e->profPending) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { e->profRecs[p.rec].ms += ms; e->profRecs[p.rec].launches++; }
@@ -368,6 +404,14 @@ void free_all(dsr_engine *e) {
   if (e->hostUsedSeen) (void)hipHostFree(e->hostUsedSeen);
   if (e->hostUsedEvent) (void)hipEventDestroy(e->hostUsedEvent);
   for (auto p : e->hostSlabs) (void)hipHostFree(p);
+  for (int k = 0; k < 2; ++k) {
+    if (e->upPin[k]) (void)hipHostFree(e->upPin[k]);
+    if (e->upSlotFree[k]) (void)hipEventDestroy(e->upSlotFree[k]);
+  }
+  F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth);
+  if (e->pvPin) (void)hipHostFree(e->pvPin);
+  if (e->statusHost) (void)hipHostFree(e->statusHost);
+  for (hipEvent_t ev : {e->evUploaded, e->evIngested, e->evView, e->evViewRead}) if (ev) (void)hipEventDestroy(ev);
   if (e->xEvent) (void)hipEventDestroy(e->xEvent);
   if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
   if (e->orderEvent) (void)hipEventDestroy(e->orderEvent);
@@ -411,10 +455,112 @@ int dmalloc(T **p, size_t n) {
   return DSR_OK;
 }
 
+// ---- host buffers in and out without draining the engine's stream (see dsr_engine) ---------------------------------
+
+int io_stream(dsr_engine *e, hipStream_t *out) {
+  if (e->device < 0 || e->device >= 64) return fail(DSR_E_ARG, "device ordinal beyond the I/O stream table");
+  std::lock_guard<std::mutex> lock(g_ioMutex);
+  if (!g_ioStream[e->device]) HIP_TRY(hipStreamCreateWithFlags(&g_ioStream[e->device], hipStreamNonBlocking));
+  *out = g_ioStream[e->device];
+  return DSR_OK;
+}
+
+int make_event(hipEvent_t *ev) {
+  if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  return DSR_OK;
+}
+
+// call before enqueuing a kernel that WRITES e's view on `stream`: readers on the I/O stream (previews, read-backs) first
+int before_view_write(dsr_engine *e, hipStream_t stream) {
+  if (e->viewReadEver) HIP_TRY(hipStreamWaitEvent(stream, e->evViewRead, 0));
+  return DSR_OK;
+}
+// ... and after it
+int view_written(dsr_engine *e, hipStream_t stream) {
+  int st = make_event(&e->evView);
+  if (st) return st;
+  HIP_TRY(hipEventRecord(e->evView, stream));
+  e->viewEventValid = true;
+  e->hasView = true;
+  return DSR_OK;
+}
+// the I/O stream becomes a reader of e's view as it is after everything queued so far that writes it
+int io_reads_view(dsr_engine *e, hipStream_t io) {
+  if (!e->viewEventValid) {  // written before this bookkeeping saw it (cannot happen through the C ABI): order after the whole stream
+    int st = view_written(e, e->stream);
+    if (st) return st;
+  }
+  HIP_TRY(hipStreamWaitEvent(io, e->evView, 0));
+  return DSR_OK;
+}
+int io_read_done(dsr_engine *e, hipStream_t io) {
+  int st = make_event(&e->evViewRead);
+  if (st) return st;
+  HIP_TRY(hipEventRecord(e->evViewRead, io));
+  e->viewReadEver = true;
+  return DSR_OK;
+}
+
+// A frame handed over as host buffers: copied into a pinned slot (the caller's buffers are free on return), uploaded on the
+// I/O stream into the landing buffer; the engine's stream waits for the upload, not the host.  -> device addresses of the two
+// parts.  The caller enqueues its ingest kernel on e->stream and then calls upload_consumed().
+int upload_frame(dsr_engine *e, const void *colour, size_t cBytes, const void *depth, size_t dBytes, const uint8_t **cDev,
+                 const uint8_t **dDev) {
+  hipStream_t io = nullptr;
+  int st = io_stream(e, &io);
+  if (st) return st;
+  if (!e->upDev) {
+    e->upDepthOff = (((size_t)e->Wr * e->Hr * 4) + 255) / 256 * 256;
+    e->upBytes = e->upDepthOff + (size_t)e->P * 4;
+    for (int k = 0; k < 2; ++k) {
+      if (hipHostMalloc(reinterpret_cast<void **>(&e->upPin[k]), e->upBytes, hipHostMallocDefault) != hipSuccess)
+        return fail(DSR_E_NOMEM, "pinned frame staging allocation failed");
+      HIP_TRY(hipEventCreateWithFlags(&e->upSlotFree[k], hipEventDisableTiming));
+    }
+    if ((st = dmalloc(&e->upDev, e->upBytes))) return st;
+    if ((st = make_event(&e->evUploaded)) || (st = make_event(&e->evIngested))) return st;
+  }
+  if (cBytes > e->upDepthOff || e->upDepthOff + dBytes > e->upBytes) return fail(DSR_E_ARG, "frame larger than the staging slot");
+  const int s = e->upNext;
+  e->upNext ^= 1;
+  if (e->upSlotUsed[s]) HIP_TRY(hipEventSynchronize(e->upSlotFree[s]));  // the upload of two frames ago: long done
+  memcpy(e->upPin[s], colour, cBytes);
+  memcpy(e->upPin[s] + e->upDepthOff, depth, dBytes);
+  if (e->ingestPending) HIP_TRY(hipStreamWaitEvent(io, e->evIngested, 0));  // the previous ingest kernel reads the landing buffer
+  HIP_TRY(hipMemcpyAsync(e->upDev, e->upPin[s], cBytes, hipMemcpyHostToDevice, io));
+  HIP_TRY(hipMemcpyAsync(e->upDev + e->upDepthOff, e->upPin[s] + e->upDepthOff, dBytes, hipMemcpyHostToDevice, io));
+  HIP_TRY(hipEventRecord(e->upSlotFree[s], io));
+  e->upSlotUsed[s] = true;
+  HIP_TRY(hipEventRecord(e->evUploaded, io));
+  HIP_TRY(hipStreamWaitEvent(e->stream, e->evUploaded, 0));
+  *cDev = e->upDev;
+  *dDev = e->upDev + e->upDepthOff;
+  return DSR_OK;
+}
+int upload_consumed(dsr_engine *e) {
+  HIP_TRY(hipEventRecord(e->evIngested, e->stream));
+  e->ingestPending = true;
+  return DSR_OK;
+}
+
+// ITMViewBuilder::UpdateView's optional bilateral passes on a view whose float depth is already in e->depth
+int filter_view(dsr_engine *e) {
+  if (!e->s.use_bilateral_filter) return DSR_OK;
+  HIP_TRY(hipMemcpyAsync(e->depthTmp, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+  for (int k = 0; k < 5; ++k) {
+    if (k & 1) LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depthTmp, e->depth, e->W, e->H);
+    else LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depth, e->depthTmp, e->W, e->H);
+  }
+  HIP_TRY(hipMemcpyAsync(e->depth, e->depthTmp, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  return DSR_OK;
+}
+
 // rgbDev/depthDev != null: device-resident inputs, ingested by one fused kernel
 int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthDev = nullptr) {
   const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
   const size_t rgbBytes = (size_t)e->Wr * e->Hr * 4;
+  { int st = before_view_write(e, e->stream); if (st) return st; }
   if (rgbDev && depthDev && ((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0) {
     const int nRgbVec = (int)(rgbBytes / 16), nQuads = div_up(e->P, 4);
     LAUNCH(e, "view_ingest", k_view_ingest, dim3(div_up(std::max(nRgbVec, nQuads), 256)), dim3(256), (const uint4 *)rgbDev,
@@ -427,18 +573,9 @@ int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthD
     LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, e->depth,
            e->P, a, b);
   }
-  if (e->s.use_bilateral_filter) {
-    // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
-    HIP_TRY(hipMemcpyAsync(e->depthTmp, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
-    dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-    for (int k = 0; k < 5; ++k) {
-      if (k & 1) LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depthTmp, e->depth, e->W, e->H);
-      else LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depth, e->depthTmp, e->W, e->H);
-    }
-    HIP_TRY(hipMemcpyAsync(e->depth, e->depthTmp, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
-  }
-  e->hasView = true;
-  return DSR_OK;
+  // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
+  { int st = filter_view(e); if (st) return st; }
+  return view_written(e, e->stream);
 }
 
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
@@ -451,6 +588,9 @@ int allocate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
+  // a range image of the PREVIOUS list may still be running on the side stream (back-to-back fusion calls without a Prepare in
+  // between): it reads the list and the count this call rewrites
+  if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
   LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
          (const int4 *)rs.visBlocks, rs.visType);
   LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
@@ -464,8 +604,10 @@ int allocate_scene(dsr_engine *e) {
          e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
          (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+  if (e->statusDev) e->statusSeq++;
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
-         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks);
+         (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks, e->statusDev,
+         e->statusSeq);
   HIP_TRY(hipGetLastError());
   e->liveExp.valid = false;
   // ... when this volume has the GPU to itself: with other volumes' engines on the device (a map + its instance volumes)
@@ -480,6 +622,7 @@ int allocate_scene(dsr_engine *e) {
       if (st) return st;
     }
     HIP_TRY(hipEventRecord(e->evExpected, e->sideStream));
+    e->sidePending = true;
     e->liveExp.valid = true; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
     memcpy(e->liveExp.proj, proj, sizeof proj);
   }
@@ -555,6 +698,30 @@ int sticky_status(dsr_engine *e, int *status) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   *status = w[2];
   e->noVisibleSeen = w[0]; e->noVisibleValid = true;
+  return DSR_OK;
+}
+
+// The same two words as k_visible_write PUBLISHED them for allocation number e->statusSeq (pinned, device-mapped memory): the
+// host polls instead of draining the stream, so it returns as soon as the allocation kernels of this frame have run — the
+// integration and everything after it are still in flight.  Falls back to the copy above when the stream ran dry without the
+// word arriving (a failed launch) or the engine has no published word.
+int published_status(dsr_engine *e, int *status) {
+  if (!e->statusHost) return sticky_status(e, status);
+  const int seq = e->statusSeq;
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) == seq) break;
+    if ((spins & 0xfff) == 0) {
+      const hipError_t q = hipStreamQuery(e->stream);
+      if (q == hipSuccess) {
+        if (__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) == seq) break;
+        return sticky_status(e, status);
+      }
+      if (q != hipErrorNotReady) return fail(DSR_E_DEVICE, std::string("engine stream: ") + hipGetErrorString(q));
+      sched_yield();
+    }
+  }
+  *status = e->statusHost[1];
+  e->noVisibleSeen = e->statusHost[0]; e->noVisibleValid = true;
   return DSR_OK;
 }
 
@@ -645,6 +812,117 @@ int swap_out(dsr_engine *e) {
     e->hostUsedCallsSince = 0;
   }
   HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
+
+// ---- RCCL, loaded on first use: the library itself does not link librccl (a host without multi-GPU needs never pays for it,
+// and a process that already holds a copy — PyTorch ships its own — keeps using that one)
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+RcclApi *rccl_api() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)  // a copy the process has loaded already (torch's) wins
+      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *n : paths)
+      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!api.lib) { api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define RCCL_SYM(field, name)                                                           \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name));            \
+    if (!api.field && api.error.empty()) api.error = std::string("librccl lacks ") + name;
+    RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(AllGather, "ncclAllGather") RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+  });
+  return &api;
+}
+#define RCCL_TRY(api, expr)                                                                              \
+  do {                                                                                                   \
+    ncclResult_t _r = (expr);                                                                            \
+    if (_r != ncclSuccess) return fail(DSR_E_DEVICE, std::string(#expr) + ": " + (api)->GetErrorString(_r)); \
+  } while (0)
+
+}  // namespace
+
+// One exchange = the layer buffers of the fused preview on every GPU this process drives, the communicator(s) between them and
+// one stream per GPU (include/dsr.h "multi-GPU").  GROUP = one GPU's worth of ranks: the unit the collective sees.  The gathered
+// buffer holds groups x perGroup x slots layers of 8 bytes per pixel (float depth plane, then RGBA plane); a rank's own slots
+// lie INSIDE the gathered buffer of its GPU (in-place all-gather), so ranks that share a GPU exchange nothing at all.
+struct dsr_exchange {
+  int nRanks = 0, slots = 0, P = 0;
+  size_t layerBytes = 0, chunkBytes = 0;  // chunk = one group's share of the gathered buffer
+  int groups = 0, perGroup = 0;
+  std::vector<int> groupOfRank, indexInGroup;
+  bool rankMode = false;
+  struct Dev {
+    int device = 0, group = 0;
+    hipStream_t stream = nullptr;
+    uint8_t *all = nullptr;                 // gathered layers
+    uchar4 *targetRgba = nullptr;           // the exchange's own composite target (lazily)
+    float *targetDepth = nullptr;
+    ncclComm_t comm = nullptr;
+  };
+  std::vector<Dev> devs;                    // local GPUs
+  std::vector<int> devOfRank;               // index into devs, -1: a rank of another process
+  bool useRccl = false;
+};
+
+namespace {
+
+size_t layer_index(const dsr_exchange *x, int rank, int slot) {
+  return ((size_t)x->groupOfRank[rank] * x->perGroup + x->indexInGroup[rank]) * x->slots + slot;
+}
+dsr_exchange::Dev *local_dev(dsr_exchange *x, int rank) {
+  if (!x || rank < 0 || rank >= x->nRanks || x->devOfRank[rank] < 0) return nullptr;
+  return &x->devs[x->devOfRank[rank]];
+}
+void exchange_free(dsr_exchange *x) {
+  if (!x) return;
+  RcclApi *api = x->useRccl ? rccl_api() : nullptr;
+  for (auto &d : x->devs) {
+    (void)hipSetDevice(d.device);
+    if (d.stream) (void)hipStreamSynchronize(d.stream);
+    if (d.comm && api && api->CommDestroy) (void)api->CommDestroy(d.comm);
+    if (d.all) (void)hipFree(d.all);
+    if (d.targetRgba) (void)hipFree(d.targetRgba);
+    if (d.targetDepth) (void)hipFree(d.targetDepth);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+  }
+  delete x;
+}
+int exchange_alloc(dsr_exchange *x) {
+  x->layerBytes = (size_t)x->P * 8;
+  x->chunkBytes = x->layerBytes * x->perGroup * x->slots;
+  for (auto &d : x->devs) {
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.all), x->chunkBytes * x->groups));
+    HIP_TRY(hipMemsetAsync(d.all, 0, x->chunkBytes * x->groups, d.stream));  // empty layers: depth 0 never wins a pixel
+    HIP_TRY(hipStreamSynchronize(d.stream));
+  }
+  return DSR_OK;
+}
+int exchange_target(dsr_exchange *x, dsr_exchange::Dev *d) {
+  if (d->targetRgba) return DSR_OK;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d->targetRgba), (size_t)x->P * 4));
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d->targetDepth), (size_t)x->P * 4));
+  HIP_TRY(hipMemsetAsync(d->targetRgba, 0, (size_t)x->P * 4, d->stream));
+  HIP_TRY(hipMemsetAsync(d->targetDepth, 0, (size_t)x->P * 4, d->stream));
   return DSR_OK;
 }
 
@@ -840,6 +1118,15 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (const char *sb = getenv("DSR_SLAB_BLOCKS")) e->scene.slabBlocks = std::max(1, atoi(sb));  // tests: force slab growth
     ALLOC(add_host_slab(e));  // the first slab, so that the first frames never wait for one
   }
+  if (s.sync_status) {
+    // the published status word (k_visible_write): pinned, device-mapped, coherent — a handful of bytes
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->statusHost), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void **>(&e->statusDev), e->statusHost, 0) != hipSuccess) {
+      if (e->statusHost) (void)hipHostFree(e->statusHost);
+      e->statusHost = e->statusDev = nullptr;  // no mapped host memory here: the status is fetched with a copy as before
+    } else memset(e->statusHost, 0, 64);
+    if (getenv("DSR_NO_PUBLISHED_STATUS") && e->statusHost) { (void)hipHostFree(e->statusHost); e->statusHost = e->statusDev = nullptr; }
+  }
   ALLOC(short_division_exact(e->stream, s.mu, &e->shortDivMuExact));
   // clear image-sized buffers once so that dumps before the first frame are defined
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
@@ -932,10 +1219,32 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
 int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm) {
   CHECK_E(e);
   if (!rgba || !depth_mm) return fail(DSR_E_ARG, "null image");
-  HIP_TRY(hipMemcpyAsync(e->rgb, rgba, (size_t)e->Wr * e->Hr * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->rawDepth, depth_mm, (size_t)e->P * 2, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));  // pageable host memory may be reused by the caller
-  return convert_view(e);
+  const uint8_t *cDev = nullptr, *dDev = nullptr;
+  int st = upload_frame(e, rgba, (size_t)e->Wr * e->Hr * 4, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
+  if (st) return st;
+  if ((st = convert_view(e, cDev, dDev))) return st;  // the landing buffer's two parts are 256-byte aligned
+  return upload_consumed(e);
+}
+
+int dsr_update_view_bgr(dsr_engine *e, const uint8_t *bgr, const int16_t *depth_mm) {
+  CHECK_E(e);
+  if (!bgr || !depth_mm) return fail(DSR_E_ARG, "null image");
+  const uint8_t *cDev = nullptr, *dDev = nullptr;
+  int st = upload_frame(e, bgr, (size_t)e->Wr * e->Hr * 3, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
+  if (st) return st;
+  if ((st = before_view_write(e, e->stream))) return st;
+  const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
+  if (e->Wr * e->Hr == e->P) {
+    LAUNCH(e, "view_ingest", k_view_ingest_bgr, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const uint32_t *)cDev,
+           reinterpret_cast<uint4 *>(e->rgb), e->P, (const short *)dDev, e->depth, a, b);
+  } else {
+    LAUNCH(e, "view_ingest", k_bgr_to_rgba, dim3(div_up(e->Wr * e->Hr, 256)), dim3(256), cDev, e->rgb, e->Wr * e->Hr);
+    LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const short *)dDev, e->depth, e->P, a, b);
+  }
+  HIP_TRY(hipGetLastError());
+  if ((st = filter_view(e))) return st;
+  if ((st = view_written(e, e->stream))) return st;
+  return upload_consumed(e);
 }
 
 int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev) {
@@ -947,30 +1256,40 @@ int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m
 int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m) {
   CHECK_E(e);
   if (!rgba || !depth_m) return fail(DSR_E_ARG, "null image");
-  HIP_TRY(hipMemcpyAsync(e->rgb, rgba, (size_t)e->Wr * e->Hr * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->depthTmp, depth_m, (size_t)e->P * 4, hipMemcpyHostToDevice, e->stream));
-  LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depthTmp, e->depth, e->P);
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  e->hasView = true;
-  return DSR_OK;
+  const uint8_t *cDev = nullptr, *dDev = nullptr;
+  int st = upload_frame(e, rgba, (size_t)e->Wr * e->Hr * 4, depth_m, (size_t)e->P * 4, &cDev, &dDev);
+  if (st) return st;
+  if ((st = before_view_write(e, e->stream))) return st;
+  LAUNCH(e, "set_view", k_set_view_ingest, dim3(div_up(std::max(e->Wr * e->Hr, e->P), 256)), dim3(256), (const uchar4 *)cDev, e->rgb,
+         e->Wr * e->Hr, (const float *)dDev, e->depth, e->P);
+  HIP_TRY(hipGetLastError());
+  if ((st = view_written(e, e->stream))) return st;
+  return upload_consumed(e);
 }
 
 int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m_dev) {
   CHECK_E(e);
   if (!rgba_dev || !depth_m_dev) return fail(DSR_E_ARG, "null image");
+  int st = before_view_write(e, e->stream);
+  if (st) return st;
   HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
   LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)depth_m_dev, e->depth, e->P);
   HIP_TRY(hipGetLastError());
-  e->hasView = true;
-  return DSR_OK;
+  return view_written(e, e->stream);
 }
 
+// view->rgb / view->depth ->UpdateHostFromDevice(): on the I/O stream, after the last kernel that wrote the view — not after
+// the fusion and the raycast that may be queued behind it on the engine's stream
 int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out) {
   CHECK_E(e);
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
-  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToHost, e->stream));
-  if (depth_m_out) HIP_TRY(hipMemcpyAsync(depth_m_out, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  hipStream_t io = nullptr;
+  int st = io_stream(e, &io);
+  if (st || (st = io_reads_view(e, io))) return st;
+  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToHost, io));
+  if (depth_m_out) HIP_TRY(hipMemcpyAsync(depth_m_out, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToHost, io));
+  if ((st = io_read_done(e, io))) return st;
+  HIP_TRY(hipEventSynchronize(e->evViewRead));
   return DSR_OK;
 }
 
@@ -1015,7 +1334,7 @@ int dsr_allocate_scene_from_depth(dsr_engine *e) {
   if (st) return st;
   if (e->s.sync_status) {
     int status = DSR_OK;
-    st = sticky_status(e, &status);
+    st = published_status(e, &status);
     if (st) return st;
     if (status != DSR_OK) return fail(status, status_text(status));
   }
@@ -1042,7 +1361,7 @@ int dsr_process_frame(dsr_engine *e) {
   e->framesProcessed++;
   if (e->s.sync_status) {
     int status = DSR_OK;
-    st = sticky_status(e, &status);
+    st = published_status(e, &status);  // final after the allocation kernels: the integration is still running
     if (st) return st;
     if (status != DSR_OK) {
       // the fork throws per failing frame: clear the sticky word after reporting it
@@ -1062,8 +1381,10 @@ int dsr_prepare(dsr_engine *e) {
   if (e->liveExp.valid && e->liveExp.version == e->listVersion && memcmp(e->liveExp.M.m, e->M_d.m, sizeof e->M_d.m) == 0 &&
       memcmp(e->liveExp.proj, proj, sizeof proj) == 0) {
     HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // computed under the integration (allocate_scene)
+    e->sidePending = false;
   } else {
-    if (e->liveExp.valid) HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // a stale one may still be writing the image
+    // a stale one may still be writing the image — whether or not it is still marked valid
+    if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
     e->liveExp.valid = false;
     int st = expected_depths(e, rs, p);
     if (st) return st;
@@ -1082,6 +1403,7 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   e->sceneVersion++;
   e->noVisibleValid = false;
   e->listVersion++;
+  if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -1178,7 +1500,7 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
                (int)SCAN_VISIBLE_FREE, e->noBlocks);
         LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
-               (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0, rs.visBlocks);
+               (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0, rs.visBlocks, (int32_t *)nullptr, 0);
         int st = expected_depths(e, rs, p);
         if (st) return st;
         launch_raycast(e, "raycast_freeview", p, rs);
@@ -1447,7 +1769,7 @@ static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h,
     if (e->maskHost) (void)hipHostFree(e->maskHost);
     e->maskHost = e->maskHostDev = nullptr; e->maskSlotBytes = 0;
     const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
-    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocMapped) != hipSuccess)
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
       return fail(DSR_E_NOMEM, "mask staging allocation failed");
     if (hipHostGetDevicePointer(reinterpret_cast<void **>(&e->maskHostDev), e->maskHost, 0) != hipSuccess)
       return fail(DSR_E_DEVICE, "mask staging is not device-visible");
@@ -1469,38 +1791,84 @@ static int mask_slot_used(dsr_engine *e, int slot) {
   return DSR_OK;
 }
 
-// maskDev == nullptr: `mask` is a host buffer, staged through the engine's scratch (synchronises)
+// One volume per GPU: the main engine (the full frame) and the instance volume may live on different devices.  The cut-out is
+// produced on main's GPU into a transfer pair, sent with one peer copy per plane (xGMI; through the host where the GPUs have no
+// peer access) on main's stream, and the instance's stream waits for the event behind it.
+static int enable_peer_access(int from, int to) {
+  static std::mutex m;
+  static unsigned long long done[64] = {};
+  if (from == to || from >= 64 || to >= 64) return DSR_OK;
+  std::lock_guard<std::mutex> lock(m);
+  if (done[from] & (1ull << to)) return DSR_OK;
+  int can = 0;
+  if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can) {
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    if (hipSetDevice(from) == hipSuccess) {
+      const hipError_t err = hipDeviceEnablePeerAccess(to, 0);
+      if (err != hipSuccess && err != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // the copy falls back to staging
+    }
+    (void)hipSetDevice(prev);
+  }
+  done[from] |= 1ull << to;
+  return DSR_OK;
+}
+
+// maskDev == nullptr: `mask` is a host buffer, staged through the engine's pinned ring (no synchronisation)
 static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, const uint8_t *maskDev,
                               int x0, int y0, int box_w, int box_h) {
   CHECK_E(main_engine);
   if (!instance || (!mask && !maskDev) || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
   if (!main_engine->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
-  if (instance->device != main_engine->device || instance->W != main_engine->W || instance->H != main_engine->H ||
+  if (instance->W != main_engine->W || instance->H != main_engine->H ||
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
-    return fail(DSR_E_ARG, "main and instance engines must share GPU and image size");
+    return fail(DSR_E_ARG, "main and instance engines must share the image size");
   int maskSlot = -1;
   if (!maskDev) {
     int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
   }
   dsr_engine *e = main_engine;
+  static const bool forcePeerPath = getenv("DSR_FORCE_PEER_PATH") != nullptr;  // tests: the cross-GPU path on one GPU
+  const bool peer = instance->device != e->device || forcePeerPath;
   // runs on the MAIN engine's stream (ordered after the view's producer and before any later
   // blanking); the instance stream then waits for it.  The kernel OVERWRITES the instance's view,
   // which work already queued on the instance's stream (the previous frame's integrate, a set_view
   // copy) may still be reading: the main stream first waits for that work.
+  // (an event is created and recorded with its own stream's device current; WAITING for it works from any device)
+  if (peer) HIP_TRY(hipSetDevice(instance->device));
   if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(instance->xEvent, instance->stream));
+  if (peer) HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamWaitEvent(e->stream, instance->xEvent, 0));
+  { int st = before_view_write(instance, e->stream); if (st) return st; }
+  uchar4 *dstRgb = instance->rgb;
+  float *dstDepth = instance->depth;
+  if (peer) {
+    if (!e->xferRgb) {
+      int st = dmalloc(&e->xferRgb, (size_t)e->P);
+      if (st || (st = dmalloc(&e->xferDepth, (size_t)e->P))) return st;
+    }
+    enable_peer_access(e->device, instance->device);
+    enable_peer_access(instance->device, e->device);
+    dstRgb = e->xferRgb; dstDepth = e->xferDepth;
+  }
   LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
-         (const uchar4 *)e->rgb, (const float *)e->depth, instance->rgb, instance->depth, e->W, e->H,
+         (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
          maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
   if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
+  if (peer) {
+    HIP_TRY(hipMemcpyPeerAsync(instance->rgb, instance->device, e->xferRgb, e->device, (size_t)e->P * 4, e->stream));
+    HIP_TRY(hipMemcpyPeerAsync(instance->depth, instance->device, e->xferDepth, e->device, (size_t)e->P * 4, e->stream));
+  }
   if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(e->xEvent2, e->stream));
+  if (peer) HIP_TRY(hipSetDevice(instance->device));
   HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent2, 0));
-  instance->hasView = true;
-  return DSR_OK;
+  const int stv = view_written(instance, instance->stream);  // the instance's view is final once its stream has passed this point
+  if (peer) HIP_TRY(hipSetDevice(e->device));
+  return stv;
 }
 
 int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
@@ -1523,11 +1891,12 @@ static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *
     int st = upload_mask(e, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
   }
+  { int st = before_view_write(e, e->stream); if (st) return st; }
   LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
          e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
   HIP_TRY(hipGetLastError());
-  if (maskSlot >= 0) return mask_slot_used(e, maskSlot);
-  return DSR_OK;
+  if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
+  return view_written(e, e->stream);
 }
 int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
   return remove_silhouette(e, mask, nullptr, x0, y0, box_w, box_h);
@@ -1605,6 +1974,246 @@ int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uin
   if (tR) CP(hipMemcpy(target_rgba, tR, P * 4, hipMemcpyDeviceToHost));
 #undef CP
   cleanup();
+  return DSR_OK;
+}
+
+// ---- multi-GPU exchange (include/dsr.h): layers of the fused preview, RCCL all-gather, composite
+
+static int exchange_create_common(dsr_exchange *x, int slots_per_rank, int n_pixels) {
+  if (slots_per_rank <= 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad exchange arguments");
+  x->slots = slots_per_rank; x->P = n_pixels;
+  return exchange_alloc(x);
+}
+
+int dsr_exchange_create(const int32_t *devices, int n_ranks, int slots_per_rank, int n_pixels, dsr_exchange **out) {
+  if (!devices || n_ranks <= 0 || !out) return fail(DSR_E_ARG, "bad exchange arguments");
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail(DSR_E_DEVICE, "no HIP device: the exchange has no CPU fallback");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  dsr_exchange *x = new (std::nothrow) dsr_exchange();
+  if (!x) return fail(DSR_E_NOMEM, "oom");
+  x->nRanks = n_ranks;
+  x->groupOfRank.assign(n_ranks, 0); x->indexInGroup.assign(n_ranks, 0); x->devOfRank.assign(n_ranks, -1);
+  std::vector<int> count;
+  for (int r = 0; r < n_ranks; ++r) {
+    const int dv = devices[r] < 0 ? prev : devices[r];
+    if (dv >= nDev) { delete x; return fail(DSR_E_ARG, "device ordinal out of range"); }
+    int g = -1;
+    for (size_t k = 0; k < x->devs.size(); ++k) if (x->devs[k].device == dv) g = (int)k;
+    if (g < 0) { dsr_exchange::Dev d; d.device = dv; d.group = (int)x->devs.size(); x->devs.push_back(d); count.push_back(0); g = d.group; }
+    x->groupOfRank[r] = g; x->indexInGroup[r] = count[g]++; x->devOfRank[r] = g;
+  }
+  x->groups = (int)x->devs.size();
+  x->perGroup = *std::max_element(count.begin(), count.end());
+  int st = exchange_create_common(x, slots_per_rank, n_pixels);
+  // one communicator rank per GPU; a single GPU has nothing to exchange (DSR_EXCHANGE_FORCE_RCCL: a 1-rank communicator anyway,
+  // so that the RCCL path runs on a one-GPU box)
+  if (st == DSR_OK && (x->groups > 1 || getenv("DSR_EXCHANGE_FORCE_RCCL"))) {
+    RcclApi *api = rccl_api();
+    if (!api->error.empty()) st = fail(DSR_E_DEVICE, api->error);
+    else {
+      std::vector<int> devlist; std::vector<ncclComm_t> comms(x->devs.size());
+      for (auto &d : x->devs) devlist.push_back(d.device);
+      const ncclResult_t r = api->CommInitAll(comms.data(), (int)devlist.size(), devlist.data());
+      if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
+      else { for (size_t k = 0; k < comms.size(); ++k) x->devs[k].comm = comms[k]; x->useRccl = true; }
+    }
+  }
+  (void)hipSetDevice(prev);
+  if (st) { exchange_free(x); return st; }
+  *out = x;
+  return DSR_OK;
+}
+
+int dsr_exchange_unique_id(uint8_t id_out[128]) {
+  if (!id_out) return fail(DSR_E_ARG, "null");
+  static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+  RcclApi *api = rccl_api();
+  if (!api->error.empty()) return fail(DSR_E_DEVICE, api->error);
+  ncclUniqueId id;
+  RCCL_TRY(api, api->GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return DSR_OK;
+}
+
+int dsr_exchange_create_rank(const uint8_t unique_id[128], int world_size, int rank, int device, int slots_per_rank, int n_pixels,
+                             dsr_exchange **out) {
+  if (!unique_id || world_size <= 0 || rank < 0 || rank >= world_size || !out) return fail(DSR_E_ARG, "bad exchange arguments");
+  int nDev = 0;
+  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail(DSR_E_DEVICE, "no HIP device: the exchange has no CPU fallback");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  if (device < 0) device = prev;
+  if (device >= nDev) return fail(DSR_E_ARG, "device ordinal out of range");
+  RcclApi *api = rccl_api();
+  if (!api->error.empty()) return fail(DSR_E_DEVICE, api->error);
+  dsr_exchange *x = new (std::nothrow) dsr_exchange();
+  if (!x) return fail(DSR_E_NOMEM, "oom");
+  x->rankMode = true; x->nRanks = world_size; x->groups = world_size; x->perGroup = 1;
+  x->groupOfRank.resize(world_size); x->indexInGroup.assign(world_size, 0); x->devOfRank.assign(world_size, -1);
+  for (int r = 0; r < world_size; ++r) x->groupOfRank[r] = r;
+  dsr_exchange::Dev d; d.device = device; d.group = rank;
+  x->devs.push_back(d);
+  x->devOfRank[rank] = 0;
+  int st = exchange_create_common(x, slots_per_rank, n_pixels);
+  if (st == DSR_OK) {
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    const ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? api->CommInitRank(&x->devs[0].comm, world_size, id, rank) : ncclUnhandledCudaError;
+    if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
+    else x->useRccl = true;
+  }
+  (void)hipSetDevice(prev);
+  if (st) { exchange_free(x); return st; }
+  *out = x;
+  return DSR_OK;
+}
+
+void dsr_exchange_destroy(dsr_exchange *x) {
+  int prev = 0;
+  const bool havePrev = hipGetDevice(&prev) == hipSuccess;
+  exchange_free(x);
+  if (havePrev) (void)hipSetDevice(prev);
+}
+
+void *dsr_exchange_stream(dsr_exchange *x, int rank) {
+  dsr_exchange::Dev *d = local_dev(x, rank);
+  return d ? (void *)d->stream : nullptr;
+}
+
+int dsr_exchange_layer_ptrs(dsr_exchange *x, int on_rank, int rank, int slot, void **rgba_dev, void **depth_dev) {
+  dsr_exchange::Dev *d = local_dev(x, on_rank);
+  if (!d || rank < 0 || rank >= x->nRanks || slot < 0 || slot >= x->slots) return fail(DSR_E_ARG, "bad exchange layer");
+  uint8_t *base = d->all + layer_index(x, rank, slot) * x->layerBytes;
+  if (depth_dev) *depth_dev = base;                       // float depth plane first,
+  if (rgba_dev) *rgba_dev = base + (size_t)x->P * 4;      // then the RGBA plane
+  return DSR_OK;
+}
+
+int dsr_exchange_slot_ptrs(dsr_exchange *x, int rank, int slot, void **rgba_dev, void **depth_dev) {
+  return dsr_exchange_layer_ptrs(x, rank, rank, slot, rgba_dev, depth_dev);
+}
+
+int dsr_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e, int type, const float pose_m[16],
+                             const float intrinsics[4]) {
+  dsr_exchange::Dev *d = local_dev(x, rank);
+  void *rgba = nullptr, *depth = nullptr;
+  if (!d || dsr_exchange_slot_ptrs(x, rank, slot, &rgba, &depth)) return fail(DSR_E_ARG, "bad exchange slot");
+  if (!e) {  // not visible in this frame: an empty layer
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipMemsetAsync(depth, 0, (size_t)x->P * 4, d->stream));
+    return DSR_OK;
+  }
+  if (e->device != d->device) return fail(DSR_E_ARG, "the engine does not live on the rank's GPU");
+  if (e->P != x->P) return fail(DSR_E_ARG, "image size differs from the exchange's");
+  int st = dsr_wait_for_stream(e, d->stream);  // the previous gather / composite is done with this slot
+  if (st) return st;
+  if ((st = render_common(e, type, pose_m, intrinsics, rgba, depth, true))) return st;
+  return dsr_stream_wait_for_engine(e, d->stream);
+}
+
+int dsr_exchange_gather(dsr_exchange *x) {
+  if (!x) return fail(DSR_E_ARG, "null exchange");
+  if (!x->useRccl) return DSR_OK;  // one GPU: every layer is where the composite reads it
+  RcclApi *api = rccl_api();
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  RCCL_TRY(api, api->GroupStart());
+  ncclResult_t r = ncclSuccess;
+  for (auto &d : x->devs) {
+    if (hipSetDevice(d.device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+    r = api->AllGather(d.all + (size_t)d.group * x->chunkBytes, d.all, x->chunkBytes, ncclUint8, d.comm, d.stream);  // in place
+    if (r != ncclSuccess) break;
+  }
+  const ncclResult_t r2 = api->GroupEnd();
+  (void)hipSetDevice(prev);
+  if (r != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclAllGather: ") + api->GetErrorString(r));
+  if (r2 != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclGroupEnd: ") + api->GetErrorString(r2));
+  return DSR_OK;
+}
+
+int dsr_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba_dev, void **depth_dev) {
+  dsr_exchange::Dev *d = local_dev(x, rank);
+  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
+  int st = exchange_target(x, d);
+  if (st) return st;
+  if (rgba_dev) *rgba_dev = d->targetRgba;
+  if (depth_dev) *depth_dev = d->targetDepth;
+  return DSR_OK;
+}
+
+int dsr_exchange_clear_target(dsr_exchange *x, int rank) {
+  dsr_exchange::Dev *d = local_dev(x, rank);
+  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
+  int st = exchange_target(x, d);
+  if (st) return st;
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipMemsetAsync(d->targetRgba, 0, (size_t)x->P * 4, d->stream));
+  HIP_TRY(hipMemsetAsync(d->targetDepth, 0, (size_t)x->P * 4, d->stream));
+  return DSR_OK;
+}
+
+int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev, void *target_depth_dev,
+                           const int32_t *ranks, const int32_t *slots, const int32_t *track_ids, int n_layers, float tint_strength,
+                           int dim_background) {
+  dsr_exchange::Dev *d = local_dev(x, root_rank);
+  if (!d || n_layers < 0 || (n_layers > 0 && (!ranks || !slots || !track_ids))) return fail(DSR_E_ARG, "bad composite arguments");
+  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
+  int st = DSR_OK;
+  if (!target_depth_dev) {
+    if ((st = exchange_target(x, d))) return st;
+    target_rgba_dev = d->targetRgba; target_depth_dev = d->targetDepth;
+  }
+  if (target_engine) {
+    if (target_engine->device != d->device) return fail(DSR_E_ARG, "the target's engine does not live on the root's GPU");
+    if ((st = dsr_stream_wait_for_engine(target_engine, d->stream))) return st;  // its render of the target
+  }
+  const void *rp[kMaxCompositeLayers], *dp[kMaxCompositeLayers];
+  for (int l = 0; l < n_layers; ++l) {
+    void *r = nullptr, *dd = nullptr;
+    if ((st = dsr_exchange_layer_ptrs(x, root_rank, ranks[l], slots[l], &r, &dd))) return st;
+    rp[l] = r; dp[l] = dd;
+  }
+  if (n_layers > 0 &&
+      (st = dsr_composite_layer_ptrs_dev(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
+                                         track_ids, n_layers, x->P, tint_strength, dim_background)))
+    return st;
+  if (target_engine) return dsr_wait_for_stream(target_engine, d->stream);  // its next render of the target waits for the composite
+  return DSR_OK;
+}
+
+int dsr_exchange_gather_and_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev,
+                                      void *target_depth_dev, const int32_t *ranks, const int32_t *slots, const int32_t *track_ids,
+                                      int n_layers, float tint_strength, int dim_background) {
+  int st = dsr_exchange_gather(x);
+  if (st) return st;
+  if (!local_dev(x, root_rank)) return DSR_OK;  // this process does not hold the consumer of the preview
+  return dsr_exchange_composite(x, root_rank, target_engine, target_rgba_dev, target_depth_dev, ranks, slots, track_ids, n_layers,
+                                tint_strength, dim_background);
+}
+
+int dsr_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float *depth_out) {
+  dsr_exchange::Dev *d = local_dev(x, rank);
+  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
+  int st = exchange_target(x, d);
+  if (st) return st;
+  HIP_TRY(hipSetDevice(d->device));
+  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, d->targetRgba, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));
+  if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d->targetDepth, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  return DSR_OK;
+}
+
+int dsr_exchange_sync(dsr_exchange *x) {
+  if (!x) return fail(DSR_E_ARG, "null exchange");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (auto &d : x->devs) {
+    HIP_TRY(hipSetDevice(d.device));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+  }
+  (void)hipSetDevice(prev);
   return DSR_OK;
 }
 
@@ -1919,19 +2528,38 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
   CHECK_E(e);
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (e->W != e->Wr || e->H != e->Hr) return fail(DSR_E_ARG, "rgb and depth sizes differ");
-  // scratch (both only ever hold data within one call): depthTmp takes the BGR triples, freeDepth the millimetre map
-  uint8_t *bgrDev = reinterpret_cast<uint8_t *>(e->depthTmp);
-  short *mmDev = reinterpret_cast<short *>(e->freeDepth);
-  if (bgr_out) {
-    LAUNCH(e, "preview_convert", k_rgba_to_bgr, dim3(div_up(e->P, 256)), dim3(256), (const uchar4 *)e->rgb, bgrDev, e->P);
-    HIP_TRY(hipMemcpyAsync(bgr_out, bgrDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, e->stream));
+  // The previews depend on the VIEW only, and the host asks for them right after queuing the raycast
+  // (InfiniTamDriver.h:148-158): they are produced on the GPU's I/O stream, ordered after the last kernel that wrote the view
+  // (evView) — not behind the integration and the raycast on the engine's stream —, land in pinned memory and are handed
+  // over with one wait for exactly that work.
+  hipStream_t io = nullptr;
+  int st = io_stream(e, &io);
+  if (st) return st;
+  if (!e->pvDev) {
+    e->pvMmOff = ((size_t)e->P * 3 + 255) / 256 * 256;
+    const size_t bytes = e->pvMmOff + (size_t)e->P * 2;
+    if ((st = dmalloc(&e->pvDev, bytes))) return st;
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->pvPin), bytes, hipHostMallocDefault) != hipSuccess)
+      return fail(DSR_E_NOMEM, "pinned preview staging allocation failed");
   }
-  if (depth_mm_out) {
-    LAUNCH(e, "preview_convert", k_depth_m_to_mm, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depth, mmDev, e->P);
-    HIP_TRY(hipMemcpyAsync(depth_mm_out, mmDev, (size_t)e->P * 2, hipMemcpyDeviceToHost, e->stream));
+  if ((st = io_reads_view(e, io))) return st;
+  {
+    StreamSwap sw(e, io);
+    if (bgr_out) {
+      LAUNCH(e, "preview_convert", k_rgba_to_bgr, dim3(div_up(e->P, 256)), dim3(256), (const uchar4 *)e->rgb, e->pvDev, e->P);
+      HIP_TRY(hipMemcpyAsync(e->pvPin, e->pvDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, io));
+    }
+    if (depth_mm_out) {
+      LAUNCH(e, "preview_convert", k_depth_m_to_mm, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depth,
+             reinterpret_cast<short *>(e->pvDev + e->pvMmOff), e->P);
+      HIP_TRY(hipMemcpyAsync(e->pvPin + e->pvMmOff, e->pvDev + e->pvMmOff, (size_t)e->P * 2, hipMemcpyDeviceToHost, io));
+    }
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if ((st = io_read_done(e, io))) return st;
+  HIP_TRY(hipEventSynchronize(e->evViewRead));
+  if (bgr_out) memcpy(bgr_out, e->pvPin, (size_t)e->P * 3);
+  if (depth_mm_out) memcpy(depth_mm_out, e->pvPin + e->pvMmOff, (size_t)e->P * 2);
   return DSR_OK;
 }
 
@@ -2002,7 +2630,7 @@ int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycas
   RenderStateDev &rs = which ? e->freeview : e->live;
   const size_t P = (size_t)e->P;
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
-  if (!which && e->liveExp.valid) HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // a range image still in flight on the side stream
+  if (!which && e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }  // a range image still in flight on the side stream
   if (minmax) HIP_TRY(hipMemcpyAsync(minmax, rs.minmax, (size_t)mw * mh * 8, hipMemcpyDeviceToHost, e->stream));
   if (raycast_result) HIP_TRY(hipMemcpyAsync(raycast_result, rs.raycastResult, P * 16, hipMemcpyDeviceToHost, e->stream));
   if (points) HIP_TRY(hipMemcpyAsync(points, e->pointsMap, P * 16, hipMemcpyDeviceToHost, e->stream));

@@ -509,8 +509,18 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP
 __global__ __launch_bounds__(kTileThreads) void k_visible_write(int noTotalEntries, const uint8_t *__restrict__ visType,
                                                                 const int2 *__restrict__ tileOffsets,
                                                                 int32_t *__restrict__ visibleIDs, int capacity,
-                                                                SceneP s, int useSwapping, int4 *__restrict__ visBlocks) {
+                                                                SceneP s, int useSwapping, int4 *__restrict__ visBlocks,
+                                                                int32_t *__restrict__ publish, int publishSeq) {
   __shared__ int2 lds[kTileThreads / 64];
+  // The host's Integrate() must report an exhausted block array (the fork throws: InstanceReconstructor.cpp:662-671) and reads
+  // noVisibleBlocks right after it (InfiniTamDriver.h:150).  Both words are final once the scan before this kernel has run —
+  // long before the integration that follows — so the first thread publishes them to a pinned, device-mapped host word here:
+  // the host polls that word instead of draining the stream behind k_integrate (dsr_engine.hip wait_published).
+  if (publish && blockIdx.x == 0 && threadIdx.x == 0) {
+    publish[0] = s.ctr[CTR_NO_VISIBLE_LIVE];
+    publish[1] = s.ctr[CTR_STATUS];
+    __hip_atomic_store(publish + 2, publishSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
   uint8_t v[kTileItems];
   bool re[kTileItems];

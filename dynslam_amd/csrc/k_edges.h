@@ -112,6 +112,47 @@ __global__ __launch_bounds__(256) void k_copy_depth_finite(const float *__restri
   if (i < n) { const float d = in[i]; out[i] = d > 1e30f ? 1e30f : d; }
 }
 
+// InfiniTamDriver::UpdateView from the host's own buffers (dsr_update_view_bgr): CvToItm's BGR -> RGBA loop
+// (InfiniTamDriver.cpp:81-100, a = 255) and convertDepthAffineToFloat in one launch, 4 pixels per thread (12 B of BGR in,
+// 16 B of RGBA out, 8 B of int16 depth in, 16 B of float depth out).  The staging buffers are 16-byte aligned.
+__global__ __launch_bounds__(256) void k_view_ingest_bgr(const uint32_t *__restrict__ bgr, uint4 *__restrict__ rgbaOut, int n,
+                                                         const short *__restrict__ depthIn, float *__restrict__ depthOut,
+                                                         float a, float b) {
+  const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    const uint32_t w0 = bgr[(i4 >> 2) * 3], w1 = bgr[(i4 >> 2) * 3 + 1], w2 = bgr[(i4 >> 2) * 3 + 2];  // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+    auto px = [](uint32_t bb, uint32_t gg, uint32_t rr) -> uint32_t { return (rr & 0xffu) | ((gg & 0xffu) << 8) | ((bb & 0xffu) << 16) | 0xff000000u; };
+    uint4 o;
+    o.x = px(w0, w0 >> 8, w0 >> 16);
+    o.y = px(w0 >> 24, w1, w1 >> 8);
+    o.z = px(w1 >> 16, w1 >> 24, w2);
+    o.w = px(w2 >> 8, w2 >> 16, w2 >> 24);
+    rgbaOut[i4 >> 2] = o;
+    const short4 d = *reinterpret_cast<const short4 *>(depthIn + i4);
+    float4 f;
+    f.x = (d.x <= 0 || d.x > 32000) ? -1.0f : (float)d.x * a + b;
+    f.y = (d.y <= 0 || d.y > 32000) ? -1.0f : (float)d.y * a + b;
+    f.z = (d.z <= 0 || d.z > 32000) ? -1.0f : (float)d.z * a + b;
+    f.w = (d.w <= 0 || d.w > 32000) ? -1.0f : (float)d.w * a + b;
+    *reinterpret_cast<float4 *>(depthOut + i4) = f;
+  } else {
+    const uint8_t *bytes = reinterpret_cast<const uint8_t *>(bgr);
+    for (int k = i4; k < n; ++k) {
+      bgr_to_rgba_px(k, bytes, reinterpret_cast<uchar4 *>(rgbaOut));
+      const short d = depthIn[k];
+      depthOut[k] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
+  }
+}
+
+// SetView from host buffers (dsr_set_view_float): RGBA copy + the finite clamp above, out of the upload staging
+__global__ __launch_bounds__(256) void k_set_view_ingest(const uchar4 *__restrict__ rgbaIn, uchar4 *__restrict__ rgbaOut, int nRgb,
+                                                         const float *__restrict__ depthIn, float *__restrict__ depthOut, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nRgb) rgbaOut[i] = rgbaIn[i];
+  if (i < n) { const float d = depthIn[i]; depthOut[i] = d > 1e30f ? 1e30f : d; }
+}
+
 // PrecomputedDepthProvider::ReadPrecomputed, the input_is_depth_ clamp for int16 maps
 // (PrecomputedDepthProvider.cpp:55-74): depth > max_depth_mm_s -> 0
 __global__ __launch_bounds__(256) void k_clip_depth_mm(short *__restrict__ depth, int n, short maxMm) {  // in place

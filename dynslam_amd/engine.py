@@ -95,6 +95,103 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class Exchange:
+    """The fused-preview exchange of include/dsr.h (`dsr_exchange_*`): layer buffers on every GPU this process drives, the RCCL
+    all-gather between them (called by the library itself) and the composite.  `devices`: one process drives all GPUs, rank r
+    on devices[r];  `unique_id` + `world_size` + `rank` + `device`: one process per GPU (the id comes from
+    `Exchange.unique_id()` on rank 0 and travels to the others by the caller's means)."""
+
+    def __init__(self, n_pixels, slots_per_rank, devices=None, unique_id=None, world_size=None, rank=None, device=-1, api=None):
+        self.api = api or load_hip_api()
+        self.P, self.slots = int(n_pixels), int(slots_per_rank)
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            self._check(self.api.exchange_create(arr, len(devices), self.slots, self.P, C.byref(h)))
+            self.n_ranks = len(devices)
+        else:
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+            self._check(self.api.exchange_create_rank(buf, int(world_size), int(rank), int(device), self.slots, self.P, C.byref(h)))
+            self.n_ranks = int(world_size)
+        self._h = h
+
+    @staticmethod
+    def unique_id(api=None):
+        api = api or load_hip_api()
+        buf = (C.c_uint8 * 128)()
+        if api.exchange_unique_id(buf) != DSR_OK:
+            msg = api.last_error()
+            raise DsrError(2, msg.decode() if msg else "exchange_unique_id")
+        return bytes(buf)
+
+    def _check(self, status):
+        if status != DSR_OK:
+            msg = self.api.last_error()
+            raise DsrError(status, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self, rank):
+        return self.api.exchange_stream(self._h, int(rank))
+
+    def slot_ptrs(self, rank, slot):
+        r, d = C.c_void_p(), C.c_void_p()
+        self._check(self.api.exchange_slot_ptrs(self._h, int(rank), int(slot), C.byref(r), C.byref(d)))
+        return r.value, d.value
+
+    def layer_ptrs(self, on_rank, rank, slot):
+        r, d = C.c_void_p(), C.c_void_p()
+        self._check(self.api.exchange_layer_ptrs(self._h, int(on_rank), int(rank), int(slot), C.byref(r), C.byref(d)))
+        return r.value, d.value
+
+    def target_ptrs(self, rank):
+        r, d = C.c_void_p(), C.c_void_p()
+        self._check(self.api.exchange_target_ptrs(self._h, int(rank), C.byref(r), C.byref(d)))
+        return r.value, d.value
+
+    def render_slot(self, rank, slot, engine, image_type=_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=None, intrinsics=None):
+        pm = _colmajor(pose_m) if pose_m is not None else None
+        intr = np.ascontiguousarray(intrinsics, dtype=np.float32) if intrinsics is not None else None
+        self._check(self.api.exchange_render_slot(self._h, int(rank), int(slot), engine._h if engine is not None else None, int(image_type),
+                                                  _ptr(pm) if pm is not None else None, _ptr(intr) if intr is not None else None))
+
+    def gather(self):
+        self._check(self.api.exchange_gather(self._h))
+
+    def clear_target(self, rank):
+        self._check(self.api.exchange_clear_target(self._h, int(rank)))
+
+    def gather_and_composite(self, root_rank, layers, target_engine=None, target_rgba_ptr=None, target_depth_ptr=None, tint_strength=1.0,
+                             dim_background=True, gather=True):
+        """layers: [(rank, slot, track id)] in compositing order (ascending track id)."""
+        n = len(layers)
+        ranks = (C.c_int32 * max(1, n))(*[int(l[0]) for l in layers])
+        slots = (C.c_int32 * max(1, n))(*[int(l[1]) for l in layers])
+        tids = (C.c_int32 * max(1, n))(*[int(l[2]) for l in layers])
+        fn = self.api.exchange_gather_and_composite if gather else self.api.exchange_composite
+        self._check(fn(self._h, int(root_rank), target_engine._h if target_engine is not None else None,
+                       C.c_void_p(target_rgba_ptr) if target_rgba_ptr else None, C.c_void_p(target_depth_ptr) if target_depth_ptr else None,
+                       ranks, slots, tids, n, float(tint_strength), int(bool(dim_background))))
+
+    def read_target(self, rank, width, height):
+        rgba = np.empty((height, width, 4), np.uint8)
+        depth = np.empty((height, width), np.float32)
+        self._check(self.api.exchange_read_target(self._h, int(rank), _ptr(rgba), _ptr(depth)))
+        return rgba, depth
+
+    def sync(self):
+        self._check(self.api.exchange_sync(self._h))
+
+
 class EngineCore:
     """One engine handle (an ITMMainEngine: scene + render states + view + pose)."""
 
@@ -150,6 +247,13 @@ class EngineCore:
         depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
         assert rgba.shape == (self.H, self.W, 4) and depth_mm.shape == (self.H, self.W)
         self._check(self.api.update_view(self._h, _ptr(rgba), _ptr(depth_mm)))
+
+    def update_view_bgr(self, bgr, depth_mm):
+        """InfiniTamDriver::UpdateView from the host's own cv::Mat3b layout (packed BGR) + int16 mm: converted in the ingest kernel."""
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        depth_mm = np.ascontiguousarray(depth_mm, dtype=np.int16)
+        assert bgr.shape == (self.H, self.W, 3) and depth_mm.shape == (self.H, self.W)
+        self._check(self.api.update_view_bgr(self._h, _ptr(bgr), _ptr(depth_mm)))
 
     def update_view_dev(self, rgba_dev_ptr, depth_mm_dev_ptr):
         self._check(self.api.update_view_dev(self._h, C.c_void_p(rgba_dev_ptr), C.c_void_p(depth_mm_dev_ptr)))

@@ -6,8 +6,13 @@ allocate / integrate / raycast / decay, so they shard by volume: the static map 
 rank 0, instance k on rank 1 + (k mod (world-1)).  The only exchange is the fused preview
 (CompositeInstances, InstanceReconstructor.cpp:933-990): every rank renders its volumes from
 the same free camera, the per-volume depth (f32) and colour (RGBA) buffers are ALL-GATHERED
-(RCCL over xGMI; `torch.distributed` backend "nccl" on ROCm, "gloo" in the CPU tests) and
-each rank z-composites them on its GPU with `dsr_composite_instances_dev`.
+and rank 0 z-composites them on its GPU.
+
+On GPUs the exchange IS the C ABI's (`dsr_exchange_*`, include/dsr.h — the same entry points a C++ host calls): the library
+owns the layer buffers, calls RCCL itself (ncclCommInitRank from a unique id this module only carries between the ranks) and
+composites where the all-gather left the layers: `NativeLayers` below is a thin caller.  `PreviewExchange` (torch tensors +
+`torch.distributed`) remains for what RCCL cannot host: the CPU tests (gloo, the oracle as the engine) and several ranks
+sharing ONE GPU (tests on a one-GPU box).
 
 torch is plumbing here (process group, device buffers); the arithmetic is the HIP library.
 """
@@ -124,6 +129,8 @@ class PreviewExchange:
             dp = (C.c_void_p * max(1, n))(*[base + l * 8 * self.P for l in layers])
             rp = (C.c_void_p * max(1, n))(*[base + l * 8 * self.P + 4 * self.P for l in layers])
             ids = (C.c_int32 * max(1, n))(*tids)
+            if len(self._ptr_cache) >= 4:  # track ids change all the time in a long run: keep the few most recent sets
+                self._ptr_cache.pop(next(iter(self._ptr_cache)))
             hit = self._ptr_cache[key] = (n, rp, dp, ids)
         return hit
 
@@ -158,6 +165,65 @@ class PreviewExchange:
         return self.composite_into(target_rgba, target_depth, track_id_of_instance, tint_strength, dim_background)
 
 
+class _DeviceArray:
+    """A torch-importable view (`__cuda_array_interface__`) of HBM the library owns."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class NativeLayers:
+    """The fused-preview exchange through the C ABI (`dynslam_amd.engine.Exchange` = `dsr_exchange_*`): what `ShardedScene` uses on
+    GPUs whenever RCCL can host the ranks (one GPU per rank, or a single rank).  Same surface as `PreviewExchange` as far as
+    `ShardedScene` and the tests need it."""
+
+    def __init__(self, n_pixels, n_volumes, world_size, rank, device, group=None, local_only=False, has_static=True):
+        import torch
+        import torch.distributed as dist
+        from .engine import Exchange
+        self.torch = torch
+        self.P, self.world, self.rank, self.device = int(n_pixels), int(world_size), int(rank), device
+        self.slots = max(1, max_local_instances(n_volumes, world_size, has_static))
+        self.local_instances = instances_of_rank(rank, n_volumes, world_size, has_static)
+        dev_index = device.index if device.index is not None else 0
+        if self.world == 1 and (local_only or not (dist.is_available() and dist.is_initialized())):
+            self.x = Exchange(self.P, self.slots, devices=[dev_index])
+        else:
+            # rank 0 makes the communicator's id, torch.distributed only CARRIES it (a 128-byte broadcast); the collective of the
+            # data path is the library's own RCCL call
+            uid = torch.zeros(128, dtype=torch.uint8, device=device)
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(Exchange.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0, group=group)
+            self.x = Exchange(self.P, self.slots, unique_id=bytes(uid.cpu().numpy().tobytes()), world_size=self.world, rank=self.rank,
+                              device=dev_index)
+        self.slot_of_instance = {}  # instance -> (rank, slot)
+        for r in range(self.world):
+            for s, k in enumerate(instances_of_rank(r, n_volumes, world_size, has_static)):
+                self.slot_of_instance[k] = (r, s)
+
+    def close(self):
+        self.x.close()
+
+    def stream(self):
+        return self.x.stream(self.rank)
+
+    def ordered_layers(self, track_id_of_instance):
+        items = sorted((track_id_of_instance[k], rs) for k, rs in self.slot_of_instance.items() if k in track_id_of_instance)
+        return [(r, s, t) for t, (r, s) in items]
+
+    @property
+    def all_depth(self):
+        """The gathered depth layers as this rank holds them, [world * slots, P] float32 (tests)."""
+        self.x.sync()
+        rows = []
+        for r in range(self.world):
+            for s in range(self.slots):
+                _, d = self.x.layer_ptrs(self.rank, r, s)
+                rows.append(self.torch.as_tensor(_DeviceArray(d, (self.P,), "<f4"), device=self.device).clone())
+        return self.torch.stack(rows)
+
+
 class ShardedScene:
     """The volumes of one DynSLAM scene sharded one-volume-per-GPU, as one object per rank.
 
@@ -190,9 +256,20 @@ class ShardedScene:
         self.instances = {k: make_engine("instance") for k in instances_of_rank(rank, n_volumes, world_size, self.has_static)}
         # the full frame the instance views are cut from
         self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
-        self.exchange = PreviewExchange(self.P, n_volumes, world_size, rank, device, group, local_only, self.has_static)
-        self.target_rgba = torch.zeros((self.P, 4), dtype=torch.uint8, device=device)
-        self.target_depth = torch.zeros((self.P,), dtype=torch.float32, device=device)
+        # GPUs: the C ABI's exchange (RCCL called by the library) whenever RCCL can host the ranks — a process group on "nccl", or a
+        # single rank; several ranks on ONE GPU (gloo, tests) and CPU tensors (the oracle, tests) go through torch.distributed
+        import torch.distributed as dist
+        grouped = dist.is_available() and dist.is_initialized() and not local_only
+        self.native = self.on_gpu and (not grouped or dist.get_backend(group) == "nccl" or int(world_size) == 1)
+        if self.native:
+            self.exchange = NativeLayers(self.P, n_volumes, world_size, rank, device, group, local_only, self.has_static)
+            r, d = self.exchange.x.target_ptrs(self.rank)  # the exchange's own composite target, seen as torch tensors
+            self.target_rgba = torch.as_tensor(_DeviceArray(r, (self.P, 4), "|u1"), device=device)
+            self.target_depth = torch.as_tensor(_DeviceArray(d, (self.P,), "<f4"), device=device)
+        else:
+            self.exchange = PreviewExchange(self.P, n_volumes, world_size, rank, device, group, local_only, self.has_static)
+            self.target_rgba = torch.zeros((self.P, 4), dtype=torch.uint8, device=device)
+            self.target_depth = torch.zeros((self.P,), dtype=torch.float32, device=device)
 
     def engines(self):
         out = ([self.static] if self.static is not None else []) + list(self.instances.values())
@@ -201,12 +278,17 @@ class ShardedScene:
         return out
 
     def close(self):
+        self.sync()
+        if self.native:
+            self.exchange.close()
         for e in self.engines():
             e.close()
 
     def sync(self):
         for e in self.engines():
             e.sync()
+        if self.native:
+            self.exchange.x.sync()
 
     # -- fusion -----------------------------------------------------------------------------
     def step(self, rgba, depth_mm, static_pose, masks):
@@ -266,6 +348,8 @@ class ShardedScene:
         ordered with events (dsr_stream_wait_for_engine)."""
         torch = self.torch
         ex = self.exchange
+        if self.native:
+            return self._preview_native(static_pose_m, instance_pose_m, track_id_of_instance, tint_strength, dim_background)
         cur = torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else None
         for slot, k in enumerate(ex.local_instances):
             ie = self.instances[k]
@@ -292,4 +376,25 @@ class ShardedScene:
         if self.rank != 0:
             return None, None
         ex.composite_into(self.target_rgba, self.target_depth, track_id_of_instance, tint_strength, dim_background)
+        return self.target_rgba, self.target_depth
+
+    def _preview_native(self, static_pose_m, instance_pose_m, track_id_of_instance, tint_strength, dim_background):
+        """The same preview through `dsr_exchange_*`: renders straight into the exchange's slots, ONE RCCL all-gather issued by the
+        library, the composite over the exchange's own target on rank 0 — every ordering (engine streams, exchange stream) is
+        the library's."""
+        from . import _capi
+        x = self.exchange.x
+        for slot, k in enumerate(self.exchange.local_instances):
+            x.render_slot(self.rank, slot, self.instances[k] if k in instance_pose_m else None, _capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+                          instance_pose_m.get(k))
+        if self.owns_static:
+            self.static.wait_for_stream(x.stream(self.rank))  # the previous composite is done with the target
+            self.static.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, static_pose_m, None, self.target_rgba.data_ptr(),
+                                      self.target_depth.data_ptr())
+        elif self.rank == 0 and not self.has_static:
+            x.clear_target(0)
+        x.gather_and_composite(0, self.exchange.ordered_layers(track_id_of_instance), target_engine=self.static if self.owns_static else None,
+                               tint_strength=tint_strength, dim_background=dim_background)
+        if self.rank != 0:
+            return None, None
         return self.target_rgba, self.target_depth

@@ -36,8 +36,9 @@ extern "C" {
 
 /* bumped whenever a public struct layout or the meaning of a field changes, so that a library and a caller built on
  * different sides of the change refuse each other at load (2: dsr_kernel_time grew bytes_layout/units, dsr_stats was
- * extended, DSR_E_IO) */
-#define DSR_ABI_VERSION 2
+ * extended, DSR_E_IO; 3: the multi-GPU exchange (dsr_exchange_*), dsr_update_view_bgr, host-buffer calls no longer
+ * synchronise with the engine's stream) */
+#define DSR_ABI_VERSION 3
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
 #define DSR_BLOCK_SIZE 8
@@ -210,6 +211,12 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
 int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm);
 /* Same with inputs already resident in HBM (no PCIe copy). */
 int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev);
+/* InfiniTamDriver::UpdateView as a whole (InfiniTamDriver.cpp:211-224): CvToItm(rgb_image) — packed BGR u8[3*W*H], the
+ * cv::Mat3b the host holds — + CvToItm(raw_depth) + viewBuilder->UpdateView in ONE call: the frame goes up as the 3 + 2
+ * bytes per pixel the host has (the RGBA form is 4 + 2 and costs the host a 465 750-pixel loop), the BGR -> RGBA
+ * conversion (a = 255) and the depth conversion run in the ingest kernel.  Like dsr_update_view it returns without
+ * waiting for the GPU: the frame is copied into a pinned staging slot (the caller's buffers are free on return). */
+int dsr_update_view_bgr(dsr_engine *e, const uint8_t *bgr, const int16_t *depth_mm);
 /* SetView() with an already converted view: RGBA + float depth in metres.  This
  * is what InstanceReconstructor builds per instance
  * (InstanceReconstructor.cpp:238-263,580) and what it writes back into the main
@@ -325,8 +332,9 @@ int dsr_depth_m_to_mm_dev(int device, void *hip_stream, const void *depth_m_dev,
  * becomes the pixels of `main`'s current view that lie under the copy mask, everything else
  * rgba (255,255,255,255) / depth 0.  mask: HOST uint8[box_h][box_w] (1 = copy), placed at
  * (x0,y0) in the frame (Mask::GetBoundingBox; may stick out of the frame).  Both engines must
- * live on the same GPU and have the same image size.  Replaces the D2H -> CPU loop -> H2D round
- * trip of InstanceReconstructor.cpp:180-197,238-263. */
+ * have the same image size.  They may live on DIFFERENT GPUs (one volume per GPU): the cut-out is
+ * produced on main's GPU and sent to the instance's with one peer copy over xGMI, stream-ordered on
+ * both sides.  Replaces the D2H -> CPU loop -> H2D round trip of InstanceReconstructor.cpp:180-197,238-263. */
 int dsr_view_extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, int x0, int y0,
                                 int box_w, int box_h);
 /* RemoveSilhouette_CPU (InstanceReconstructor.cpp:135-170): pixels of the engine's view under
@@ -369,6 +377,66 @@ int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba
 int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
                             const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
                             float tint_strength, int dim_background);
+
+/* ---- multi-GPU: one volume per GPU, the fused preview exchanged over RCCL / xGMI ---------------
+ *
+ * The reference keeps one InfiniTamDriver per tracked instance (InstanceReconstructor::InitializeReconstruction,
+ * InstanceReconstructor.cpp:363-392) next to the static map's, all on one GPU, and fuses / previews them one after
+ * the other (:315-361, CompositeInstances :933-990).  Volumes share no data, so each engine may live on its own GPU
+ * (dsr_settings.device); the ONE exchange of the path is the fused preview: every volume is raycast from the shared
+ * camera on its own GPU, the per-volume layers (float depth plane + RGBA plane = 8 bytes per pixel) are ALL-GATHERED
+ * and z-composited where the preview is consumed.  A dsr_exchange owns the layer buffers, the RCCL communicator(s) and
+ * one stream per GPU; it calls RCCL itself (librccl is loaded on first use), so a C / C++ host needs nothing else.
+ *
+ * Ranks: a rank is one slot owner — one GPU's worth of volumes.  Two ways to create the exchange:
+ *   dsr_exchange_create       ONE process drives all GPUs (DynSLAM's C++ host): rank r lives on devices[r]; ranks may
+ *                             share a device (their layers are then already in place there; with a single device no
+ *                             communicator is created at all).  Distinct devices: ncclCommInitAll, grouped all-gather.
+ *   dsr_exchange_create_rank  one process per GPU (`torch.distributed`-style launch): rank 0 calls
+ *                             dsr_exchange_unique_id, hands the 128 bytes to every rank by its own means, all ranks call
+ *                             dsr_exchange_create_rank (ncclCommInitRank) collectively.
+ * Every rank contributes `slots_per_rank` layers of n_pixels pixels (unused slots stay empty: depth 0 never wins a
+ * pixel).  Calls on one exchange come from one thread at a time. */
+typedef struct dsr_exchange dsr_exchange;
+int dsr_exchange_create(const int32_t *devices, int n_ranks, int slots_per_rank, int n_pixels, dsr_exchange **out);
+int dsr_exchange_unique_id(uint8_t id_out[128]);
+int dsr_exchange_create_rank(const uint8_t unique_id[128], int world_size, int rank, int device, int slots_per_rank,
+                             int n_pixels, dsr_exchange **out);
+void dsr_exchange_destroy(dsr_exchange *x);
+/* The exchange's hipStream_t on the GPU of local rank `rank` (gather and composite run on it), for callers that order
+ * other streams against it with dsr_wait_for_stream / dsr_stream_wait_for_engine.  NULL for a rank of another process. */
+void *dsr_exchange_stream(dsr_exchange *x, int rank);
+/* HBM addresses of slot `slot` of local rank `rank`: where that rank's renders go (dsr_get_image_dev's two outputs). */
+int dsr_exchange_slot_ptrs(dsr_exchange *x, int rank, int slot, void **rgba_dev, void **depth_dev);
+/* ... and of the gathered copy of (rank, slot) on the GPU of local rank `on_rank` (valid after dsr_exchange_gather). */
+int dsr_exchange_layer_ptrs(dsr_exchange *x, int on_rank, int rank, int slot, void **rgba_dev, void **depth_dev);
+/* GetImage(colour) + GetFloatImage(depth) of one volume from the preview camera (InstanceReconstructor.cpp:923,968:
+ * the model view composed with the instance's pose) straight into slot `slot` of local rank `rank`, ordered after the
+ * previous gather's reads of that slot and before the next gather — no host synchronisation.  `e` must live on the
+ * rank's GPU.  e == NULL: the slot becomes an empty layer (an instance that is not visible in this frame). */
+int dsr_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e, int type, const float pose_m[16],
+                             const float intrinsics[4]);
+/* The all-gather of every rank's layers (one collective; nothing for a single device).  Collective in rank mode. */
+int dsr_exchange_gather(dsr_exchange *x);
+/* CompositeInstances on the GPU of local rank `root_rank`: layers (ranks[i], slots[i]) with track_ids[i], in the
+ * given order (the host's ascending track ids), over the target — arithmetic of dsr_composite_layer_ptrs_dev.
+ * target_*_dev == NULL: the exchange's own target pair on that GPU (dsr_exchange_target_ptrs: render the static map
+ * into it first, or clear it).  target_engine (may be NULL): the engine that rendered the target — the composite is
+ * ordered after its queued work and its later work after the composite. */
+int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev,
+                           void *target_depth_dev, const int32_t *ranks, const int32_t *slots, const int32_t *track_ids,
+                           int n_layers, float tint_strength, int dim_background);
+/* dsr_exchange_gather + dsr_exchange_composite (ranks without the root: root_rank < 0 or not local — gather only). */
+int dsr_exchange_gather_and_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev,
+                                      void *target_depth_dev, const int32_t *ranks, const int32_t *slots,
+                                      const int32_t *track_ids, int n_layers, float tint_strength, int dim_background);
+/* The exchange's own composite target on the GPU of local rank `rank` (RGBA + float depth, n_pixels each), its
+ * clearing (no static map: instances over an empty frame) and its read-back (synchronises). */
+int dsr_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba_dev, void **depth_dev);
+int dsr_exchange_clear_target(dsr_exchange *x, int rank);
+int dsr_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float *depth_out);
+/* Blocks until the exchange's streams are idle. */
+int dsr_exchange_sync(dsr_exchange *x);
 
 /* ---- statistics / parity dumps ------------------------------------------------ */
 

@@ -1378,6 +1378,16 @@ int orc_update_view(dsr_engine *h, const uint8_t *rgba, const int16_t *depth_mm)
 int orc_update_view_dev(dsr_engine *h, const void *rgba, const void *depth_mm) {
   return orc_update_view(h, (const uint8_t *)rgba, (const int16_t *)depth_mm);
 }
+/* InfiniTamDriver::UpdateView as a whole (InfiniTamDriver.cpp:211-224): CvToItm(rgb_image) (:81-100, restated in
+ * orc_bgr_to_rgba) followed by viewBuilder->UpdateView. */
+int orc_bgr_to_rgba(const uint8_t *bgr, uint8_t *rgba_out, int n);
+int orc_update_view_bgr(dsr_engine *h, const uint8_t *bgr, const int16_t *depth_mm) {
+  if (!h || !bgr || !depth_mm) return fail(DSR_E_ARG, "null");
+  std::vector<uint8_t> rgba((size_t)E.Wr * E.Hr * 4);
+  int st = orc_bgr_to_rgba(bgr, rgba.data(), E.Wr * E.Hr);
+  if (st) return st;
+  return orc_update_view(h, rgba.data(), depth_mm);
+}
 int orc_set_view_float(dsr_engine *h, const uint8_t *rgba, const float *depth_m) {
   if (!h || !rgba || !depth_m) return fail(DSR_E_ARG, "null");
   memcpy(E.rgb.data(), rgba, (size_t)E.Wr * E.Hr * 4);
@@ -1771,6 +1781,95 @@ int orc_composite_instances_dev(int, void *, void *target_rgba, void *target_dep
   return orc_composite_instances((uint8_t *)target_rgba, (float *)target_depth, (const uint8_t *)layers_rgba,
                                  (const float *)layers_depth, track_ids, n_layers, n_pixels, tint_strength, dim_background);
 }
+
+/* ---- the multi-GPU exchange (include/dsr.h) as the CPU checker sees it: "devices" are host memory, every rank lives in this
+ * process, the layers of all ranks lie in one buffer — the all-gather has nothing to move.  Rank-per-process mode exists only
+ * for a world of one (the checker has no transport; the multi-process CPU tests exchange the layers over gloo). */
+struct dsr_exchange {
+  int nRanks = 0, slots = 0, P = 0;
+  std::vector<uint8_t> all;                  /* nRanks x slots layers: float depth plane, then RGBA plane */
+  std::vector<uint8_t> targetRgba;
+  std::vector<float> targetDepth;
+};
+static int orc_exchange_make(int n_ranks, int slots, int P, dsr_exchange **out) {
+  if (n_ranks <= 0 || slots <= 0 || P <= 0 || !out) return fail(DSR_E_ARG, "bad exchange arguments");
+  dsr_exchange *x = new dsr_exchange();
+  x->nRanks = n_ranks; x->slots = slots; x->P = P;
+  x->all.assign((size_t)n_ranks * slots * P * 8, 0);
+  x->targetRgba.assign((size_t)P * 4, 0); x->targetDepth.assign((size_t)P, 0.0f);
+  *out = x;
+  return DSR_OK;
+}
+int orc_exchange_create(const int32_t *devices, int n_ranks, int slots_per_rank, int n_pixels, dsr_exchange **out) {
+  if (!devices) return fail(DSR_E_ARG, "bad exchange arguments");
+  return orc_exchange_make(n_ranks, slots_per_rank, n_pixels, out);
+}
+int orc_exchange_unique_id(uint8_t id_out[128]) { if (!id_out) return fail(DSR_E_ARG, "null"); memset(id_out, 0, 128); return DSR_OK; }
+int orc_exchange_create_rank(const uint8_t unique_id[128], int world_size, int rank, int, int slots_per_rank, int n_pixels, dsr_exchange **out) {
+  if (!unique_id || world_size != 1 || rank != 0) return fail(DSR_E_ARG, "the CPU checker has no transport between processes");
+  return orc_exchange_make(1, slots_per_rank, n_pixels, out);
+}
+void orc_exchange_destroy(dsr_exchange *x) { delete x; }
+void *orc_exchange_stream(dsr_exchange *, int) { return nullptr; }
+int orc_exchange_layer_ptrs(dsr_exchange *x, int on_rank, int rank, int slot, void **rgba, void **depth) {
+  if (!x || on_rank < 0 || on_rank >= x->nRanks || rank < 0 || rank >= x->nRanks || slot < 0 || slot >= x->slots) return fail(DSR_E_ARG, "bad exchange layer");
+  uint8_t *base = x->all.data() + ((size_t)rank * x->slots + slot) * x->P * 8;
+  if (depth) *depth = base;
+  if (rgba) *rgba = base + (size_t)x->P * 4;
+  return DSR_OK;
+}
+int orc_exchange_slot_ptrs(dsr_exchange *x, int rank, int slot, void **rgba, void **depth) { return orc_exchange_layer_ptrs(x, rank, rank, slot, rgba, depth); }
+int orc_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4]) {
+  void *rgba = nullptr, *depth = nullptr;
+  int st = orc_exchange_slot_ptrs(x, rank, slot, &rgba, &depth);
+  if (st) return st;
+  if (!e) { memset(depth, 0, (size_t)x->P * 4); return DSR_OK; }
+  if (e->e.W * e->e.H != x->P) return fail(DSR_E_ARG, "image size differs from the exchange's");
+  return orc_get_image_dev(e, type, pose_m, intrinsics, rgba, depth);
+}
+int orc_exchange_gather(dsr_exchange *x) { return x ? DSR_OK : fail(DSR_E_ARG, "null exchange"); }
+int orc_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba, void **depth) {
+  if (!x || rank < 0 || rank >= x->nRanks) return fail(DSR_E_ARG, "bad exchange rank");
+  if (rgba) *rgba = x->targetRgba.data();
+  if (depth) *depth = x->targetDepth.data();
+  return DSR_OK;
+}
+int orc_exchange_clear_target(dsr_exchange *x, int rank) {
+  if (!x || rank < 0 || rank >= x->nRanks) return fail(DSR_E_ARG, "bad exchange rank");
+  std::fill(x->targetRgba.begin(), x->targetRgba.end(), 0); std::fill(x->targetDepth.begin(), x->targetDepth.end(), 0.0f);
+  return DSR_OK;
+}
+int orc_composite_layer_ptrs_dev(int, void *, void *target_rgba, void *target_depth, const void *const *layer_rgba_ptrs,
+                                 const void *const *layer_depth_ptrs, const int32_t *track_ids, int n_layers, int n_pixels,
+                                 float tint_strength, int dim_background);
+int orc_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *, void *target_rgba, void *target_depth, const int32_t *ranks,
+                           const int32_t *slots, const int32_t *track_ids, int n_layers, float tint_strength, int dim_background) {
+  if (!x || root_rank < 0 || root_rank >= x->nRanks || n_layers < 0 || (n_layers > 0 && (!ranks || !slots || !track_ids))) return fail(DSR_E_ARG, "bad composite arguments");
+  if (!target_depth) { target_rgba = x->targetRgba.data(); target_depth = x->targetDepth.data(); }
+  std::vector<const void *> rp((size_t)std::max(n_layers, 1)), dp((size_t)std::max(n_layers, 1));
+  for (int l = 0; l < n_layers; ++l) {
+    void *r = nullptr, *d = nullptr;
+    int st = orc_exchange_layer_ptrs(x, root_rank, ranks[l], slots[l], &r, &d);
+    if (st) return st;
+    rp[l] = r; dp[l] = d;
+  }
+  if (n_layers == 0) return DSR_OK;
+  return orc_composite_layer_ptrs_dev(-1, nullptr, target_rgba, target_depth, target_rgba ? rp.data() : nullptr, dp.data(), track_ids, n_layers,
+                                      x->P, tint_strength, dim_background);
+}
+int orc_exchange_gather_and_composite(dsr_exchange *x, int root_rank, dsr_engine *te, void *target_rgba, void *target_depth, const int32_t *ranks,
+                                      const int32_t *slots, const int32_t *track_ids, int n_layers, float tint_strength, int dim_background) {
+  if (!x) return fail(DSR_E_ARG, "null exchange");
+  if (root_rank < 0 || root_rank >= x->nRanks) return DSR_OK;
+  return orc_exchange_composite(x, root_rank, te, target_rgba, target_depth, ranks, slots, track_ids, n_layers, tint_strength, dim_background);
+}
+int orc_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float *depth_out) {
+  if (!x || rank < 0 || rank >= x->nRanks) return fail(DSR_E_ARG, "bad exchange rank");
+  if (rgba_out) memcpy(rgba_out, x->targetRgba.data(), (size_t)x->P * 4);
+  if (depth_out) memcpy(depth_out, x->targetDepth.data(), (size_t)x->P * 4);
+  return DSR_OK;
+}
+int orc_exchange_sync(dsr_exchange *x) { return x ? DSR_OK : fail(DSR_E_ARG, "null exchange"); }
 
 int orc_get_stats(dsr_engine *h, dsr_stats *out) {
   if (!h || !out) return fail(DSR_E_ARG, "null");

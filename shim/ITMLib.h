@@ -15,6 +15,7 @@
 // which is exactly the round trip InstanceReconstructor.cpp:180-197,262-263 performs.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <stdexcept>
@@ -213,6 +214,10 @@ struct ITMLibSettings {
   int maxWDynamic = 10;                                 // fork (DynSLAMGUI.cpp:1217-1219)
   // engine table sizes (upstream compile-time constants)
   int hashBucketNum = DSR_DEFAULT_BUCKET_NUM, excessListSize = DSR_DEFAULT_EXCESS_LIST_SIZE;
+  // one volume per GPU: the HIP device the engine built from these settings lives on; -1 = the placement
+  // policy below (dynslam_shim::PlaceVolume), so that the reference's UNMODIFIED InstanceReconstructor::InitializeReconstruction
+  // (InstanceReconstructor.cpp:363-392: `new InfiniTamDriver(settings, ...)` per track) lands every track's volume on its own GPU
+  int deviceIndex = -1;
   std::string groundTruthPoseFpath; int groundTruthPoseOffset = 0;
 };
 
@@ -311,6 +316,39 @@ inline void dsr_throw(int st) {
 
 using namespace ITMLib::Objects;
 using ITMLib::Engine::WeightParams;
+
+// Device placement of a volume.  DSR_DEVICES="0,1,2,3" lists the GPUs this host may use (unset: everything on the current
+// device, as the reference).  The static map — any volume larger than an instance's — takes the first; instance volumes
+// (sdfLocalBlockNum <= 16384; the reference's are 7142, InstanceReconstructor.cpp:379) go round-robin over the OTHERS
+// (BASELINE configs[3]: "static map on GPU0 + 7 instance volumes on GPUs 1-7"), or over all of them with
+// DSR_INSTANCES_ON_ALL_DEVICES=1 (north_star's N concurrent instance volumes).  An explicit ITMLibSettings::deviceIndex wins.
+namespace dynslam_shim {
+inline const std::vector<int> &Devices() {
+  static const std::vector<int> devices = [] {
+    std::vector<int> d;
+    const char *env = std::getenv("DSR_DEVICES");
+    for (const char *p = env; p && *p;) {
+      char *end = nullptr;
+      const long v = std::strtol(p, &end, 10);
+      if (end == p) break;
+      d.push_back((int)v);
+      p = (*end == ',') ? end + 1 : end;
+    }
+    return d;
+  }();
+  return devices;
+}
+inline int PlaceVolume(const ITMLib::Objects::ITMLibSettings *s) {
+  if (s->deviceIndex >= 0) return s->deviceIndex;
+  const std::vector<int> &d = Devices();
+  if (d.empty()) return -1;
+  if (s->sdfLocalBlockNum > 16384 || d.size() == 1) return d[0];
+  static int next = 0;
+  const bool all = std::getenv("DSR_INSTANCES_ON_ALL_DEVICES") != nullptr;
+  const int n = all ? (int)d.size() : (int)d.size() - 1;
+  return d[(all ? 0 : 1) + (next++ % n)];
+}
+}  // namespace dynslam_shim
 
 // The layout loops of InfiniTamDriver.cpp:81-144 on the GPU, for hosts without OpenCV types at hand:
 // raw buffers in, raw buffers out (a cv::Mat3b is `rows*cols` packed BGR triples, a cv::Mat1s `short`s).
@@ -437,6 +475,14 @@ class ITMViewBuilder {
     // keep the host colour copy current; the converted depth is fetched on UpdateHostFromDevice()
     (*view)->rgb->SetFrom(rgb, ORUtils::MemoryBlock<Vector4u>::CPU_TO_CPU);
   }
+  // InfiniTamDriver::UpdateView as a whole (InfiniTamDriver.cpp:211-224) for hosts that hold the frame as OpenCV does — packed
+  // BGR + int16 mm: CvToItm's loop runs in the engine's ingest kernel (dsr_update_view_bgr), the host copies of the view are
+  // fetched when somebody asks for them (UpdateHostFromDevice)
+  void UpdateViewBgr(ITMView **view, const unsigned char *bgr, const short *rawDepthMm, Vector2i size) {
+    if (*view == nullptr) *view = new ITMView(calib_, size, size, true);
+    ITMLib::Engine::dsr_throw(dsr_update_view_bgr(e_, bgr, rawDepthMm));
+    (*view)->bind(e_); (*view)->deviceStale = false;
+  }
  private:
   dsr_engine *e_;
   const ITMRGBDCalib *calib_;
@@ -465,6 +511,7 @@ class ITMMainEngine {
     s.sdf_local_block_num = (int32_t)settings->sdfLocalBlockNum;
     s.hash_bucket_num = settings->hashBucketNum; s.excess_list_size = settings->excessListSize;
     s.use_swapping = settings->useSwapping; s.use_bilateral_filter = settings->useBilateralFilter; s.sync_status = 1;
+    s.device = deviceIndex_ = dynslam_shim::PlaceVolume(settings);
     dsr_calib c; std::memset(&c, 0, sizeof c);
     auto fill = [](dsr_intrinsics &o, const ITMIntrinsics &i, Vector2i sz) {
       o.fx = i.projectionParamsSimple.all.x; o.fy = i.projectionParamsSimple.all.y; o.cx = i.projectionParamsSimple.all.z;
@@ -494,6 +541,7 @@ class ITMMainEngine {
   ITMScene<ITMVoxel, ITMVoxelIndex> *GetScene() { return scene; }
   Vector2i GetImageSize() const { return imgSize_; }
   dsr_engine *GetDsrEngine() { return engine_; }
+  int GetDeviceIndex() const { return deviceIndex_; }  // -1: the device that was current when the engine was built
 
   // ITMMainEngine::GetImage(out, outFloat, type, pose, intrinsics) (InfiniTamDriver.cpp:178-183,202-207)
   void GetImage(ITMUChar4Image *out, ITMFloatImage *outFloat, GetImageType type, ITMPose *pose = nullptr, ITMIntrinsics *intrinsics = nullptr) {
@@ -524,4 +572,5 @@ class ITMMainEngine {
  private:
   dsr_engine *engine_ = nullptr;
   Vector2i imgSize_;
+  int deviceIndex_ = -1;
 };

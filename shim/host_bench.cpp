@@ -17,11 +17,20 @@
 //        cut out of the static view ON THE GPU (dsr_view_extract_silhouette / dsr_view_remove_silhouette — what replaces
 //        ProcessSilhouette_CPU / RemoveSilhouette_CPU and their D2H/H2D round trip, InstanceReconstructor.cpp:59-197) and fused
 //        into their own volumes (0.035 m, mu 1.0, 7142 blocks: InstanceReconstructor.cpp:372-379) by further HostDrivers.
+//        [--devices d0,d1,...]  (with --masks) one volume per GPU through the C ABI: the static map lives on d0, instance k on
+//        d[1 + k mod (n-1)] (n = 1: everything on d0) — ITMLibSettings::deviceIndex, what dynslam_shim::PlaceVolume derives from
+//        DSR_DEVICES for the reference's unmodified InstanceReconstructor::InitializeReconstruction (:363-392); the view split
+//        crosses GPUs inside dsr_view_extract_silhouette; the fused preview (CompositeInstances, :933-990) is served by a
+//        dsr_exchange: every volume raycast on its own GPU into its slot, ONE RCCL all-gather, composite on d0.  Devices may repeat
+//        ("0,0": two ranks on one GPU — the exchange degenerates to buffers in place).
+//        [--preview]  the fused preview inside the timed loop, every frame (without --devices: GetImage + GetFloatImage per volume
+//        to the host and dsr_composite_instances — the reference's own flow)
 //   masks.bin: per frame int32 n; per mask int32 k, x0, y0, bw, bh; float rel[16] (camera->object, ROW-major); u8 mask[bw*bh]
 //   frames.bin: per frame  BGR u8[H*W*3], depth int16[H*W] (mm), pose float[16] (camera->world, ROW-major);
 //               then float[16]: model-view matrix (world->camera, row-major) of the final free-view render
 // prints one line: key=value ... (frames_per_s over the frames after `warmup`, FNV-1a digest of the
 // final free-view colour + float depth renders, the view depth and the previews)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -53,9 +62,15 @@ class HostDriver : public ITMMainEngine {
       : ITMMainEngine(s, c, size, size), rgb_(size, true, true), rawDepth_(size, true, true), previewMm_((size_t)size.x * size.y),
         previewBgr_((size_t)size.x * size.y * 3), decay_(decay), decayMaxW_(decayMaxW), decayMinAge_(decayMinAge) {}
   void UpdateView(const unsigned char *bgr, const short *depthMm) {  // InfiniTamDriver.cpp:211-224
-    dynslam_shim::CvToItm(bgr, rawDepth_.noDims.y, rawDepth_.noDims.x, &rgb_);
-    std::memcpy(rawDepth_.GetData(MEMORYDEVICE_CPU), depthMm, rawDepth_.dataSize * sizeof(short));
-    viewBuilder->UpdateView(&view, &rgb_, &rawDepth_, settings->useBilateralFilter, settings->modelSensorNoise);
+    static const bool twoStep = std::getenv("DSR_HOST_TWO_STEP_UPDATE") != nullptr;  // A/B: the reference's two-step form
+    if (twoStep) {
+      dynslam_shim::CvToItm(bgr, rawDepth_.noDims.y, rawDepth_.noDims.x, &rgb_);
+      std::memcpy(rawDepth_.GetData(MEMORYDEVICE_CPU), depthMm, rawDepth_.dataSize * sizeof(short));
+      viewBuilder->UpdateView(&view, &rgb_, &rawDepth_, settings->useBilateralFilter, settings->modelSensorNoise);
+    } else {
+      // CvToItm + viewBuilder->UpdateView in one call: the BGR frame goes up as it is, the conversion runs in the ingest kernel
+      viewBuilder->UpdateViewBgr(&view, bgr, depthMm, rawDepth_.noDims);
+    }
   }
   void SetPose(const Matrix4f &invM) { trackingState->pose_d->SetInvM(invM); }  // .h:131-134
   void Integrate() {                                                         // .h:137-146
@@ -115,6 +130,15 @@ int main(int argc, char **argv) {
   const float fx = (float)atof(argv[4]), fy = (float)atof(argv[5]), cx = (float)atof(argv[6]), cy = (float)atof(argv[7]);
   const char *masksPath = nullptr;
   int nInstances = 0;
+  std::vector<int> devices;
+  bool previewEveryFrame = false;
+  for (int a = argc - 1; a >= 15; a--) {  // trailing options, stripped from the positional list
+    if (strcmp(argv[a], "--preview") == 0 && a == argc - 1) { previewEveryFrame = true; argc = a; }
+    else if (a + 1 < argc && strcmp(argv[a], "--devices") == 0 && a + 2 == argc) {
+      for (const char *p = argv[a + 1]; *p;) { char *end = nullptr; devices.push_back((int)strtol(p, &end, 10)); if (end == p) break; p = (*end == ',') ? end + 1 : end; }
+      argc = a;
+    }
+  }
   for (int a = 15; a + 2 < argc + 0; a++)
     if (strcmp(argv[a], "--masks") == 0) { masksPath = argv[a + 1]; nInstances = atoi(argv[a + 2]); argc = a; break; }
   const bool decay = argc > 16;
@@ -180,13 +204,69 @@ int main(int argc, char **argv) {
     Matrix4f identity; identity.setIdentity();
     calib->trafo_rgb_to_depth.SetFrom(identity);
     calib->disparityCalib.SetFrom(1.0f / 1000.0f, 0.0f, ITMDisparityCalib::TRAFO_AFFINE);
+    // one volume per GPU: rank 0 = the static map on devices[0], instance k on rank 1 + k mod (n - 1)
+    const int nRanks = devices.empty() ? 1 : (int)devices.size();
+    auto rankOfInstance = [&](int k) { return nRanks > 1 ? 1 + k % (nRanks - 1) : 0; };
+    if (!devices.empty()) settings.deviceIndex = devices[0];
     HostDriver drv(&settings, calib, Vector2i(W, H), decay, decayMaxW, decayMinAge);
     // one volume per tracked instance (InstanceReconstructor.cpp:363-389)
-    ITMLibSettings instSettings = settings;
-    instSettings.sceneParams.voxelSize = 0.035f; instSettings.sceneParams.mu = 1.0f;
-    instSettings.sdfLocalBlockNum = 7142; instSettings.hashBucketNum = 0x100000; instSettings.excessListSize = 0x20000;
+    std::vector<ITMLibSettings> instSettings(std::max(1, nInstances), settings);
     std::vector<std::unique_ptr<HostDriver>> inst;
-    for (int k = 0; k < nInstances; k++) inst.emplace_back(new HostDriver(&instSettings, calib, Vector2i(W, H), false, 0, 0));
+    std::vector<int> slotOfInstance(nInstances, 0), perRank(nRanks, 0);
+    for (int k = 0; k < nInstances; k++) {
+      ITMLibSettings &is = instSettings[k];
+      is.sceneParams.voxelSize = 0.035f; is.sceneParams.mu = 1.0f;
+      is.sdfLocalBlockNum = 7142; is.hashBucketNum = 0x100000; is.excessListSize = 0x20000;
+      if (!devices.empty()) is.deviceIndex = devices[rankOfInstance(k)];
+      slotOfInstance[k] = perRank[rankOfInstance(k)]++;
+      inst.emplace_back(new HostDriver(&is, calib, Vector2i(W, H), false, 0, 0));
+    }
+    // the fused preview (CompositeInstances, InstanceReconstructor.cpp:933-990): through the exchange with --devices, else the
+    // reference's own flow (every volume's colour + depth to the host, composited there by dsr_composite_instances)
+    dsr_exchange *xch = nullptr;
+    if (!devices.empty() && nInstances > 0) {
+      std::vector<int32_t> dv(devices.begin(), devices.end());
+      const int slots = std::max(1, *std::max_element(perRank.begin(), perRank.end()));
+      ITMLib::Engine::dsr_throw(dsr_exchange_create(dv.data(), nRanks, slots, W * H, &xch));
+    }
+    std::vector<unsigned char> compRgba(P * 4, 0), layerRgba;
+    std::vector<float> compDepth(P, 0.0f), layerDepth;
+    auto fusedPreview = [&](const Matrix4f &M, const std::vector<MaskRec> &frameMasks, bool readBack) {
+      // object -> camera of the preview camera = the model view composed with the instance's pose (:923,968)
+      std::vector<int32_t> ranks, slots, tids;
+      std::vector<Matrix4f> poses;
+      for (const auto &m : frameMasks) {
+        Matrix4f rel, relInv;
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) rel.at(c, r) = m.rel[r * 4 + c];
+        rel.inv(relInv);
+        poses.push_back(relInv); ranks.push_back(rankOfInstance(m.k)); slots.push_back(slotOfInstance[m.k]); tids.push_back(1 + m.k);
+      }
+      for (size_t a = 0; a + 1 < tids.size(); a++)  // ascending track id, the order of the host's loop over its tracks
+        for (size_t b = a + 1; b < tids.size(); b++)
+          if (tids[b] < tids[a]) { std::swap(tids[a], tids[b]); std::swap(ranks[a], ranks[b]); std::swap(slots[a], slots[b]); std::swap(poses[a], poses[b]); }
+      if (xch) {
+        void *tr = nullptr, *td = nullptr;
+        ITMLib::Engine::dsr_throw(dsr_exchange_target_ptrs(xch, 0, &tr, &td));
+        ITMLib::Engine::dsr_throw(dsr_wait_for_stream(drv.GetDsrEngine(), dsr_exchange_stream(xch, 0)));
+        ITMLib::Engine::dsr_throw(dsr_get_image_dev(drv.GetDsrEngine(), DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, M.m, nullptr, tr, td));
+        for (size_t l = 0; l < tids.size(); l++) {
+          const int k = tids[l] - 1;
+          ITMLib::Engine::dsr_throw(dsr_exchange_render_slot(xch, ranks[l], slots[l], inst[k]->GetDsrEngine(), DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+                                                             poses[l].m, nullptr));
+        }
+        ITMLib::Engine::dsr_throw(dsr_exchange_gather_and_composite(xch, 0, drv.GetDsrEngine(), nullptr, nullptr, ranks.data(), slots.data(), tids.data(),
+                                                                    (int)tids.size(), 1.0f, 1));
+        if (readBack) ITMLib::Engine::dsr_throw(dsr_exchange_read_target(xch, 0, compRgba.data(), compDepth.data()));
+      } else {
+        ITMLib::Engine::dsr_throw(dsr_get_image(drv.GetDsrEngine(), DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, M.m, nullptr, compRgba.data(), compDepth.data()));
+        layerRgba.resize(P * 4 * std::max<size_t>(1, tids.size())); layerDepth.resize(P * std::max<size_t>(1, tids.size()));
+        for (size_t l = 0; l < tids.size(); l++)
+          ITMLib::Engine::dsr_throw(dsr_get_image(inst[tids[l] - 1]->GetDsrEngine(), DSR_IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, poses[l].m, nullptr,
+                                                  layerRgba.data() + l * P * 4, layerDepth.data() + l * P));
+        ITMLib::Engine::dsr_throw(dsr_composite_instances(compRgba.data(), compDepth.data(), layerRgba.data(), layerDepth.data(), tids.data(),
+                                                          (int)tids.size(), (int)P, 1.0f, 1));
+      }
+    };
 #endif
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < nFrames; i++) {
@@ -219,6 +299,13 @@ int main(int argc, char **argv) {
       drv.Integrate();
       drv.PrepareNextStep();
       drv.Decay();
+#ifndef DSR_HOST_REFERENCE_DRIVER
+      if (previewEveryFrame && masksPath) {
+        Matrix4f Mv;
+        invM.inv(Mv);
+        fusedPreview(Mv, masks[i], false);
+      }
+#endif
     }
     // GetUsedMemoryBytes reads the free-list head from the device: it also drains the stream
     size_t instUsed = 0;
@@ -226,6 +313,9 @@ int main(int argc, char **argv) {
     for (auto &id : inst) instUsed += id->GetUsedMemoryBytes();
 #endif
     const size_t used = drv.GetUsedMemoryBytes();
+#ifndef DSR_HOST_REFERENCE_DRIVER
+    if (xch) ITMLib::Engine::dsr_throw(dsr_exchange_sync(xch));
+#endif
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
     // a free-view colour + depth render from the pose in the file's trailer
@@ -261,14 +351,26 @@ int main(int argc, char **argv) {
 #endif
     h = fnv(mm.data(), P * 2, h);
     h = fnv(pbgr.data(), P * 3, h);
-    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu instances=%d inst_used_bytes=%zu hash=%016llx\n",
+    unsigned long long compositeHash = 0;
+#ifndef DSR_HOST_REFERENCE_DRIVER
+    if (masksPath && nFrames > 0) {  // the fused preview of the last frame, from its own camera
+      Matrix4f lastInv, lastM;
+      const float *T = &poses[(size_t)(nFrames - 1) * 16];
+      for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) lastInv.at(c, r) = T[r * 4 + c];
+      lastInv.inv(lastM);
+      fusedPreview(lastM, masks[nFrames - 1], true);
+      compositeHash = fnv(compDepth.data(), P * 4, fnv(compRgba.data(), P * 4));
+    }
+    if (xch) dsr_exchange_destroy(xch);
+#endif
+    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu instances=%d inst_used_bytes=%zu composite_hash=%016llx ranks=%d hash=%016llx\n",
 #ifdef DSR_HOST_REFERENCE_DRIVER
            "reference",
 #else
            "shim",
 #endif
            nFrames, nFrames - warmup, (nFrames - warmup) / secs, 1e3 * secs / (nFrames - warmup), used, drv.GetSavedDecayMemoryBytes(),
-           nInstances, instUsed, (unsigned long long)h);
+           nInstances, instUsed, compositeHash, (int)(devices.empty() ? 1 : devices.size()), (unsigned long long)h);
   } catch (const std::exception &ex) {
     fprintf(stderr, "error: %s\n", ex.what());
     return 1;

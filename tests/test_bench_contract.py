@@ -90,7 +90,7 @@ def _volumes_worker(rank, world, port, out_dir):
     from oracle.oracle import OracleEngine, load_api, oracle_settings
     W, H, V = 256, 80, world
     args = argparse.Namespace(volumes=V, width=W, height=H, steps=3, warmup=1, preset="5cm", no_profile=False, no_time_sliced=False,
-                              decay=False, swap=False, instances=0)
+                              decay=False, swap=False, instances=0, no_cpu_baseline=False, cpu_budget_s=1.0)
     frames = [bench._gen_frame((W, H, i, V - 1)) for i in range(args.steps + args.warmup)]
     calib = make_calib(*StreetScene(W, H, n_instances=V - 1).intrinsics(), W, H)
     kinds = bench.volume_settings(args.preset)
@@ -118,7 +118,7 @@ def test_configs3_bench_line_at_world_size_n(tmp_path, world):
     s.close()
     mp.spawn(_volumes_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     line = json.load(open(tmp_path / "line.json"))
-    assert line["n_gpus"] == world and line["unit"] == "volume-frames/s" and line["scaling"] == "weak" and line["steps"] == 3 and line["warmup"] == 1
+    assert line["n_gpus"] == world and line["unit"] == "volume-frames/s" and line["scaling"] == "strong" and line["steps"] == 3 and line["warmup"] == 1
     assert line["metric"].startswith("frames/sec TSDF integrate+raycast") and line["higher_is_better"] is True and line["vs_baseline"] is None
     cfg = line["config"]
     assert cfg["volumes"] == world and cfg["volumes_per_rank"] == [1] * world and cfg["workload"].startswith("configs[3]")
@@ -127,8 +127,13 @@ def test_configs3_bench_line_at_world_size_n(tmp_path, world):
     assert abs(cfg["composited_frames_per_s"] * world - line["value"]) / line["value"] < 1e-3
     assert cfg["preview_hit_fraction"] > 0.3 and cfg["status"] == 0 and cfg["static_visible_blocks_last_frame"] > 100
     ts = line["time_sliced_1gpu"]
-    assert ts and ts["composited_frames_per_s"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0
-    assert line["roofline"] is None and line["cpu_baseline"] is None  # no HIP events on a CPU device; N = 1 item
+    assert ts and ts["composited_frames_per_s"] > 0
+    # the same workload on ONE GPU and the ratio are top-level keys of the line
+    assert line["value_same_workload_1gpu"] == ts["value"] and abs(line["speedup_vs_1gpu"] - line["value"] / ts["value"]) < 2e-3
+    assert line["roofline"] is None  # no HIP events on a CPU device
+    cpu = line["cpu_baseline"]  # the N > 1 line carries the CPU baseline of ITS workload: the same volumes on the host cores
+    assert cpu["kind"] == "port" and cpu["unit"] == "volume-frames/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and str(world) in cpu["sample"]
+    assert line["backend"] == "hip"  # run_volumes' default: only bench._test_backend's seam stamps anything else
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -149,20 +154,33 @@ def test_cli_gpus_n_spawns_its_own_ranks(n):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout  # ONE line for the whole job
     line = json.loads(lines[0])
-    assert line["n_gpus"] == n and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["n_gpus"] == n and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "strong"
     assert line["unit"] == "volume-frames/s" and line["metric"].startswith("frames/sec TSDF integrate+raycast")
+    assert line["backend"] == "test-seam:tests.bench_backend_oracle"  # a line made through the seam says so
     cfg = line["config"]
-    # the headline leg: N concurrent instance volumes, one per rank, no static map
+    # the headline leg: north_star's 8 concurrent instance volumes — the SAME 8 for every N, instance k on rank k mod N
     assert cfg["workload"].startswith("north_star scaling workload") and cfg["has_static_map"] is False
-    assert cfg["volumes"] == n and cfg["volumes_per_rank"] == [1] * n and cfg["status"] == 0
-    assert abs(line["value"] - n * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-3
-    assert line["time_sliced_1gpu"]["value"] > 0 and line["speedup_vs_time_sliced_1gpu"] > 0
+    assert cfg["volumes"] == 8 and cfg["volumes_per_rank"] == {2: [4, 4], 3: [3, 3, 2]}[n] and cfg["status"] == 0
+    assert abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2 / 1e3)) / line["value"] < 1e-3
+    assert line["time_sliced_1gpu"]["value"] == line["value_same_workload_1gpu"] > 0 and line["speedup_vs_1gpu"] > 0
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
     assert cfg["preview_hit_fraction"] > 0.001  # the composited preview holds the instances' pixels
-    # the second leg, nested: configs[3] with the static map on rank 0
+    # the second leg, nested: configs[3] — the static map on rank 0 + 7 instance volumes on the other ranks
     c3 = line["configs3"]
     assert c3["config"]["workload"].startswith("configs[3]") and c3["config"]["has_static_map"] is True
-    assert c3["config"]["volumes_per_rank"] == [1] * n and c3["value"] > 0 and c3["time_sliced_1gpu"]["value"] > 0
-    assert c3["config"]["static_visible_blocks_last_frame"] > 100
+    assert c3["config"]["volumes_per_rank"] == {2: [1, 7], 3: [1, 4, 3]}[n] and c3["value"] > 0 and c3["time_sliced_1gpu"]["value"] > 0
+    assert c3["config"]["static_visible_blocks_last_frame"] > 100 and c3["cpu_baseline"]["value"] > 0
+
+
+def test_seam_refuses_modules_outside_tests(monkeypatch):
+    """DSR_BENCH_TEST_BACKEND may only name a module under tests/: the oracle itself, or anything else importable, is refused."""
+    monkeypatch.setenv("DSR_BENCH_TEST_BACKEND", "oracle.oracle")
+    with pytest.raises(RuntimeError, match="only loads modules under tests/"):
+        bench._test_backend()
+    monkeypatch.setenv("DSR_BENCH_TEST_BACKEND", "tests.bench_backend_oracle")
+    assert bench.backend_name(bench._test_backend()) == "test-seam:tests.bench_backend_oracle"
+    monkeypatch.delenv("DSR_BENCH_TEST_BACKEND")
+    assert bench._test_backend() is None and bench.backend_name(None) == "hip"
 
 
 def test_cli_rank_failure_does_not_hang():
@@ -193,7 +211,8 @@ def test_cli_gpus_2_with_hip_engines_on_one_gpu(hip_api):
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["unit"] == "volume-frames/s" and line["config"]["volumes_per_rank"] == [1, 1]
+    assert line["n_gpus"] == 2 and line["unit"] == "volume-frames/s" and line["config"]["volumes_per_rank"] == [4, 4]
+    assert line["backend"] == "test-seam:tests.bench_backend_hip_gloo"
     assert line["config"]["status"] == 0 and line["config"]["preview_hit_fraction"] > 0.001
     assert line["time_sliced_1gpu"]["value"] > 0 and line["configs3"]["config"]["static_visible_blocks_last_frame"] > 100
     assert line["configs3"]["config"]["preview_hit_fraction"] > 0.3

@@ -281,6 +281,49 @@ def test_cpp_host_with_instance_volumes_runs_on_the_cpu_oracle(oracle_lib, tmp_p
     assert int(got["instances"]) == n_inst and int(got["inst_used_bytes"]) == inst_used > 2 * 4096, out
     assert int(got["used_bytes"]) == 8 * 512 * (st.num_allocated_voxel_blocks - st.last_free_block_id), out
     assert got["hash"] == f"{h:016x}", out
+    # one volume per GPU through the C ABI (--devices: ITMLibSettings::deviceIndex + dsr_exchange_*): the fused preview served by
+    # the exchange equals the reference's own flow (every volume's render to the host, composited there) — with one rank, with
+    # two ranks "on one device" and with the preview inside the frame loop
+    assert int(got["composite_hash"], 16) != 0
+    for extra, ranks in (["--devices", "0"], 1), (["--devices", "0,0"], 2), (["--devices", "0,0,0", "--preview"], 3), (["--preview"], 1):
+        o2 = dict(kv.split("=") for kv in subprocess.check_output([str(exe)] + _instances_args(path, mpath, sc, n, W, H, n_inst) + extra).decode().split())
+        assert o2["composite_hash"] == got["composite_hash"] and o2["hash"] == got["hash"] and int(o2["ranks"]) == ranks, (extra, o2)
+
+
+def build_oracle_host(tmp_path):
+    """shim/host_bench.cpp with every dsr_* call renamed to the CPU oracle's orc_* (TEST-ONLY build: the checker of the -m gpu tests)"""
+    from dynslam_amd import _capi
+    from oracle.oracle import LIB_PATH
+    rename = tmp_path / "dsr_to_orc.h"
+    rename.write_text("".join(f"#define dsr_{name} orc_{name}\n" for name in _capi.SIGNATURES))
+    exe = tmp_path / "host_bench_cpu"
+    odir = os.path.dirname(LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-include", str(rename), "-I", os.path.join(ROOT, "shim"),
+                           os.path.join(ROOT, "shim", "host_bench.cpp"), "-o", str(exe), "-L", odir, "-loracle", f"-Wl,-rpath,{odir}"])
+    return str(exe)
+
+
+@pytest.mark.gpu
+def test_cpp_host_one_volume_per_gpu_through_the_exchange(hip_api, oracle_lib, tmp_path):
+    """VERDICT r3 item 1b: `shim/host_bench --masks --devices N` — the volume-per-GPU split (ITMLibSettings::deviceIndex), the
+    cross-GPU view split and the fused preview through dsr_exchange_* (RCCL called by the library) from a C++ host.  On a
+    one-GPU box: devices {0,0} (two ranks, one GPU: the exchange degenerates to layers in place), the same with the cross-GPU
+    code paths forced (peer copy of the cut-out; a 1-rank RCCL communicator and its all-gather) — each equals the
+    single-engine run (no exchange: renders to the host + dsr_composite_instances) and the SAME host on the CPU oracle."""
+    W, H, n, n_inst = 320, 96, 4, 3
+    sc, frames, path, mpath, M = _instances_case(tmp_path, W, H, n, n_inst)
+    assert sum(len(f[3]) for f in frames) >= n
+    base = _instances_args(path, mpath, sc, n, W, H, n_inst)
+    ref = dict(kv.split("=") for kv in subprocess.check_output([build_oracle_host(tmp_path)] + base).decode().split())
+    assert int(ref["composite_hash"], 16) != 0
+    hip = build_shim_host()
+    runs = [([], {}), (["--devices", "0,0"], {}), (["--devices", "0,0", "--preview"], {}),
+            (["--devices", "0,0,0"], {"DSR_FORCE_PEER_PATH": "1"}), (["--devices", "0"], {"DSR_EXCHANGE_FORCE_RCCL": "1"}),
+            (["--devices", "0,0"], {"DSR_EXCHANGE_FORCE_RCCL": "1", "DSR_FORCE_PEER_PATH": "1"})]
+    for extra, env in runs:
+        got = dict(kv.split("=") for kv in subprocess.check_output([hip] + base + extra, env=dict(os.environ, **env)).decode().split())
+        assert got["composite_hash"] == ref["composite_hash"] and got["hash"] == ref["hash"], (extra, env, got, ref)
+        assert got["inst_used_bytes"] == ref["inst_used_bytes"] and got["used_bytes"] == ref["used_bytes"]
 
 
 @pytest.mark.gpu
