@@ -158,6 +158,14 @@ struct dsr_engine {
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
+  // k_raycast leaves a ray after this many loop trips and k_raycast_tail resumes it, 8 lanes per ray (k_raycast.h); 0: one kernel.
+  // env DSR_RAYCAST_SPLIT overrides (tests: 0 = every ray goes through the tail kernel is NOT expressible — use 1).
+  int raycastSplit = 0;
+  int gridRaycastTail = 2048;   // env DSR_GRID_RAYCAST_TAIL
+  float4 *tailState = nullptr;
+  int *tailPix = nullptr;
+  uint32_t *tailCount = nullptr;
+  unsigned long long raycastLaunches = 0;
   int threadsExpected = 1024;   // ... and their size (env DSR_EXPECTED_THREADS: a multiple of 64 up to 1024)
   bool expectedFilter = false;  // k_expected_depth_lds<FILTER> (env DSR_EXPECTED_FILTER)
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
@@ -408,7 +416,7 @@ void free_all(dsr_engine *e) {
     if (e->upPin[k]) (void)hipHostFree(e->upPin[k]);
     if (e->upSlotFree[k]) (void)hipEventDestroy(e->upSlotFree[k]);
   }
-  F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth);
+  F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth); F(e->tailState); F(e->tailPix); F(e->tailCount);
   if (e->pvPin) (void)hipHostFree(e->pvPin);
   if (e->statusHost) (void)hipHostFree(e->statusHost);
   for (hipEvent_t ev : {e->evUploaded, e->evIngested, e->evView, e->evViewRead}) if (ev) (void)hipEventDestroy(ev);
@@ -680,7 +688,25 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
 
 int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderStateDev &rs) {
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  if (e->raycastSplit > 0) {
+    // the march in two kernels (k_raycast.h "the tail of the launch taken out of the kernel"): the counters alternate between
+    // launches — k_raycast appends to tailCount[parity], k_raycast_tail reads it and clears the other one for the next launch
+    if (!e->tailState) {
+      int st = dmalloc(&e->tailState, (size_t)e->P);
+      if (st || (st = dmalloc(&e->tailPix, (size_t)e->P)) || (st = dmalloc(&e->tailCount, (size_t)2))) return st;
+      HIP_TRY(hipMemsetAsync(e->tailCount, 0, 8, e->stream));
+    }
+    uint32_t *cur = e->tailCount + (e->raycastLaunches & 1), *next = e->tailCount + ((e->raycastLaunches + 1) & 1);
+    e->raycastLaunches++;
+    ProfScope _ps(e, name);  // one record for the pair: the frame's raycast
+    hipLaunchKernelGGL(k_raycast, g, dim3(256), 0, e->stream, p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult,
+                       e->raycastSplit, e->tailState, e->tailPix, cur);
+    hipLaunchKernelGGL(k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), 0, e->stream, p, e->scene, (const float2 *)rs.minmax,
+                       rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
+    return DSR_OK;
+  }
+  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, 0,
+         (float4 *)nullptr, (int *)nullptr, (uint32_t *)nullptr);
   return DSR_OK;
 }
 
@@ -1043,6 +1069,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
   if (const char *ef = getenv("DSR_EXPECTED_FILTER")) e->expectedFilter = atoi(ef) != 0;
   if (const char *et = getenv("DSR_EXPECTED_THREADS")) e->threadsExpected = std::min(1024, std::max(64, (atoi(et) / 64) * 64));
+  if (const char *rs = getenv("DSR_RAYCAST_SPLIT")) e->raycastSplit = std::max(0, atoi(rs));
+  if (const char *gt = getenv("DSR_GRID_RAYCAST_TAIL")) e->gridRaycastTail = std::max(1, atoi(gt));
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));

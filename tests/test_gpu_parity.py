@@ -360,7 +360,11 @@ def test_free_view_cache(hip_api):
                                  dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768"),
                                  # the small-volume paths (expected depths by one workgroup, free-view list by one sweep) forced
                                  # onto this 40000-block volume; the large-volume paths are what the other cases run
-                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5")])
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5"),
+                                 # the raycast in two kernels (k_raycast cut after K loop trips, k_raycast_tail with 8 lanes per ray):
+                                 # every ray through the tail kernel (K = 1), a cut in the middle of the march, a tiny tail grid
+                                 dict(DSR_RAYCAST_SPLIT="1"), dict(DSR_RAYCAST_SPLIT="6", DSR_GRID_RAYCAST_TAIL="3"),
+                                 dict(DSR_RAYCAST_SPLIT="17", DSR_SMALL_VOLUME="1"), dict(DSR_RAYCAST_SPLIT="0")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
@@ -438,3 +442,111 @@ def test_pose_or_list_change_between_fusion_and_prepare(hip_api):
     # ... and the plain sequence afterwards still takes the speculative image and matches
     feed((g, o), sc, 5)
     assert_render_equal(g, o)
+
+
+@pytest.mark.parametrize("size", [(320, 96), (203, 77)])
+def test_update_view_bgr_equals_the_two_step_form(hip_api, size):
+    """dsr_update_view_bgr (InfiniTamDriver::UpdateView as a whole: CvToItm's BGR -> RGBA loop inside the ingest kernel) gives the
+    view and the scene of CvToItm on the host followed by dsr_update_view — also for pixel counts that are not multiples of 4."""
+    W, H = size
+    sc, g, o = make_pair(W=W, H=H)
+    sc2, g2, o2 = make_pair(W=W, H=H)
+    o2.close()
+    for i in range(3):
+        rgba, d, T, _ = sc.frame(i)
+        rgba = rgba.copy(); rgba[..., 3] = 255  # CvToItm sets alpha to 255 (InfiniTamDriver.cpp:94)
+        bgr = np.ascontiguousarray(rgba[..., 2::-1])
+        g.update_view(rgba, d); o.update_view(rgba, d)
+        g2.update_view_bgr(bgr, d)
+        for e in (g, o, g2):
+            e.set_pose_inv_m(T); e.process_frame(); e.prepare()
+        va, vb, vo = g.get_view(), g2.get_view(), o.get_view()
+        assert np.array_equal(va[0], vo[0]) and np.array_equal(vb[0], vo[0])
+        assert np.array_equal(va[1].view(np.uint32), vo[1].view(np.uint32)) and np.array_equal(vb[1].view(np.uint32), vo[1].view(np.uint32))
+    assert_scene_equal(g, o)
+    assert_scene_equal(g2, o)
+    for e in (g, o, g2):
+        e.close()
+
+
+def test_host_buffer_frames_pipelined_without_waiting(hip_api):
+    """Host-buffer frames (dsr_update_view: pinned double-buffered staging, upload on the I/O stream, landing buffer, ingest on the
+    engine's stream) handed over back to back with sync_status = 0 — the host never waits, overwrites its own buffers right after
+    every call, and asks for previews and the view in between (I/O-stream readers of the view) — the final state is the
+    oracle's, several times over."""
+    from tests.common import assert_render_equal
+    import ctypes as C
+    for rep in range(3):
+        sc, g, o = make_pair(sync_status=0)
+        frames = [sc.frame(i) for i in range(9)]
+        W, H = g.W, g.H
+        scratch_c = np.empty((H, W, 4), np.uint8); scratch_d = np.empty((H, W), np.int16)
+        for i, (rgba, d, T, _) in enumerate(frames):
+            scratch_c[...] = rgba; scratch_d[...] = d
+            g.update_view(scratch_c, scratch_d)
+            scratch_c[...] = 0; scratch_d[...] = 0  # the caller's buffers are free as soon as the call returns
+            g.set_pose_inv_m(T); g.process_frame(); g.prepare()
+            o.update_view(rgba, d); o.set_pose_inv_m(T); o.process_frame(); o.prepare()
+            if i % 3 == 1:  # previews / read-backs of the view while the fusion of this frame is still in flight
+                bgr = np.zeros((H, W, 3), np.uint8); mm = np.zeros((H, W), np.int16)
+                assert hip_api.get_view_previews(g._h, bgr.ctypes.data_as(C.c_void_p), mm.ctypes.data_as(C.c_void_p)) == 0
+                assert np.array_equal(bgr, rgba[..., 2::-1])
+                vr, vd = g.get_view()
+                assert np.array_equal(vr, rgba) and np.array_equal(vd.view(np.uint32), o.get_view()[1].view(np.uint32))
+        g.sync()
+        assert_scene_equal(g, o)
+        assert_render_equal(g, o)
+        g.close(); o.close()
+
+
+def test_published_status_and_visible_count(hip_api, monkeypatch):
+    """The status word dsr_process_frame returns and noVisibleBlocks are PUBLISHED by the allocation's last kernel into pinned
+    host memory (the host does not wait for the integration): same values as the read-back path (DSR_NO_PUBLISHED_STATUS), an
+    exhausted block array is still reported by the frame that caused it, and the next frame starts clean."""
+    import ctypes as C
+    from dynslam_amd.engine import OutOfBlocksError
+    n = C.c_int32(-1)
+    results = []
+    for published in (True, False):
+        if not published:
+            monkeypatch.setenv("DSR_NO_PUBLISHED_STATUS", "1")
+        sc, g, o = make_pair(sdf_local_block_num=1500)
+        seen = []
+        for i in range(4):
+            rgba, d, T, _ = sc.frame(i)
+            flags = []
+            for e in (g, o):
+                e.update_view(rgba, d); e.set_pose_inv_m(T)
+                try:
+                    e.process_frame(); flags.append(False)
+                except OutOfBlocksError:
+                    flags.append(True)
+            assert flags[0] == flags[1]
+            assert hip_api.get_no_visible_blocks(g._h, C.byref(n)) == 0 and n.value == o.get_stats().no_visible_blocks
+            seen.append((flags[0], n.value))
+        assert any(f for f, _ in seen)
+        assert_scene_equal(g, o)
+        results.append(seen)
+        g.close(); o.close()
+    assert results[0] == results[1]
+
+
+def test_mask_staging_ring_reuse(hip_api):
+    """the pinned, device-mapped mask ring (32 slots) reused more than twice over with a DIFFERENT mask every time and
+    no synchronisation in between — every kernel must have read its own mask (coherent mapping, slot events)."""
+    sc, g, o = make_pair()
+    rgba, d, T, _ = sc.frame(0)
+    for e in (g, o):
+        e.update_view(rgba, d)
+    rng = np.random.default_rng(5)
+    W, H = g.W, g.H
+    for i in range(81):
+        bw, bh = int(rng.integers(8, 40)), int(rng.integers(6, 24))
+        x0, y0 = int(rng.integers(-10, W - 10)), int(rng.integers(-5, H - 5))
+        mask = (rng.random((bh, bw)) < 0.35).astype(np.uint8)
+        for e in (g, o):
+            e.remove_silhouette(mask, x0, y0)
+    vg, vo = g.get_view(), o.get_view()
+    assert np.array_equal(vg[0], vo[0]) and np.array_equal(vg[1].view(np.uint32), vo[1].view(np.uint32))
+    assert (vo[1] == 0).mean() > 0.2
+    g.close(); o.close()
