@@ -154,6 +154,7 @@ struct dsr_engine {
   // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
+  bool integrateXLds = false;  // k_integrate<..., XLDS>: the wave-uniform x terms through LDS (env DSR_INTEGRATE_XLDS)
   // a volume of instance size (7142 blocks in the reference, InstanceReconstructor.cpp:379): its frames are bound by the number
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
@@ -643,8 +644,14 @@ int integrate_scene(dsr_engine *e) {
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
-  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC>), dim3(e->gridIntegrate), dim3(256), p, e->scene,       \
-         (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats)
+  do {                                                                                                       \
+    if (e->integrateXLds)                                                                                    \
+      LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, true>), dim3(e->gridIntegrate), dim3(256), p, e->scene, \
+             (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats); \
+    else                                                                                                     \
+      LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, false>), dim3(e->gridIntegrate), dim3(256), p, e->scene, \
+             (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats); \
+  } while (0)
 #define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
   do {                                                                                                       \
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
@@ -1077,6 +1084,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
+  if (const char *xl = getenv("DSR_INTEGRATE_XLDS")) e->integrateXLds = atoi(xl) != 0;
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();

@@ -117,7 +117,12 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 //  SIMD, 546 / 561 us against 559 / 559 us — nothing, profiles/r03g_integrate_vreg_variants.log.  With the row products
 //  hoisted by hand (to_camera below) the kernel needs 65 VGPRs; compiled for 8 waves per SIMD (64 VGPRs, 35 SGPR spills) it
 //  is slower: 576-584 vs 557-560 us, profiles/r03h_integrate_occ8_variants.log.)
-template <bool RGB_SAME, bool PLAIN, int VOX, int OCC>
+// XLDS (round 4): with VOX = 8 a lane's eight voxels are the block's eight x positions, the same for every lane of the wave: the
+// x terms of the camera transform — (float)(gx + x) * voxelSize and its three products with the first matrix column, five VALU
+// instructions per voxel on wave-uniform values — are computed ONCE per task by lanes 0..7, parked in LDS and read back by every
+// lane with one broadcast ds_read_b128 per voxel: the LDS port instead of the vector ALU this kernel is bound by (35 of ~695
+// instructions per task).  The values are the same products of the same operands: bit-identical.
+template <bool RGB_SAME, bool PLAIN, int VOX, int OCC, bool XLDS = false>
 __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                          const uchar4 *__restrict__ rgb,
                                                                          const int4 *__restrict__ visBlocks,
@@ -129,6 +134,8 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   constexpr int kPendCap = 64 + kVoxPerTask;
   __shared__ uint32_t s_pend[kIntegrateWaves][kPendCap];
   __shared__ float s_rcpW[257];  // RN(1/w), w = 1..256 (`/` is the correctly rounded division)
+  __shared__ float4 s_xprod[XLDS ? kIntegrateWaves : 1][8];  // per wave: (M0 mx, M1 mx, M2 mx, mx) of the task's eight x positions
+  static_assert(!XLDS || VOX == 8, "the x positions are wave-uniform only when a lane owns a whole x row");
   for (int i = threadIdx.x; i < 257; i += 64 * kIntegrateWaves) s_rcpW[i] = 1.0f / (float)(i > 0 ? i : 1);
   __syncthreads();
 
@@ -266,6 +273,18 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       r.z = hM2 * mx + yz_ + zz + hM14 * 1.0f;
       return r;
     };
+    if (XLDS) {
+      // (the previous task's reads of the row are complete: its results were consumed before its stores were issued)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < 8) {
+        const float mx = (float)(gx + lane) * hVs;
+        s_xprod[wave][lane] = make_float4(hM0 * mx, hM1 * mx, hM2 * mx, mx);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     // ---------------------------------------------- phase A1: project, issue the depth gathers
     float pz[VOX], dm[VOX];
@@ -274,8 +293,16 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
       bool allTame = true;
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
-        const float mx = (float)(gx + x) * hVs;
-        const float3 pc = to_camera(mx);
+        float3 pc;
+        if (XLDS) {
+          const float4 xp = s_xprod[wave][x];  // same address in every lane: a broadcast read
+          pc.x = xp.x + yx + zx + hM12 * 1.0f;
+          pc.y = xp.y + yy + zy + hM13 * 1.0f;
+          pc.z = xp.z + yz_ + zz + hM14 * 1.0f;
+        } else {
+          const float mx = (float)(gx + x) * hVs;
+          pc = to_camera(mx);
+        }
         const bool tame = pc.z >= 1e-4f;
         const float zs = tame ? pc.z : 1.0f;
         const float yz = rcp_refined(zs);

@@ -18,6 +18,11 @@ Cases
   cfg2_instances BASELINE configs[2]: static 5 mm map + 4 instance volumes (0.035 m, mu 1.0,
                  7142 blocks: InstanceReconstructor.cpp:372-379), masks split on the device
                  (ProcessSilhouette / RemoveSilhouette), 3 frames.
+  cfg3_static_plus_7_instances  BASELINE configs[3]: static 5 mm map + 7 instance volumes, 15 frames (the far boxes of
+                 the synthetic street come inside the 20 m depth clip from frame ~5 on: all seven are fused and composited by the
+                 end), and EVERY frame the fused preview of InstanceReconstructor::CompositeInstances (:911-990): the map and
+                 every visible instance raycast (colour + float depth) from the frame's camera, z-composited in ascending track
+                 id — digests of the composited colour and depth next to every volume's state.
 
 Like state_digests.json these pin the ORACLE's outputs (the reference's engines are an empty
 submodule: parity with upstream itself stays unpinned).
@@ -62,6 +67,9 @@ CASES = {
     "cfg2_instances": dict(frames=3, instances=4, decay=None, render_every=1,
                            settings=dict(voxel_size=0.005, mu=0.02, sdf_local_block_num=1 << 21, hash_bucket_num=1 << 22,
                                          excess_list_size=1 << 20, **COMMON)),
+    "cfg3_static_plus_7_instances": dict(frames=15, instances=7, decay=None, render_every=5, composite=True,
+                                         settings=dict(voxel_size=0.005, mu=0.02, sdf_local_block_num=1 << 21, hash_bucket_num=1 << 22,
+                                                       excess_list_size=1 << 20, **COMMON)),
 }
 
 
@@ -109,6 +117,30 @@ def scene_digest(e, voxels, render):
     return out
 
 
+def fused_preview(e, inst, masks, T):
+    """InstanceReconstructor::CompositeInstances (InstanceReconstructor.cpp:911-990) for one frame: the static map and every
+    instance with a detection in this frame raycast (colour + float depth) from the frame's camera — the instance's pose is the
+    model view composed with its object pose (:923,968) —, z-composited over the dimmed map in ascending track id (= 1 + k).
+    -> (rgba [H, W, 4], depth [H, W]) through the engine's own C ABI (dsr_composite_instances / the oracle's restatement)."""
+    import ctypes as C
+    from dynslam_amd import _capi
+    M = np.linalg.inv(np.asarray(T, np.float64)).astype(np.float32)
+    rgba, depth = e.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+    layers = sorted((1 + k, k, rel) for k, _, _, _, rel in masks)
+    if layers:
+        lc, ld = [], []
+        for _, k, rel in layers:
+            c, d = inst[k].get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32),
+                                     want_rgba=True, want_depth=True)
+            lc.append(c); ld.append(d)
+        lc, ld = np.ascontiguousarray(np.stack(lc)), np.ascontiguousarray(np.stack(ld))
+        tids = np.array([t for t, _, _ in layers], np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        st = e.api.composite_instances(vp(rgba), vp(depth), vp(lc), vp(ld), vp(tids), len(layers), depth.size, 1.0, 1)
+        assert st == 0, st
+    return rgba, depth
+
+
 def run_case(make_engine, case, frames, log=None):
     """make_engine(settings_kwargs, calib_args) -> EngineCore-like; frames = bench.make_frames(...)."""
     from dynslam_amd import _capi
@@ -154,6 +186,11 @@ def run_case(make_engine, case, frames, log=None):
             rec["stored_blocks_first64"] = sha.hexdigest()
         if inst and (render or last):
             rec["instances"] = [scene_digest(ie, "all", True) for ie in inst]
+        if case.get("composite"):
+            c_rgba, c_depth = fused_preview(e, inst, masks, T)
+            rec["composite_rgba"], rec["composite_depth"] = _h(c_rgba), _h(c_depth)
+            rec["composite_layers"] = len(masks)
+            rec["composite_hit_fraction"] = round(float((c_depth > 0).mean()), 6)
         out["frames"].append(rec)
         if log:
             log(f"frame {i}: visible {rec['no_visible_blocks']}, free head {rec['last_free_block_id']}")
