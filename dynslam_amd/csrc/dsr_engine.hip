@@ -2462,6 +2462,16 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
   return DSR_OK;
 }
 
+// measurement only (tools/ab_raycast_split.py; not part of include/dsr.h): rays the last two launches of k_raycast handed to k_raycast_tail
+int dsr_debug_tail_rays(dsr_engine *e, uint32_t out[2]) {
+  CHECK_E(e);
+  out[0] = out[1] = 0;
+  if (!e->tailCount) return DSR_OK;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(out, e->tailCount, 8, hipMemcpyDeviceToHost));
+  return DSR_OK;
+}
+
 #ifdef DSR_RAYCAST_STATS
 // measurement builds only (tools/raycast_wave_stats.py): where k_raycast writes its 12 words per wave
 int dsr_debug_raycast_stats(void *dev_buf) {

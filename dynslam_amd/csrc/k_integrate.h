@@ -291,11 +291,22 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
     bool graze = false;
     {
       bool allTame = true;
+      // the row is read one voxel AHEAD of its use (a read issued right before its use costs the wave the LDS latency eight
+      // times per task); the address lives in a vector register of its own (an opaque copy: otherwise re-made per read)
+      // (three words per row are read: a b128 read's unused fourth register gets re-used by the compiler at once, and the
+      //  write-after-write hazard on it makes the wave wait for the read right where it was issued)
+      typedef const __attribute__((address_space(3))) float *lds_row_t;
+      struct xrow_v3 { float x, y, z; };
+      lds_row_t xrow = (lds_row_t)&s_xprod[XLDS ? wave : 0][0];
+      if (XLDS) asm volatile("" : "+v"(xrow));
+      xrow_v3 xpNext = {0.f, 0.f, 0.f};
+      if (XLDS) xpNext = xrow_v3{xrow[0], xrow[1], xrow[2]};
 #pragma unroll
       for (int x = 0; x < VOX; ++x) {
         float3 pc;
         if (XLDS) {
-          const float4 xp = s_xprod[wave][x];  // same address in every lane: a broadcast read
+          const xrow_v3 xp = xpNext;  // same address in every lane: a broadcast read
+          if (x + 1 < VOX) xpNext = xrow_v3{xrow[4 * (x + 1)], xrow[4 * (x + 1) + 1], xrow[4 * (x + 1) + 2]};
           pc.x = xp.x + yx + zx + hM12 * 1.0f;
           pc.y = xp.y + yy + zy + hM13 * 1.0f;
           pc.z = xp.z + yz_ + zz + hM14 * 1.0f;
