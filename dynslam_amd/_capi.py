@@ -74,7 +74,8 @@ class Stats(C.Structure):
 
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("total_ms", C.c_double), ("launches", C.c_int64),
-                ("bytes", C.c_double), ("bytes_layout", C.c_double), ("units", C.c_double)]
+                ("bytes", C.c_double), ("bytes_layout", C.c_double), ("units", C.c_double),
+                ("store_lanes", C.c_double), ("colour_voxels", C.c_double)]
 
 
 assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8
@@ -104,6 +105,8 @@ SIGNATURES = {
     "get_view": (C.c_int, [_H, _P, _P]),
     "get_view_previews": (C.c_int, [_H, _P, _P]),
     "get_no_visible_blocks": (C.c_int, [_H, C.POINTER(C.c_int32)]),
+    "pin_host_buffer": (C.c_int, [_P, C.c_size_t]),
+    "unpin_host_buffer": (C.c_int, [_P]),
     "set_pose_inv_m": (C.c_int, [_H, _P]),
     "set_pose_m": (C.c_int, [_H, _P]),
     "get_pose": (C.c_int, [_H, _P, _P]),

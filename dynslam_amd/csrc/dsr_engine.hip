@@ -12,6 +12,7 @@
 
 #include <dlfcn.h>
 #include <sched.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -44,6 +45,16 @@ thread_local std::string g_err;
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
 std::atomic<int> g_enginesOnDevice[64];         // live engines per device (range-image overlap policy, allocate_scene)
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
+std::mutex g_pinMutex;
+std::map<uintptr_t, size_t> g_pinned;           // host ranges the caller page-locked through dsr_pin_host_buffer
+bool host_range_pinned(const void *p, size_t bytes) {
+  std::lock_guard<std::mutex> lock(g_pinMutex);
+  if (g_pinned.empty()) return false;
+  auto it = g_pinned.upper_bound((uintptr_t)p);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return (uintptr_t)p + bytes <= it->first + it->second;
+}
 std::mutex g_ioMutex;
 hipStream_t g_ioStream[64] = {};                // per GPU: uploads, previews and view read-backs of every engine on it
 
@@ -154,7 +165,9 @@ struct dsr_engine {
   // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
-  bool integrateXLds = false;  // k_integrate<..., XLDS>: the wave-uniform x terms through LDS (env DSR_INTEGRATE_XLDS)
+  // k_integrate<..., XLDS>: the wave-uniform x terms of the camera transform through LDS (k_integrate.h): 562 -> 540-545 us on the
+  // bench workload, bit-identical (profiles/r04b_integrate_xlds_ab.log).  env DSR_INTEGRATE_XLDS=0: the round-3 kernel.
+  bool integrateXLds = true;
   // a volume of instance size (7142 blocks in the reference, InstanceReconstructor.cpp:379): its frames are bound by the number
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
@@ -163,6 +176,7 @@ struct dsr_engine {
   // env DSR_RAYCAST_SPLIT overrides (tests: 0 = every ray goes through the tail kernel is NOT expressible — use 1).
   int raycastSplit = 0;
   int gridRaycastTail = 2048;   // env DSR_GRID_RAYCAST_TAIL
+  int raycastTailMode = 1;      // 1: one lane per ray, 8 probes per round; 4: ... 4 probes; 8: eight lanes per ray (env DSR_RAYCAST_TAIL_MODE)
   float4 *tailState = nullptr;
   int *tailPix = nullptr;
   uint32_t *tailCount = nullptr;
@@ -247,6 +261,20 @@ struct dsr_engine {
   // kernel reads; the status words are PUBLISHED by k_visible_write into a pinned, device-mapped word the host polls; previews
   // and view read-backs run on the I/O stream after the last kernel that wrote the view (evView) — none of them waits for
   // k_integrate or k_raycast.
+  // PIPELINED VIEW (engines with sync_status, i.e. driven by a host that waits for status words): everything that writes or
+  // modifies the view — ingest, SetView, the silhouette kernels — runs on the engine's VIEW stream, and the view is double
+  // buffered: a frame's view is built in the buffer fusion is not reading, so the next frame's view split (and with it the
+  // instance volumes' whole frames) proceeds while this volume's integration and raycast are still running.  Without it the
+  // view kernels of frame i + 1 queue behind the raycast of frame i on the one stream, and a host that waits for an instance's
+  // allocation status waits for the map's whole previous frame (configs[2] through the reference's call pattern).
+  bool pipelinedView = false;
+  hipStream_t viewStream = nullptr;
+  uchar4 *rgbAlt = nullptr;
+  float *depthAlt = nullptr;
+  hipEvent_t evAltFree = nullptr;      // recorded on the fusion stream when the buffers were swapped: readers of the old view are behind it
+  bool altFreeValid = false;
+  hipEvent_t evFusionRead = nullptr;   // the last fusion work that read the view ...
+  const float *fusionReadDepth = nullptr;  // ... and which buffer it read
   uint8_t *upPin[2] = {nullptr, nullptr};
   size_t upBytes = 0, upDepthOff = 0;
   hipEvent_t upSlotFree[2] = {nullptr, nullptr};
@@ -267,6 +295,14 @@ struct dsr_engine {
   uchar4 *xferRgb = nullptr;
   float *xferDepth = nullptr;
   bool sidePending = false;          // evExpected has been recorded and not been waited for by the main stream since
+  // Prepare (raycast + ICP maps) on the SIDE stream (round 4): the last third of a raycast launch runs on a few per cent of the
+  // waves (k_raycast.h), and what the next frame does first — view ingest, the frustum re-test of the visible list, the
+  // per-pixel allocation mark — only READS the scene: it runs on the engine's stream under that tail, and the first kernel that
+  // modifies anything the raycast reads (the allocation's scan / commit) waits for evRenderDone.  Same policy as the range image:
+  // volumes of at least 2^20 blocks that have the GPU to themselves.  env DSR_OVERLAP_PREPARE=0/1.
+  bool overlapPrepare = true;
+  hipEvent_t evPrepareGo = nullptr, evRenderDone = nullptr;
+  bool renderPending = false;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
   hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
@@ -297,6 +333,7 @@ hipEvent_t get_event(dsr_engine *e) {
 
 void prof_resolve(dsr_engine *e) {
   if (e->profPending.empty()) return;
+  if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
   (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
   if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
@@ -312,7 +349,7 @@ struct ProfScope {
   dsr_engine *e; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(dsr_engine *e_, const char *name) : e(e_) {
     if (!e->profiling) return;
-    if (e->profiling == 2 && strcmp(name, "integrate") != 0 && strcmp(name, "raycast") != 0) return;
+    if (e->profiling == 2 && strcmp(name, "integrate") != 0 && strcmp(name, "raycast") != 0 && strcmp(name, "raycast_tail") != 0) return;
     auto it = e->profIndex.find(name);
     if (it == e->profIndex.end()) {
       rec = (int)e->profRecs.size();
@@ -369,7 +406,10 @@ void depth_proj(const dsr_engine *e, float proj[4]) {
   proj[0] = e->calib.depth.fx; proj[1] = e->calib.depth.fy; proj[2] = e->calib.depth.cx; proj[3] = e->calib.depth.cy;
 }
 
+int wait_render(dsr_engine *e);
+
 int reset_scene(dsr_engine *e) {
+  { int st = wait_render(e); if (st) return st; }
   e->sceneVersion++;
   e->noVisibleValid = false;
   e->listVersion++;
@@ -418,6 +458,9 @@ void free_all(dsr_engine *e) {
     if (e->upSlotFree[k]) (void)hipEventDestroy(e->upSlotFree[k]);
   }
   F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth); F(e->tailState); F(e->tailPix); F(e->tailCount);
+  F(e->rgbAlt); F(e->depthAlt);
+  for (hipEvent_t ev : {e->evAltFree, e->evFusionRead}) if (ev) (void)hipEventDestroy(ev);
+  if (e->viewStream) (void)hipStreamDestroy(e->viewStream);
   if (e->pvPin) (void)hipHostFree(e->pvPin);
   if (e->statusHost) (void)hipHostFree(e->statusHost);
   for (hipEvent_t ev : {e->evUploaded, e->evIngested, e->evView, e->evViewRead}) if (ev) (void)hipEventDestroy(ev);
@@ -428,6 +471,8 @@ void free_all(dsr_engine *e) {
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->evList) (void)hipEventDestroy(e->evList);
   if (e->evExpected) (void)hipEventDestroy(e->evExpected);
+  if (e->evPrepareGo) (void)hipEventDestroy(e->evPrepareGo);
+  if (e->evRenderDone) (void)hipEventDestroy(e->evRenderDone);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream) (void)hipStreamDestroy(e->stream);
 }
@@ -510,11 +555,72 @@ int io_read_done(dsr_engine *e, hipStream_t io) {
   return DSR_OK;
 }
 
+// ---- the pipelined view (see dsr_engine): which stream a view operation of `e` runs on, and the hand-over of buffers
+hipStream_t vstream(dsr_engine *e) { return e->pipelinedView ? e->viewStream : e->stream; }
+
+struct ViewTarget { uchar4 *rgb; float *depth; };
+
+// `ws` is about to REPLACE e's whole view (ingest, SetView, a cut-out from another engine's view): -> the buffers to write
+int begin_view_replace(dsr_engine *e, hipStream_t ws, ViewTarget *t) {
+  int st = before_view_write(e, ws);  // readers on the I/O stream
+  if (st) return st;
+  if (!e->pipelinedView) { t->rgb = e->rgb; t->depth = e->depth; return DSR_OK; }
+  if (!e->rgbAlt) {
+    if ((st = dmalloc(&e->rgbAlt, (size_t)e->Wr * e->Hr)) || (st = dmalloc(&e->depthAlt, (size_t)e->P))) return st;
+    if ((st = make_event(&e->evAltFree)) || (st = make_event(&e->evFusionRead))) return st;
+  }
+  if (e->altFreeValid) HIP_TRY(hipStreamWaitEvent(ws, e->evAltFree, 0));  // fusion work that read this buffer when it was current
+  if (ws != e->viewStream && e->viewEventValid) HIP_TRY(hipStreamWaitEvent(ws, e->evView, 0));  // a writer on another stream before us
+  t->rgb = e->rgbAlt; t->depth = e->depthAlt;
+  return DSR_OK;
+}
+// ... has queued its writes: the new view becomes current
+int end_view_replace(dsr_engine *e, hipStream_t ws, bool recordView = true) {
+  if (e->pipelinedView) {
+    std::swap(e->rgb, e->rgbAlt);
+    std::swap(e->depth, e->depthAlt);
+    // whatever reads the old view (now the spare buffer) has been queued on the fusion stream by now
+    HIP_TRY(hipEventRecord(e->evAltFree, e->stream));
+    e->altFreeValid = true;
+  }
+  return recordView ? view_written(e, ws) : DSR_OK;
+}
+// an in-place modification of the CURRENT view on e's view stream (blanking a silhouette): after the fusion that read this buffer
+int begin_view_modify(dsr_engine *e) {
+  hipStream_t ws = vstream(e);
+  int st = before_view_write(e, ws);
+  if (st) return st;
+  if (e->pipelinedView && e->fusionReadDepth == e->depth) HIP_TRY(hipStreamWaitEvent(ws, e->evFusionRead, 0));
+  return DSR_OK;
+}
+// fusion (allocation, integration, anything on the engine's stream that READS the view) starts / has been queued
+int before_fusion(dsr_engine *e) {
+  if (e->pipelinedView && e->viewEventValid) HIP_TRY(hipStreamWaitEvent(e->stream, e->evView, 0));
+  return DSR_OK;
+}
+int after_fusion(dsr_engine *e) {
+  if (e->pipelinedView && e->evFusionRead) {
+    HIP_TRY(hipEventRecord(e->evFusionRead, e->stream));
+    e->fusionReadDepth = e->depth;
+  }
+  return DSR_OK;
+}
+
+// the engine's stream is about to touch what a Prepare on the side stream reads or writes (table, voxels, range image, raycast
+// result, ICP maps, the tail list of the split raycast): behind it
+int wait_render(dsr_engine *e) {
+  if (e->renderPending) {
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->evRenderDone, 0));
+    e->renderPending = false;
+  }
+  return DSR_OK;
+}
+
 // A frame handed over as host buffers: copied into a pinned slot (the caller's buffers are free on return), uploaded on the
 // I/O stream into the landing buffer; the engine's stream waits for the upload, not the host.  -> device addresses of the two
 // parts.  The caller enqueues its ingest kernel on e->stream and then calls upload_consumed().
-int upload_frame(dsr_engine *e, const void *colour, size_t cBytes, const void *depth, size_t dBytes, const uint8_t **cDev,
-                 const uint8_t **dDev) {
+int upload_frame(dsr_engine *e, hipStream_t consumer, const void *colour, size_t cBytes, const void *depth, size_t dBytes,
+                 const uint8_t **cDev, const uint8_t **dDev) {
   hipStream_t io = nullptr;
   int st = io_stream(e, &io);
   if (st) return st;
@@ -536,55 +642,65 @@ int upload_frame(dsr_engine *e, const void *colour, size_t cBytes, const void *d
   memcpy(e->upPin[s], colour, cBytes);
   memcpy(e->upPin[s] + e->upDepthOff, depth, dBytes);
   if (e->ingestPending) HIP_TRY(hipStreamWaitEvent(io, e->evIngested, 0));  // the previous ingest kernel reads the landing buffer
+  // (the frame is staged even when the caller's buffers are page-locked: "free on return" is part of the contract, and a copy
+  //  straight out of the caller's buffer would still be reading it after the call)
   HIP_TRY(hipMemcpyAsync(e->upDev, e->upPin[s], cBytes, hipMemcpyHostToDevice, io));
   HIP_TRY(hipMemcpyAsync(e->upDev + e->upDepthOff, e->upPin[s] + e->upDepthOff, dBytes, hipMemcpyHostToDevice, io));
   HIP_TRY(hipEventRecord(e->upSlotFree[s], io));
   e->upSlotUsed[s] = true;
   HIP_TRY(hipEventRecord(e->evUploaded, io));
-  HIP_TRY(hipStreamWaitEvent(e->stream, e->evUploaded, 0));
+  HIP_TRY(hipStreamWaitEvent(consumer, e->evUploaded, 0));
   *cDev = e->upDev;
   *dDev = e->upDev + e->upDepthOff;
   return DSR_OK;
 }
-int upload_consumed(dsr_engine *e) {
-  HIP_TRY(hipEventRecord(e->evIngested, e->stream));
+int upload_consumed(dsr_engine *e, hipStream_t consumer) {
+  HIP_TRY(hipEventRecord(e->evIngested, consumer));
   e->ingestPending = true;
   return DSR_OK;
 }
 
-// ITMViewBuilder::UpdateView's optional bilateral passes on a view whose float depth is already in e->depth
-int filter_view(dsr_engine *e) {
+// ITMViewBuilder::UpdateView's optional bilateral passes on a view whose float depth is already in `depth` (on e->stream as the
+// caller has set it)
+int filter_view(dsr_engine *e, float *depth) {
   if (!e->s.use_bilateral_filter) return DSR_OK;
-  HIP_TRY(hipMemcpyAsync(e->depthTmp, e->depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->depthTmp, depth, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
   for (int k = 0; k < 5; ++k) {
-    if (k & 1) LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depthTmp, e->depth, e->W, e->H);
-    else LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depth, e->depthTmp, e->W, e->H);
+    if (k & 1) LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)e->depthTmp, depth, e->W, e->H);
+    else LAUNCH(e, "filter_depth", k_filter_depth, g, dim3(256), (const float *)depth, e->depthTmp, e->W, e->H);
   }
-  HIP_TRY(hipMemcpyAsync(e->depth, e->depthTmp, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(depth, e->depthTmp, (size_t)e->P * 4, hipMemcpyDeviceToDevice, e->stream));
   return DSR_OK;
 }
 
-// rgbDev/depthDev != null: device-resident inputs, ingested by one fused kernel
-int convert_view(dsr_engine *e, const void *rgbDev = nullptr, const void *depthDev = nullptr) {
+// UpdateView from device-resident RGBA + int16 mm (the caller's HBM buffers, or the landing buffer of an upload): one fused
+// ingest kernel when both are 16-byte aligned.  Runs on the view stream; `uploaded`: the inputs are the landing buffer.
+int convert_view(dsr_engine *e, const void *rgbDev, const void *depthDev, bool uploaded = false) {
   const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
   const size_t rgbBytes = (size_t)e->Wr * e->Hr * 4;
-  { int st = before_view_write(e, e->stream); if (st) return st; }
-  if (rgbDev && depthDev && ((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0) {
-    const int nRgbVec = (int)(rgbBytes / 16), nQuads = div_up(e->P, 4);
-    LAUNCH(e, "view_ingest", k_view_ingest, dim3(div_up(std::max(nRgbVec, nQuads), 256)), dim3(256), (const uint4 *)rgbDev,
-           reinterpret_cast<uint4 *>(e->rgb), nRgbVec, e->Wr * e->Hr, (const short *)depthDev, e->depth, e->P, a, b);
-  } else {
-    if (rgbDev) {
-      HIP_TRY(hipMemcpyAsync(e->rgb, rgbDev, rgbBytes, hipMemcpyDeviceToDevice, e->stream));
-      HIP_TRY(hipMemcpyAsync(e->rawDepth, depthDev, (size_t)e->P * 2, hipMemcpyDeviceToDevice, e->stream));
+  hipStream_t ws = vstream(e);
+  ViewTarget t;
+  int st = begin_view_replace(e, ws, &t);
+  if (st) return st;
+  {
+    StreamSwap sw(e, ws);
+    if (((uintptr_t)rgbDev & 15) == 0 && ((uintptr_t)depthDev & 15) == 0) {
+      const int nRgbVec = (int)(rgbBytes / 16), nQuads = div_up(e->P, 4);
+      LAUNCH(e, "view_ingest", k_view_ingest, dim3(div_up(std::max(nRgbVec, nQuads), 256)), dim3(256), (const uint4 *)rgbDev,
+             reinterpret_cast<uint4 *>(t.rgb), nRgbVec, e->Wr * e->Hr, (const short *)depthDev, t.depth, e->P, a, b);
+    } else {
+      HIP_TRY(hipMemcpyAsync(t.rgb, rgbDev, rgbBytes, hipMemcpyDeviceToDevice, ws));
+      HIP_TRY(hipMemcpyAsync(e->rawDepth, depthDev, (size_t)e->P * 2, hipMemcpyDeviceToDevice, ws));
+      LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, t.depth,
+             e->P, a, b);
     }
-    LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), e->rawDepth, e->depth,
-           e->P, a, b);
+    HIP_TRY(hipGetLastError());
+    if (uploaded && (st = upload_consumed(e, ws))) return st;
+    // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
+    if ((st = filter_view(e, t.depth))) return st;
   }
-  // ITMViewBuilder::UpdateView: five ping-pong passes, result copied back into view->depth
-  { int st = filter_view(e); if (st) return st; }
-  return view_written(e, e->stream);
+  return end_view_replace(e, ws);
 }
 
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
@@ -597,6 +713,7 @@ int allocate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   RenderStateDev &rs = e->live;
+  { int st = before_fusion(e); if (st) return st; }
   // a range image of the PREVIOUS list may still be running on the side stream (back-to-back fusion calls without a Prepare in
   // between): it reads the list and the count this call rewrites
   if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
@@ -604,6 +721,8 @@ int allocate_scene(dsr_engine *e) {
          (const int4 *)rs.visBlocks, rs.visType);
   LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
          (const float *)e->depth, rs.visType);
+  // (up to here the frame has only READ the scene and written allocation scratch: it may run under the previous frame's raycast)
+  { int st = wait_render(e); if (st) return st; }
   int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
   LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, allocTile, e->allocWork);
@@ -618,6 +737,7 @@ int allocate_scene(dsr_engine *e) {
          (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks, e->statusDev,
          e->statusSeq);
   HIP_TRY(hipGetLastError());
+  { int st = after_fusion(e); if (st) return st; }
   e->liveExp.valid = false;
   // ... when this volume has the GPU to itself: with other volumes' engines on the device (a map + its instance volumes)
   // their streams fill the phases the side stream would, and the extra stream only costs (configs[2]: 733 vs 686 frames/s)
@@ -643,6 +763,8 @@ int integrate_scene(dsr_engine *e) {
   float proj[4]; depth_proj(e, proj);
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
+  { int st = before_fusion(e); if (st) return st; }
+  { int st = wait_render(e); if (st) return st; }
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
   do {                                                                                                       \
     if (e->integrateXLds)                                                                                    \
@@ -661,7 +783,7 @@ int integrate_scene(dsr_engine *e) {
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
-  return DSR_OK;
+  return after_fusion(e);
 }
 
 int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
@@ -705,11 +827,17 @@ int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderState
     }
     uint32_t *cur = e->tailCount + (e->raycastLaunches & 1), *next = e->tailCount + ((e->raycastLaunches + 1) & 1);
     e->raycastLaunches++;
-    ProfScope _ps(e, name);  // one record for the pair: the frame's raycast
-    hipLaunchKernelGGL(k_raycast, g, dim3(256), 0, e->stream, p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult,
-                       e->raycastSplit, e->tailState, e->tailPix, cur);
-    hipLaunchKernelGGL(k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), 0, e->stream, p, e->scene, (const float2 *)rs.minmax,
-                       rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
+    LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult,
+           e->raycastSplit, e->tailState, e->tailPix, cur);
+    if (e->raycastTailMode == 8)
+      LAUNCH(e, "raycast_tail", k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
+             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
+    else if (e->raycastTailMode == 4)
+      LAUNCH(e, "raycast_tail", (k_raycast_tail_lanes<4>), dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
+             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
+    else
+      LAUNCH(e, "raycast_tail", (k_raycast_tail_lanes<8>), dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
+             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
     return DSR_OK;
   }
   LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, 0,
@@ -883,6 +1011,13 @@ RcclApi *rccl_api() {
   });
   return &api;
 }
+// RCCL prints a version banner on STDOUT when a process's first communicator comes up; a host that reports on stdout (a bench
+// line, DynSLAM's own logs piped to a tool) must not find it there: fd 1 points at stderr while the communicator is created.
+struct StdoutToStderr {
+  int saved = -1;
+  StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+  ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); dup2(saved, 1); close(saved); } }
+};
 #define RCCL_TRY(api, expr)                                                                              \
   do {                                                                                                   \
     ncclResult_t _r = (expr);                                                                            \
@@ -1078,6 +1213,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *et = getenv("DSR_EXPECTED_THREADS")) e->threadsExpected = std::min(1024, std::max(64, (atoi(et) / 64) * 64));
   if (const char *rs = getenv("DSR_RAYCAST_SPLIT")) e->raycastSplit = std::max(0, atoi(rs));
   if (const char *gt = getenv("DSR_GRID_RAYCAST_TAIL")) e->gridRaycastTail = std::max(1, atoi(gt));
+  if (const char *tm = getenv("DSR_RAYCAST_TAIL_MODE")) e->raycastTailMode = atoi(tm);
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
@@ -1102,7 +1238,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (e->overlapExpected &&
       (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
        hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
+       hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evPrepareGo, hipEventDisableTiming) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evRenderDone, hipEventDisableTiming) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
+  if (const char *op = getenv("DSR_OVERLAP_PREPARE")) e->overlapPrepare = atoi(op) != 0;
   ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
   ALLOC(dmalloc(&e->scene.voxelAllocList, (size_t)e->noBlocks));
@@ -1154,6 +1293,11 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (const char *sb = getenv("DSR_SLAB_BLOCKS")) e->scene.slabBlocks = std::max(1, atoi(sb));  // tests: force slab growth
     ALLOC(add_host_slab(e));  // the first slab, so that the first frames never wait for one
   }
+  e->pipelinedView = s.sync_status != 0;  // a host that waits for status words: see dsr_engine
+  if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
+  if (e->pipelinedView && hipStreamCreateWithFlags(&e->viewStream, hipStreamNonBlocking) != hipSuccess) {
+    free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
+  }
   if (s.sync_status) {
     // the published status word (k_visible_write): pinned, device-mapped, coherent — a handful of bytes
     if (hipHostMalloc(reinterpret_cast<void **>(&e->statusHost), 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -1184,8 +1328,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
 void dsr_engine_destroy(dsr_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
+  if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
   if (e->device < 64) g_enginesOnDevice[e->device].fetch_sub(1);
   free_all(e);
   delete e;
@@ -1198,6 +1344,7 @@ int dsr_reset_scene(dsr_engine *e) {
 
 int dsr_sync(dsr_engine *e) {
   CHECK_E(e);
+  if (e->viewStream) HIP_TRY(hipStreamSynchronize(e->viewStream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->sideStream) HIP_TRY(hipStreamSynchronize(e->sideStream));
   return DSR_OK;
@@ -1239,6 +1386,7 @@ int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
   if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
+  if (e->pipelinedView) HIP_TRY(hipStreamWaitEvent(e->viewStream, e->orderEvent, 0));  // "_dev" view inputs are read there
   return DSR_OK;
 }
 
@@ -1247,6 +1395,8 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
   if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(e->orderEvent, e->stream));
   HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->orderEvent, 0));
+  if (e->pipelinedView && e->viewEventValid) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evView, 0));
+  if (e->renderPending) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evRenderDone, 0));
   return DSR_OK;
 }
 
@@ -1256,31 +1406,34 @@ int dsr_update_view(dsr_engine *e, const uint8_t *rgba, const int16_t *depth_mm)
   CHECK_E(e);
   if (!rgba || !depth_mm) return fail(DSR_E_ARG, "null image");
   const uint8_t *cDev = nullptr, *dDev = nullptr;
-  int st = upload_frame(e, rgba, (size_t)e->Wr * e->Hr * 4, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
+  int st = upload_frame(e, vstream(e), rgba, (size_t)e->Wr * e->Hr * 4, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
   if (st) return st;
-  if ((st = convert_view(e, cDev, dDev))) return st;  // the landing buffer's two parts are 256-byte aligned
-  return upload_consumed(e);
+  return convert_view(e, cDev, dDev, true);  // the landing buffer's two parts are 256-byte aligned
 }
 
 int dsr_update_view_bgr(dsr_engine *e, const uint8_t *bgr, const int16_t *depth_mm) {
   CHECK_E(e);
   if (!bgr || !depth_mm) return fail(DSR_E_ARG, "null image");
   const uint8_t *cDev = nullptr, *dDev = nullptr;
-  int st = upload_frame(e, bgr, (size_t)e->Wr * e->Hr * 3, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
+  hipStream_t ws = vstream(e);
+  int st = upload_frame(e, ws, bgr, (size_t)e->Wr * e->Hr * 3, depth_mm, (size_t)e->P * 2, &cDev, &dDev);
   if (st) return st;
-  if ((st = before_view_write(e, e->stream))) return st;
+  ViewTarget t;
+  if ((st = begin_view_replace(e, ws, &t))) return st;
   const float a = e->calib.disparity_calib[0], b = e->calib.disparity_calib[1];
-  if (e->Wr * e->Hr == e->P) {
-    LAUNCH(e, "view_ingest", k_view_ingest_bgr, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const uint32_t *)cDev,
-           reinterpret_cast<uint4 *>(e->rgb), e->P, (const short *)dDev, e->depth, a, b);
-  } else {
-    LAUNCH(e, "view_ingest", k_bgr_to_rgba, dim3(div_up(e->Wr * e->Hr, 256)), dim3(256), cDev, e->rgb, e->Wr * e->Hr);
-    LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const short *)dDev, e->depth, e->P, a, b);
+  {
+    StreamSwap sw(e, ws);
+    if (e->Wr * e->Hr == e->P) {
+      LAUNCH(e, "view_ingest", k_view_ingest_bgr, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const uint32_t *)cDev,
+             reinterpret_cast<uint4 *>(t.rgb), e->P, (const short *)dDev, t.depth, a, b);
+    } else {
+      LAUNCH(e, "view_ingest", k_bgr_to_rgba, dim3(div_up(e->Wr * e->Hr, 256)), dim3(256), cDev, t.rgb, e->Wr * e->Hr);
+      LAUNCH(e, "depth_to_float", k_depth_to_float, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const short *)dDev, t.depth, e->P, a, b);
+    }
+    HIP_TRY(hipGetLastError());
+    if ((st = upload_consumed(e, ws)) || (st = filter_view(e, t.depth))) return st;
   }
-  HIP_TRY(hipGetLastError());
-  if ((st = filter_view(e))) return st;
-  if ((st = view_written(e, e->stream))) return st;
-  return upload_consumed(e);
+  return end_view_replace(e, ws);
 }
 
 int dsr_update_view_dev(dsr_engine *e, const void *rgba_dev, const void *depth_mm_dev) {
@@ -1293,29 +1446,59 @@ int dsr_set_view_float(dsr_engine *e, const uint8_t *rgba, const float *depth_m)
   CHECK_E(e);
   if (!rgba || !depth_m) return fail(DSR_E_ARG, "null image");
   const uint8_t *cDev = nullptr, *dDev = nullptr;
-  int st = upload_frame(e, rgba, (size_t)e->Wr * e->Hr * 4, depth_m, (size_t)e->P * 4, &cDev, &dDev);
+  hipStream_t ws = vstream(e);
+  int st = upload_frame(e, ws, rgba, (size_t)e->Wr * e->Hr * 4, depth_m, (size_t)e->P * 4, &cDev, &dDev);
   if (st) return st;
-  if ((st = before_view_write(e, e->stream))) return st;
-  LAUNCH(e, "set_view", k_set_view_ingest, dim3(div_up(std::max(e->Wr * e->Hr, e->P), 256)), dim3(256), (const uchar4 *)cDev, e->rgb,
-         e->Wr * e->Hr, (const float *)dDev, e->depth, e->P);
-  HIP_TRY(hipGetLastError());
-  if ((st = view_written(e, e->stream))) return st;
-  return upload_consumed(e);
+  ViewTarget t;
+  if ((st = begin_view_replace(e, ws, &t))) return st;
+  {
+    StreamSwap sw(e, ws);
+    LAUNCH(e, "set_view", k_set_view_ingest, dim3(div_up(std::max(e->Wr * e->Hr, e->P), 256)), dim3(256), (const uchar4 *)cDev, t.rgb,
+           e->Wr * e->Hr, (const float *)dDev, t.depth, e->P);
+    HIP_TRY(hipGetLastError());
+    if ((st = upload_consumed(e, ws))) return st;
+  }
+  return end_view_replace(e, ws);
 }
 
 int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *depth_m_dev) {
   CHECK_E(e);
   if (!rgba_dev || !depth_m_dev) return fail(DSR_E_ARG, "null image");
-  int st = before_view_write(e, e->stream);
+  hipStream_t ws = vstream(e);
+  ViewTarget t;
+  int st = begin_view_replace(e, ws, &t);
   if (st) return st;
-  HIP_TRY(hipMemcpyAsync(e->rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, e->stream));
-  LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)depth_m_dev, e->depth, e->P);
-  HIP_TRY(hipGetLastError());
-  return view_written(e, e->stream);
+  {
+    StreamSwap sw(e, ws);
+    HIP_TRY(hipMemcpyAsync(t.rgb, rgba_dev, (size_t)e->Wr * e->Hr * 4, hipMemcpyDeviceToDevice, ws));
+    LAUNCH(e, "set_view", k_copy_depth_finite, dim3(div_up(e->P, 256)), dim3(256), (const float *)depth_m_dev, t.depth, e->P);
+    HIP_TRY(hipGetLastError());
+  }
+  return end_view_replace(e, ws);
 }
 
 // view->rgb / view->depth ->UpdateHostFromDevice(): on the I/O stream, after the last kernel that wrote the view — not after
 // the fusion and the raycast that may be queued behind it on the engine's stream
+int dsr_pin_host_buffer(void *ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(DSR_E_ARG, "null buffer");
+  if (host_range_pinned(ptr, bytes)) return DSR_OK;
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  std::lock_guard<std::mutex> lock(g_pinMutex);
+  g_pinned[(uintptr_t)ptr] = bytes;
+  return DSR_OK;
+}
+int dsr_unpin_host_buffer(void *ptr) {
+  if (!ptr) return fail(DSR_E_ARG, "null buffer");
+  {
+    std::lock_guard<std::mutex> lock(g_pinMutex);
+    auto it = g_pinned.find((uintptr_t)ptr);
+    if (it == g_pinned.end()) return fail(DSR_E_ARG, "not a buffer pinned through dsr_pin_host_buffer");
+    g_pinned.erase(it);
+  }
+  HIP_TRY(hipHostUnregister(ptr));
+  return DSR_OK;
+}
+
 int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out) {
   CHECK_E(e);
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
@@ -1421,15 +1604,32 @@ int dsr_prepare(dsr_engine *e) {
   } else {
     // a stale one may still be writing the image — whether or not it is still marked valid
     if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
+    { int st = wait_render(e); if (st) return st; }  // a previous Prepare on the side stream reads the image this one rewrites
     e->liveExp.valid = false;
     int st = expected_depths(e, rs, p);
     if (st) return st;
   }
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  launch_raycast(e, "raycast", p, rs);
-  LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
-         e->normalsMap, rs.raycastImage);
+  const bool onSide = e->overlapPrepare && e->sideStream && e->evRenderDone &&
+                      (e->device >= 64 || g_enginesOnDevice[e->device].load(std::memory_order_relaxed) <= 1);
+  if (onSide) {
+    // raycast + ICP maps on the side stream, behind everything queued on the engine's stream so far (the integration); the
+    // engine's stream goes on with the next frame's read-only prefix and waits at its first write (wait_render)
+    HIP_TRY(hipEventRecord(e->evPrepareGo, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->sideStream, e->evPrepareGo, 0));
+  }
+  {
+    StreamSwap sw(e, onSide ? e->sideStream : e->stream);
+    int st = launch_raycast(e, "raycast", p, rs);
+    if (st) return st;
+    LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+           e->normalsMap, rs.raycastImage);
+  }
   HIP_TRY(hipGetLastError());
+  if (onSide) {
+    HIP_TRY(hipEventRecord(e->evRenderDone, e->sideStream));
+    e->renderPending = true;
+  }
   return DSR_OK;
 }
 
@@ -1440,6 +1640,7 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   e->noVisibleValid = false;
   e->listVersion++;
   if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
+  { int st = wait_render(e); if (st) return st; }
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -1503,11 +1704,17 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
 static int render_common(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out,
                          void *depth_out, bool outIsDevice) {
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  { int st = wait_render(e); if (st) return st; }
   const hipMemcpyKind kind = outIsDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   const size_t P = (size_t)e->P;
   switch (type) {
     case DSR_IMAGE_ORIGINAL_RGB:
-      if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, P * 4, kind, e->stream));
+      if (rgba_out) {
+        int st = before_fusion(e);
+        if (st) return st;
+        HIP_TRY(hipMemcpyAsync(rgba_out, e->rgb, P * 4, kind, e->stream));
+        if ((st = after_fusion(e))) return st;
+      }
       break;
     case DSR_IMAGE_SCENERAYCAST:
       if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, e->live.raycastImage, P * 4, kind, e->stream));
@@ -1801,7 +2008,7 @@ int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *he
 static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h, const uint8_t **devOut, int *slotOut) {
   const size_t n = (size_t)box_w * box_h;
   if (e->maskSlotBytes < n) {  // grow: rare (a mask larger than any before) — drain, then reallocate the ring
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(vstream(e)));
     if (e->maskHost) (void)hipHostFree(e->maskHost);
     e->maskHost = e->maskHostDev = nullptr; e->maskSlotBytes = 0;
     const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
@@ -1822,7 +2029,7 @@ static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h,
   return DSR_OK;
 }
 static int mask_slot_used(dsr_engine *e, int slot) {
-  HIP_TRY(hipEventRecord(e->maskEvent[slot], e->stream));
+  HIP_TRY(hipEventRecord(e->maskEvent[slot], vstream(e)));
   e->maskEventUsed[slot] = true;
   return DSR_OK;
 }
@@ -1867,19 +2074,23 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   dsr_engine *e = main_engine;
   static const bool forcePeerPath = getenv("DSR_FORCE_PEER_PATH") != nullptr;  // tests: the cross-GPU path on one GPU
   const bool peer = instance->device != e->device || forcePeerPath;
-  // runs on the MAIN engine's stream (ordered after the view's producer and before any later
-  // blanking); the instance stream then waits for it.  The kernel OVERWRITES the instance's view,
-  // which work already queued on the instance's stream (the previous frame's integrate, a set_view
-  // copy) may still be reading: the main stream first waits for that work.
-  // (an event is created and recorded with its own stream's device current; WAITING for it works from any device)
-  if (peer) HIP_TRY(hipSetDevice(instance->device));
-  if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(instance->xEvent, instance->stream));
-  if (peer) HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipStreamWaitEvent(e->stream, instance->xEvent, 0));
-  { int st = before_view_write(instance, e->stream); if (st) return st; }
-  uchar4 *dstRgb = instance->rgb;
-  float *dstDepth = instance->depth;
+  // Runs on the MAIN engine's view stream: ordered after the producer of its view and before any later blanking.  The kernel
+  // REPLACES the instance's view: a pipelined instance takes it in its spare buffer (begin_view_replace: only the fusion that
+  // last read that buffer is waited for); otherwise work queued on the instance's stream (the previous frame's integration) may
+  // still be reading the one buffer, and the main side first waits for all of it.
+  hipStream_t ws = vstream(e);
+  if (!instance->pipelinedView) {
+    // (an event is created and recorded with its own stream's device current; WAITING for it works from any device)
+    if (peer) HIP_TRY(hipSetDevice(instance->device));
+    if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(instance->xEvent, instance->stream));
+    if (peer) HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamWaitEvent(ws, instance->xEvent, 0));
+  }
+  ViewTarget t;
+  { int st = begin_view_replace(instance, ws, &t); if (st) return st; }
+  uchar4 *dstRgb = t.rgb;
+  float *dstDepth = t.depth;
   if (peer) {
     if (!e->xferRgb) {
       int st = dmalloc(&e->xferRgb, (size_t)e->P);
@@ -1889,20 +2100,30 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     enable_peer_access(instance->device, e->device);
     dstRgb = e->xferRgb; dstDepth = e->xferDepth;
   }
-  LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
-         (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
-         maskDev, x0, y0, box_w, box_h);
+  {
+    StreamSwap sw(e, ws);
+    LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
+           (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
+           maskDev, x0, y0, box_w, box_h);
+  }
   HIP_TRY(hipGetLastError());
   if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
   if (peer) {
-    HIP_TRY(hipMemcpyPeerAsync(instance->rgb, instance->device, e->xferRgb, e->device, (size_t)e->P * 4, e->stream));
-    HIP_TRY(hipMemcpyPeerAsync(instance->depth, instance->device, e->xferDepth, e->device, (size_t)e->P * 4, e->stream));
+    HIP_TRY(hipMemcpyPeerAsync(t.rgb, instance->device, e->xferRgb, e->device, (size_t)e->P * 4, ws));
+    HIP_TRY(hipMemcpyPeerAsync(t.depth, instance->device, e->xferDepth, e->device, (size_t)e->P * 4, ws));
   }
+  // the instance's side: its "view written" event is recorded on a stream of ITS device (its view stream / its only stream),
+  // behind a wait for the main side — so every event is only ever recorded with its own device's streams
   if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(e->xEvent2, e->stream));
+  HIP_TRY(hipEventRecord(e->xEvent2, ws));
   if (peer) HIP_TRY(hipSetDevice(instance->device));
-  HIP_TRY(hipStreamWaitEvent(instance->stream, e->xEvent2, 0));
-  const int stv = view_written(instance, instance->stream);  // the instance's view is final once its stream has passed this point
+  int stv = DSR_OK;
+  {
+    hipStream_t is = vstream(instance);
+    const hipError_t werr = hipStreamWaitEvent(is, e->xEvent2, 0);
+    if (werr != hipSuccess) stv = fail(DSR_E_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(werr));
+    else stv = end_view_replace(instance, is);  // buffers swapped; the instance's view is final once `is` has passed this point
+  }
   if (peer) HIP_TRY(hipSetDevice(e->device));
   return stv;
 }
@@ -1927,12 +2148,15 @@ static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *
     int st = upload_mask(e, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
   }
-  { int st = before_view_write(e, e->stream); if (st) return st; }
-  LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
-         e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
+  { int st = begin_view_modify(e); if (st) return st; }
+  {
+    StreamSwap sw(e, vstream(e));
+    LAUNCH(e, "remove_silhouette", k_remove_silhouette, dim3(div_up(box_w, 16), div_up(box_h, 16)), dim3(256), e->rgb,
+           e->depth, e->W, e->H, maskDev, x0, y0, box_w, box_h);
+  }
   HIP_TRY(hipGetLastError());
   if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
-  return view_written(e, e->stream);
+  return view_written(e, vstream(e));
 }
 int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y0, int box_w, int box_h) {
   return remove_silhouette(e, mask, nullptr, x0, y0, box_w, box_h);
@@ -2051,7 +2275,8 @@ int dsr_exchange_create(const int32_t *devices, int n_ranks, int slots_per_rank,
     else {
       std::vector<int> devlist; std::vector<ncclComm_t> comms(x->devs.size());
       for (auto &d : x->devs) devlist.push_back(d.device);
-      const ncclResult_t r = api->CommInitAll(comms.data(), (int)devlist.size(), devlist.data());
+      ncclResult_t r;
+      { StdoutToStderr quiet; r = api->CommInitAll(comms.data(), (int)devlist.size(), devlist.data()); }
       if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
       else { for (size_t k = 0; k < comms.size(); ++k) x->devs[k].comm = comms[k]; x->useRccl = true; }
     }
@@ -2096,7 +2321,8 @@ int dsr_exchange_create_rank(const uint8_t unique_id[128], int world_size, int r
   if (st == DSR_OK) {
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    const ncclResult_t r = (hipSetDevice(device) == hipSuccess) ? api->CommInitRank(&x->devs[0].comm, world_size, id, rank) : ncclUnhandledCudaError;
+    ncclResult_t r;
+    { StdoutToStderr quiet; r = (hipSetDevice(device) == hipSuccess) ? api->CommInitRank(&x->devs[0].comm, world_size, id, rank) : ncclUnhandledCudaError; }
     if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
     else x->useRccl = true;
   }
@@ -2255,6 +2481,7 @@ int dsr_exchange_sync(dsr_exchange *x) {
 
 int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored) {
   CHECK_E(e);
+  { int st = wait_render(e); if (st) return st; }
   if (!e->scene.swapState) return fail(DSR_E_ARG, "swapping is not enabled");
   if (states) HIP_TRY(hipMemcpyAsync(states, e->scene.swapState, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
   if (has_stored) HIP_TRY(hipMemcpyAsync(has_stored, e->scene.swapStored, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
@@ -2301,7 +2528,7 @@ int dsr_mesh_free(dsr_engine *e) {
 int dsr_mesh_scene(dsr_engine *e, uint64_t *n_triangles) {
   CHECK_E(e);
   int st = dsr_mesh_free(e);
-  if (st) return st;
+  if (st || (st = wait_render(e))) return st;
   // ascending list of the allocated entries (shared with Decay(forceAllVoxels))
   LAUNCH(e, "mesh_candidates", k_allocated_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_NCAND, e->noBlocks);
@@ -2589,28 +2816,33 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
       return fail(DSR_E_NOMEM, "pinned preview staging allocation failed");
   }
   if ((st = io_reads_view(e, io))) return st;
+  // buffers the caller page-locked (dsr_pin_host_buffer) take the copy directly: no staging copy on the host
+  const bool bgrPinned = bgr_out && host_range_pinned(bgr_out, (size_t)e->P * 3);
+  const bool mmPinned = depth_mm_out && host_range_pinned(depth_mm_out, (size_t)e->P * 2);
   {
     StreamSwap sw(e, io);
     if (bgr_out) {
       LAUNCH(e, "preview_convert", k_rgba_to_bgr, dim3(div_up(e->P, 256)), dim3(256), (const uchar4 *)e->rgb, e->pvDev, e->P);
-      HIP_TRY(hipMemcpyAsync(e->pvPin, e->pvDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, io));
+      HIP_TRY(hipMemcpyAsync(bgrPinned ? bgr_out : e->pvPin, e->pvDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, io));
     }
     if (depth_mm_out) {
       LAUNCH(e, "preview_convert", k_depth_m_to_mm, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depth,
              reinterpret_cast<short *>(e->pvDev + e->pvMmOff), e->P);
-      HIP_TRY(hipMemcpyAsync(e->pvPin + e->pvMmOff, e->pvDev + e->pvMmOff, (size_t)e->P * 2, hipMemcpyDeviceToHost, io));
+      HIP_TRY(hipMemcpyAsync(mmPinned ? (uint8_t *)depth_mm_out : e->pvPin + e->pvMmOff, e->pvDev + e->pvMmOff, (size_t)e->P * 2,
+                             hipMemcpyDeviceToHost, io));
     }
   }
   HIP_TRY(hipGetLastError());
   if ((st = io_read_done(e, io))) return st;
   HIP_TRY(hipEventSynchronize(e->evViewRead));
-  if (bgr_out) memcpy(bgr_out, e->pvPin, (size_t)e->P * 3);
-  if (depth_mm_out) memcpy(depth_mm_out, e->pvPin + e->pvMmOff, (size_t)e->P * 2);
+  if (bgr_out && !bgrPinned) memcpy(bgr_out, e->pvPin, (size_t)e->P * 3);
+  if (depth_mm_out && !mmPinned) memcpy(depth_mm_out, e->pvPin + e->pvMmOff, (size_t)e->P * 2);
   return DSR_OK;
 }
 
 int dsr_dump_hash_table(dsr_engine *e, dsr_hash_entry *out) {
   CHECK_E(e);
+  { int st = wait_render(e); if (st) return st; }
   if (!out) return fail(DSR_E_ARG, "null");
   HIP_TRY(hipMemcpyAsync(out, e->scene.table, (size_t)e->E * sizeof(dsr_hash_entry), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2642,6 +2874,7 @@ int dsr_dump_visible_types(dsr_engine *e, uint8_t *out) {
 
 int dsr_dump_voxel_blocks(dsr_engine *e, int first_block, int n_blocks, dsr_voxel *out) {
   CHECK_E(e);
+  { int st = wait_render(e); if (st) return st; }
   if (!out || first_block < 0 || n_blocks < 0 || (long long)first_block + n_blocks > e->noBlocks) return fail(DSR_E_ARG, "bad block range");
   const int chunk = 16384;  // 64 MiB of AoS voxels per pass
   if (e->aosScratchBlocks < std::min(chunk, n_blocks)) {
@@ -2673,6 +2906,7 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result, float *points, float *normals,
                           uint8_t *raycast_image) {
   CHECK_E(e);
+  { int st = wait_render(e); if (st) return st; }
   RenderStateDev &rs = which ? e->freeview : e->live;
   const size_t P = (size_t)e->P;
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
@@ -2741,6 +2975,7 @@ int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
       // a voxel; per colour voxel ONE 4-byte word (r, g, b, w_color) read and written; the depth and RGB frames (8 B per pixel)
       k.bytes_layout = V * (4.0 + 16.0 + 1536.0) + storeLanes * 24.0 + colourVoxels * 8.0 + L * 8.0 * P;
       k.units = V;
+      k.store_lanes = storeLanes; k.colour_voxels = colourVoxels;
     }
     else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;
     else if (r.name == "expected_depth") k.bytes = (double)work[WORK_V_EXPECTED] * 16.0 + L * 8.0 * std::ceil(e->W / 8.0) * std::ceil(e->H / 8.0);

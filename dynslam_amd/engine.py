@@ -440,7 +440,8 @@ class EngineCore:
         buf = (KernelTime * 64)()
         n = self.api.profile_get(self._h, buf, 64)
         return [dict(name=buf[i].name.decode(), total_ms=buf[i].total_ms, launches=buf[i].launches,
-                     bytes=buf[i].bytes, bytes_layout=buf[i].bytes_layout, units=buf[i].units) for i in range(n)]
+                     bytes=buf[i].bytes, bytes_layout=buf[i].bytes_layout, units=buf[i].units,
+                     store_lanes=buf[i].store_lanes, colour_voxels=buf[i].colour_voxels) for i in range(n)]
 
 
 class VoxelDecayParams:

@@ -235,6 +235,13 @@ int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out);
  * pointer may be NULL. */
 int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out);
 
+/* Page-locks a HOST buffer the caller hands to the library again and again — the cv::Mat behind a driver's previews, a frame
+ * buffer it refills every frame — (what cudaHostRegister is to a CUDA host): transfers to and from a pinned buffer go straight
+ * between it and HBM on the I/O stream, without the staging copy every pageable buffer costs (2.3 MB per preview pair).  The
+ * buffer must stay allocated until dsr_unpin_host_buffer.  Purely an optimisation: every entry point takes either kind. */
+int dsr_pin_host_buffer(void *ptr, size_t bytes);
+int dsr_unpin_host_buffer(void *ptr);
+
 /* ---- pose (trackingState->pose_d) ------------------------------------------- */
 
 /* pose_d->SetInvM(invM) (InfiniTamDriver.h:131-134): invM = camera->world. */
@@ -507,6 +514,9 @@ typedef struct dsr_kernel_time {
   double bytes_layout; /* integrate: compulsory bytes of the plane-wise layout actually used (DESIGN.md
                           "byte model"), from the kernel's own tallies; 0 for the other kernels       */
   double units;      /* integrate: visible blocks processed over all launches                     */
+  double store_lanes;   /* integrate: the kernel's own tallies behind bytes_layout — lanes (= x rows of a block) that wrote
+                           their 24 B of sdf + w_depth back, ...                                       */
+  double colour_voxels; /* ... voxels that went through the colour update (8 B each)                   */
 } dsr_kernel_time;
 /* enable == 1 brackets every kernel launch with HIP events, enable == 2 only the two
  * dominant kernels (integrate, raycast); 0 = off.  Events cost ~3 us per bracketed launch

@@ -593,8 +593,10 @@ static inline void computeUpdatedVoxelColorInfo(dsr_voxel &voxel, const V4f &pt_
   voxel.w_color = (uint8_t)f2i(newW);
 }
 
-/* oracle-only diagnostics of the integration (orc_debug_integrate_stats): blocks, voxels whose
- * depth was updated, voxels whose colour was updated, half blocks / z-slices / blocks with any update */
+/* oracle-only diagnostics of the integration (orc_debug_integrate_stats): [0] blocks, [1] voxels whose depth was updated, [2] voxels
+ * that passed the colour gate, [3] half blocks / [4] z-slices / [5] blocks with any update, [6] x columns with any update per
+ * block, [7] x ROWS — the 64 (y, z) pairs of a block — with any updated voxel: the unit the HIP kernel stores (a lane owns a row:
+ * 24 bytes written back per row with an update; tests/test_gpu_fullsize.py compares the kernel's own tallies with [7] and [2]) */
 static long long g_int_stats[8];
 static bool g_int_stats_on = false;
 
@@ -615,7 +617,7 @@ static void integrate_into_scene(Engine &e) {
     if (he.ptr < 0) continue;
     V3i globalPos = {he.pos[0] * DSR_BLOCK_SIZE, he.pos[1] * DSR_BLOCK_SIZE, he.pos[2] * DSR_BLOCK_SIZE};
     dsr_voxel *localVoxelBlock = &e.voxels[(size_t)he.ptr * DSR_BLOCK_SIZE3];
-    long long nUpd = 0, nClr = 0; unsigned sliceMask = 0, xMask = 0, yMask = 0;
+    long long nUpd = 0, nClr = 0; unsigned sliceMask = 0, xMask = 0; unsigned long long rowMask = 0;
     for (int z = 0; z < DSR_BLOCK_SIZE; z++)
       for (int y = 0; y < DSR_BLOCK_SIZE; y++)
         for (int x = 0; x < DSR_BLOCK_SIZE; x++) {
@@ -631,7 +633,7 @@ static void integrate_into_scene(Engine &e) {
           const dsr_voxel before = voxel;
           float eta = computeUpdatedVoxelDepthInfo(voxel, pt_model, M_d, projParams_d, mu, maxW, e.depth.data(),
                                                    e.W, e.H, e.depthWeighting);
-          if (g_int_stats_on && (eta != -1 && !(eta < -mu))) { nUpd++; sliceMask |= 1u << z; xMask |= 1u << x; yMask |= 1u << y; }
+          if (g_int_stats_on && (eta != -1 && !(eta < -mu))) { nUpd++; sliceMask |= 1u << z; xMask |= 1u << x; rowMask |= 1ull << (y + 8 * z); }
           (void)before;
           if ((eta > mu) || (fabsf(eta / mu) > 0.25f)) continue;
           computeUpdatedVoxelColorInfo(voxel, pt_model, M_rgb, projParams_rgb, maxW, e.rgb.data(), e.Wr, e.Hr);
@@ -644,7 +646,7 @@ static void integrate_into_scene(Engine &e) {
         g_int_stats[3] += ((sliceMask & 0x0f) != 0) + ((sliceMask & 0xf0) != 0);
         g_int_stats[4] += __builtin_popcount(sliceMask);
         g_int_stats[5] += sliceMask != 0;
-        g_int_stats[6] += __builtin_popcount(xMask); g_int_stats[7] += __builtin_popcount(yMask);
+        g_int_stats[6] += __builtin_popcount(xMask); g_int_stats[7] += __builtin_popcountll(rowMask);
       }
     }
   }
@@ -1398,6 +1400,8 @@ int orc_set_view_float(dsr_engine *h, const uint8_t *rgba, const float *depth_m)
 int orc_set_view_float_dev(dsr_engine *h, const void *rgba, const void *depth_m) {
   return orc_set_view_float(h, (const uint8_t *)rgba, (const float *)depth_m);
 }
+int orc_pin_host_buffer(void *ptr, size_t bytes) { return (ptr && bytes) ? DSR_OK : fail(DSR_E_ARG, "null"); }  /* nothing to pin on the host */
+int orc_unpin_host_buffer(void *ptr) { return ptr ? DSR_OK : fail(DSR_E_ARG, "null"); }
 int orc_get_view(dsr_engine *h, uint8_t *rgba_out, float *depth_m_out) {
   if (!h) return fail(DSR_E_ARG, "null");
   if (!E.hasView) return fail(DSR_E_NO_VIEW, "no view yet");

@@ -60,7 +60,17 @@ class HostDriver : public ITMMainEngine {
  public:
   HostDriver(const ITMLibSettings *s, const ITMRGBDCalib *c, Vector2i size, bool decay, int decayMaxW, int decayMinAge)
       : ITMMainEngine(s, c, size, size), rgb_(size, true, true), rawDepth_(size, true, true), previewMm_((size_t)size.x * size.y),
-        previewBgr_((size_t)size.x * size.y * 3), decay_(decay), decayMaxW_(decayMaxW), decayMinAge_(decayMinAge) {}
+        previewBgr_((size_t)size.x * size.y * 3), decay_(decay), decayMaxW_(decayMaxW), decayMinAge_(decayMinAge) {
+    // the previews live as long as the driver (the reference keeps them in cv::Mat members): page-locked once, every frame's
+    // read-back then lands in them directly
+    if (!std::getenv("DSR_HOST_PAGEABLE_PREVIEWS")) {
+      pinned_ = dsr_pin_host_buffer(previewBgr_.data(), previewBgr_.size()) == DSR_OK &&
+                dsr_pin_host_buffer(previewMm_.data(), previewMm_.size() * sizeof(short)) == DSR_OK;
+    }
+  }
+  ~HostDriver() {
+    if (pinned_) { dsr_unpin_host_buffer(previewBgr_.data()); dsr_unpin_host_buffer(previewMm_.data()); }
+  }
   void UpdateView(const unsigned char *bgr, const short *depthMm) {  // InfiniTamDriver.cpp:211-224
     static const bool twoStep = std::getenv("DSR_HOST_TWO_STEP_UPDATE") != nullptr;  // A/B: the reference's two-step form
     if (twoStep) {
@@ -115,6 +125,7 @@ class HostDriver : public ITMMainEngine {
   WeightParams weights_;
   bool decay_;
   int decayMaxW_, decayMinAge_;
+  bool pinned_ = false;
 };
 #endif
 

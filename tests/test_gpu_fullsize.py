@@ -1,6 +1,8 @@
 """-m gpu: BASELINE.json's full size (1242x375, 5 mm voxels, 2^23-entry table) — the oracle
 only checks the first two frames here (seconds with OpenMP); beyond that the engine state is
 checked through size-independent properties of the data structure."""
+import os
+
 import numpy as np
 import pytest
 
@@ -176,3 +178,40 @@ def test_full_size_free_view_and_reset(hip_api):
     st = g.get_stats()
     assert st.last_free_block_id == (1 << 21) - 1 and st.no_visible_blocks == 0
     assert (g.dump_hash_table()["ptr"] == -2).all()
+
+
+def test_byte_tallies_of_k_integrate_equal_an_independent_count(hip_api, oracle_lib):
+    """`roofline.achieved` prices a launch of k_integrate with bytes the kernel tallies ITSELF (lanes that wrote their 24 B of sdf +
+    w_depth back, voxels that went through the colour update: dsr_profile_get's store_lanes / colour_voxels).  The oracle counts
+    the same two quantities independently while it fuses the same full-size frames (orc_debug_integrate_stats: x rows of a block
+    with any updated voxel, voxels that pass the colour gate) — they must agree exactly, and so must the visible blocks."""
+    import ctypes as C
+    from oracle.oracle import OracleEngine, oracle_settings
+    sc = StreetScene(W, H)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    kw = dict(KW)
+    g = EngineCore(default_settings(**kw), calib)
+    o = OracleEngine(oracle_settings(**kw), calib, threads=os.cpu_count() or 1)
+    stats_fn = oracle_lib.lib.orc_debug_integrate_stats
+    stats_fn.restype = C.c_int
+    stats_fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    out = (C.c_longlong * 8)()
+    stats_fn(1, 1, out)
+    g.profile_enable(2)
+    g.profile_reset()
+    for i in range(2):
+        rgba, d, T, _ = sc.frame(i)
+        for e in (g, o):
+            e.update_view(rgba, d); e.set_pose_inv_m(T); e.process_frame()
+    g.sync()
+    rec = next(r for r in g.profile_get() if r["name"] == "integrate")
+    stats_fn(0, 1, out)
+    blocks, upd_voxels, colour_voxels, rows = out[0], out[1], out[2], out[7]
+    assert rec["launches"] == 2 and blocks > 300_000
+    assert int(rec["units"]) == blocks
+    assert int(rec["store_lanes"]) == rows and rows * 8 >= upd_voxels > 0
+    assert int(rec["colour_voxels"]) == colour_voxels > 0
+    # ... and the layout-true byte model built from them
+    P = W * H
+    assert rec["bytes_layout"] == blocks * (4 + 16 + 1536) + rows * 24 + colour_voxels * 8 + 2 * 8 * P
+    g.close(); o.close()

@@ -262,12 +262,18 @@ def test_device_resident_view_equals_host_view(hip_api):
         e.close()
 
 
-def test_asynchronous_loop_bit_exact(hip_api):
+@pytest.mark.parametrize("env", [dict(), dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_PIPELINED_VIEW="1"),
+                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_RAYCAST_SPLIT="9", DSR_INTEGRATE_XLDS="1")])
+def test_asynchronous_loop_bit_exact(hip_api, monkeypatch, env):
     """The steady loop UpdateView(dev) -> ProcessFrame -> Prepare with sync_status = 0, as bench.py
     drives it: nothing is read back and the host never waits in between; the final state must be
-    the oracle's, several times over (a missing dependency would show as a flaky difference)."""
+    the oracle's, several times over (a missing dependency would show as a flaky difference).  With the side stream forced on
+    (a small volume does not get one by itself) the range image runs under the integration and the raycast + ICP maps under the
+    next frame's ingest / re-test / mark: the hazards wait_render / evExpected guard."""
     import torch
     from tests.common import assert_render_equal
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     dev = torch.device("cuda", 0)
     for rep in range(3):
         sc, g, o = make_pair(sync_status=0)
@@ -364,7 +370,14 @@ def test_free_view_cache(hip_api):
                                  # the raycast in two kernels (k_raycast cut after K loop trips, k_raycast_tail with 8 lanes per ray):
                                  # every ray through the tail kernel (K = 1), a cut in the middle of the march, a tiny tail grid
                                  dict(DSR_RAYCAST_SPLIT="1"), dict(DSR_RAYCAST_SPLIT="6", DSR_GRID_RAYCAST_TAIL="3"),
-                                 dict(DSR_RAYCAST_SPLIT="17", DSR_SMALL_VOLUME="1"), dict(DSR_RAYCAST_SPLIT="0")])
+                                 dict(DSR_RAYCAST_SPLIT="1", DSR_RAYCAST_TAIL_MODE="8"), dict(DSR_RAYCAST_SPLIT="3", DSR_RAYCAST_TAIL_MODE="4"),
+                                 dict(DSR_RAYCAST_SPLIT="17", DSR_SMALL_VOLUME="1"), dict(DSR_RAYCAST_SPLIT="0"),
+                                 # the side stream forced onto this small volume: range image under the integration, raycast + ICP
+                                 # maps under the next frame's read-only prefix (and each of the two alone); one view buffer
+                                 dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_RAYCAST_SPLIT="5"),
+                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="0"), dict(DSR_PIPELINED_VIEW="0"),
+                                 # k_integrate with the wave-uniform x terms of the camera transform through LDS
+                                 dict(DSR_INTEGRATE_XLDS="1"), dict(DSR_INTEGRATE_XLDS="1", DSR_GRID_INTEGRATE="3")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour

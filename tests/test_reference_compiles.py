@@ -321,7 +321,10 @@ def test_cpp_host_one_volume_per_gpu_through_the_exchange(hip_api, oracle_lib, t
             (["--devices", "0,0,0"], {"DSR_FORCE_PEER_PATH": "1"}), (["--devices", "0"], {"DSR_EXCHANGE_FORCE_RCCL": "1"}),
             (["--devices", "0,0"], {"DSR_EXCHANGE_FORCE_RCCL": "1", "DSR_FORCE_PEER_PATH": "1"})]
     for extra, env in runs:
-        got = dict(kv.split("=") for kv in subprocess.check_output([hip] + base + extra, env=dict(os.environ, **env)).decode().split())
+        out = subprocess.check_output([hip] + base + extra, env=dict(os.environ, **env), timeout=300).decode()
+        lines = [ln for ln in out.splitlines() if ln.startswith("driver=")]
+        assert len(lines) == 1 and out.strip().startswith("driver="), out  # nothing but the host's own line on stdout (no RCCL banner)
+        got = dict(kv.split("=") for kv in lines[0].split())
         assert got["composite_hash"] == ref["composite_hash"] and got["hash"] == ref["hash"], (extra, env, got, ref)
         assert got["inst_used_bytes"] == ref["inst_used_bytes"] and got["used_bytes"] == ref["used_bytes"]
 

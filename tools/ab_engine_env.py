@@ -59,8 +59,8 @@ def main():
             wall = (time.perf_counter() - t0) / (a.frames - a.warmup)
             prof = {r["name"]: 1e3 * r["total_ms"] / max(1, r["launches"]) for r in e.profile_get()}
             e.profile_enable(False)
-            rec = {"variant": v, "rep": rep, "integrate_us": round(prof.get("integrate", 0.0), 1), "raycast_us": round(prof.get("raycast", 0.0), 1),
-                   "ms_per_frame": round(1e3 * wall, 4)}
+            rec = {"variant": v, "rep": rep, "integrate_us": round(prof.get("integrate", 0.0), 1), "raycast_us": round(prof.get("raycast", 0.0), 1), "raycast_tail_us": round(prof.get("raycast_tail", 0.0), 1),
+                   "raycast_tail_us": round(prof.get("raycast_tail", 0.0), 1), "ms_per_frame": round(1e3 * wall, 4)}
             if rep == 0:
                 rs = e.dump_render_state()
                 ht = e.dump_hash_table()

@@ -54,7 +54,7 @@ def main():
             import ctypes as C
             cnt = (C.c_uint32 * 2)()
             e.api.lib.dsr_debug_tail_rays(e._h, cnt)
-            rec = {"split_trips": K, "tail_grid": grid, "tail_rays": max(cnt[0], cnt[1]), "raycast_us": round(prof.get("raycast", 0.0), 1),
+            rec = {"split_trips": K, "tail_grid": grid, "tail_rays": max(cnt[0], cnt[1]), "raycast_us": round(prof.get("raycast", 0.0), 1), "tail_us": round(prof.get("raycast_tail", 0.0), 1),
                    "integrate_us": round(prof.get("integrate", 0.0), 1), "digest": digest}
             print(json.dumps(rec), flush=True)
             out.append(rec)
