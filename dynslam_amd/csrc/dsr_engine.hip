@@ -173,10 +173,11 @@ struct dsr_engine {
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
   // k_raycast leaves a ray after this many loop trips and k_raycast_tail resumes it, 8 lanes per ray (k_raycast.h); 0: one kernel.
-  // env DSR_RAYCAST_SPLIT overrides (tests: 0 = every ray goes through the tail kernel is NOT expressible — use 1).
+  // OFF by default: measured on the bench workload (profiles/r04c_raycast_split_kernels_ab.log) the pair costs what the one
+  // kernel costs at every cut — K = 64: 285 + 160 us against 444 — the work moves, the critical path does not get shorter
+  // (DESIGN.md 6.3).  env DSR_RAYCAST_SPLIT=K enables it (the parity suite runs it at K = 1, 6, 17).
   int raycastSplit = 0;
   int gridRaycastTail = 2048;   // env DSR_GRID_RAYCAST_TAIL
-  int raycastTailMode = 1;      // 1: one lane per ray, 8 probes per round; 4: ... 4 probes; 8: eight lanes per ray (env DSR_RAYCAST_TAIL_MODE)
   float4 *tailState = nullptr;
   int *tailPix = nullptr;
   uint32_t *tailCount = nullptr;
@@ -299,8 +300,10 @@ struct dsr_engine {
   // waves (k_raycast.h), and what the next frame does first — view ingest, the frustum re-test of the visible list, the
   // per-pixel allocation mark — only READS the scene: it runs on the engine's stream under that tail, and the first kernel that
   // modifies anything the raycast reads (the allocation's scan / commit) waits for evRenderDone.  Same policy as the range image:
-  // volumes of at least 2^20 blocks that have the GPU to themselves.  env DSR_OVERLAP_PREPARE=0/1.
-  bool overlapPrepare = true;
+  // volumes of at least 2^20 blocks that have the GPU to themselves.  MEASURED AND OFF BY DEFAULT (profiles/r04c_overlap_prepare_ab.log):
+  // the kernels do overlap, and the raycast pays for it — 422 -> 444 us, 1.121 -> 1.130 ms per frame, the result round 1 got with a
+  // second stream for the prefix.  env DSR_OVERLAP_PREPARE=1 enables it (the parity suite does).
+  bool overlapPrepare = false;
   hipEvent_t evPrepareGo = nullptr, evRenderDone = nullptr;
   bool renderPending = false;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
@@ -511,10 +514,23 @@ int dmalloc(T **p, size_t n) {
 
 // ---- host buffers in and out without draining the engine's stream (see dsr_engine) ---------------------------------
 
+// Streams of small work that must not queue behind a large volume's long kernels (instance volumes, view operations, I/O):
+// created at the device's highest priority when DSR_STREAM_PRIORITY is set — the runtime keeps separate hardware queues per
+// priority, so such a stream never shares one with a map's integration (measurement knob, see DESIGN.md "through the host").
+hipError_t create_stream(hipStream_t *out, bool small) {
+  static const bool prio = getenv("DSR_STREAM_PRIORITY") != nullptr && atoi(getenv("DSR_STREAM_PRIORITY")) != 0;
+  if (prio && small) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+      return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
+  }
+  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 int io_stream(dsr_engine *e, hipStream_t *out) {
   if (e->device < 0 || e->device >= 64) return fail(DSR_E_ARG, "device ordinal beyond the I/O stream table");
   std::lock_guard<std::mutex> lock(g_ioMutex);
-  if (!g_ioStream[e->device]) HIP_TRY(hipStreamCreateWithFlags(&g_ioStream[e->device], hipStreamNonBlocking));
+  if (!g_ioStream[e->device]) HIP_TRY(create_stream(&g_ioStream[e->device], true));
   *out = g_ioStream[e->device];
   return DSR_OK;
 }
@@ -829,15 +845,8 @@ int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderState
     e->raycastLaunches++;
     LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult,
            e->raycastSplit, e->tailState, e->tailPix, cur);
-    if (e->raycastTailMode == 8)
-      LAUNCH(e, "raycast_tail", k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
-             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
-    else if (e->raycastTailMode == 4)
-      LAUNCH(e, "raycast_tail", (k_raycast_tail_lanes<4>), dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
-             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
-    else
-      LAUNCH(e, "raycast_tail", (k_raycast_tail_lanes<8>), dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
-             rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
+    LAUNCH(e, "raycast_tail", k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
+           rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
     return DSR_OK;
   }
   LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, 0,
@@ -1213,7 +1222,6 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *et = getenv("DSR_EXPECTED_THREADS")) e->threadsExpected = std::min(1024, std::max(64, (atoi(et) / 64) * 64));
   if (const char *rs = getenv("DSR_RAYCAST_SPLIT")) e->raycastSplit = std::max(0, atoi(rs));
   if (const char *gt = getenv("DSR_GRID_RAYCAST_TAIL")) e->gridRaycastTail = std::max(1, atoi(gt));
-  if (const char *tm = getenv("DSR_RAYCAST_TAIL_MODE")) e->raycastTailMode = atoi(tm);
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
@@ -1228,7 +1236,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   int st = set_device(e);
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
+  if (create_stream(&e->stream, s.sdf_local_block_num <= 16384) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
   // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
   // ones, not for a map at the reference's 5 cm / 2^18 blocks, whose whole frame is 0.24 ms), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
   // map + N instance volumes is N + 1 engines — with a (high-priority) side stream per engine `bench.py --instance-volumes 8`
@@ -1295,7 +1303,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   }
   e->pipelinedView = s.sync_status != 0;  // a host that waits for status words: see dsr_engine
   if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
-  if (e->pipelinedView && hipStreamCreateWithFlags(&e->viewStream, hipStreamNonBlocking) != hipSuccess) {
+  if (e->pipelinedView && create_stream(&e->viewStream, true) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
   }
   if (s.sync_status) {

@@ -276,6 +276,7 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
       if (mode == SCAN_COMPACT_LIVE) ctr[CTR_TMP_OLD_NVIS] = ctr[CTR_NO_VISIBLE_LIVE];
       ctr[mode == SCAN_VISIBLE_FREE ? CTR_NO_VISIBLE_FREE : CTR_NO_VISIBLE_LIVE] = n;
       if (mode == SCAN_VISIBLE_LIVE) {
+        ctr[CTR_VIS_OVERFLOW] = carry.x > capacity ? 1 : 0;  // more visible entries than the list holds (K0b)
         // with swapping: visible swapped-out entries (y) take fresh blocks, after the frame's
         // regular allocations, in ascending entry order
         const int oldV = ctr[CTR_LAST_FREE_BLOCK];
@@ -451,6 +452,24 @@ __global__ __launch_bounds__(256) void k_retest_previous_visible(FrameP p, Scene
     } else {
       check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
       visType[t] = isVisible ? 3 : 0;
+    }
+  }
+  // The serial engine re-tests EVERY entry of type 3, not just the entries of the list.  The two sets differ only after a frame
+  // whose visible entries did not fit the list (capacity = the block array size: a volume exhausted long before): an entry that
+  // was cut off keeps its 3 and has no list slot to be re-tested through.  Then — and only then — the whole table is swept for
+  // type-3 entries (re-testing a list entry again gives the same answer; found by the exhausted-volume parity test of round 4).
+  if (s.ctr[CTR_VIS_OVERFLOW]) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < p.noTotalEntries; t += gridDim.x * blockDim.x) {
+      if (visType[t] != 3) continue;
+      const dsr_hash_entry he = load_entry(s.table, t);
+      bool isVisible, isVisibleEnlarged;
+      if (p.useSwapping) {
+        check_block_visibility<true>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+        if (!isVisibleEnlarged) visType[t] = 0;
+      } else {
+        check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+        if (!isVisible) visType[t] = 0;
+      }
     }
   }
 }

@@ -715,107 +715,6 @@ __global__ __launch_bounds__(256) void k_raycast_tail(FrameP p, SceneP s, const 
   }
 }
 
-// The same resumption with ONE LANE PER RAY (64 rays per wave): in the 8-lanes-per-ray form a wave serves 8 rays, so every
-// serial trip — a ray inside allocated space, where nothing can be probed ahead — costs the wave's full instruction issue for an
-// eighth of the rays, and the tail kernel becomes issue bound (tail list of 36 k rays: 4.5 k waves).  Here a lane in empty space
-// looks NP steps ahead BY ITSELF: NP candidate positions (sequential additions), NP bucket heads requested together, chains
-// walked, first stop taken — what the one-kernel march could not afford in registers (round 3: 69 VGPRs cost the busy first
-// half of the launch more than the probing saved) is affordable in a kernel that only ever holds the few long rays.
-template <int NP>
-__global__ __launch_bounds__(256) void k_raycast_tail_lanes(FrameP p, SceneP s, const float2 *__restrict__ minmax,
-                                                            float4 *__restrict__ raycastResult, const float4 *__restrict__ tailState,
-                                                            const int *__restrict__ tailPix, const uint32_t *__restrict__ tailCount,
-                                                            uint32_t *__restrict__ nextCount) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *nextCount = 0u;
-  const uint32_t n = *tailCount;
-  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
-  const float stepScale = p.mu * (1.0f / p.voxelSize);
-  for (uint32_t ray = blockIdx.x * 256u + threadIdx.x; ray < n; ray += gridDim.x * 256u) {
-    const int pix = tailPix[ray];
-    const float4 st = tailState[ray];
-    const int y = pix / p.W, x = pix - y * p.W;
-    RayState r;
-    ray_setup<DeviceOps>(p, x, y, minmax[(x >> 3) + (y >> 3) * mw], r);
-    r.rx = st.x; r.ry = st.y; r.rz = st.z; r.totalLength = st.w;
-    const float sx = (float)kBlockSize * r.dx, sy = (float)kBlockSize * r.dy, sz = (float)kBlockSize * r.dz;
-    VoxCache cache; cache_init(cache);
-    VoxCache cache2; cache_init(cache2);
-    float sdfValue = 1.0f;
-    bool probe = true, done = false;
-    while (!done) {
-      // candidates 0 .. cnt-1: the ray's state after that many further misses
-      const int cnt = probe ? NP : 1;
-      float cx[NP], cy[NP], cz[NP], cl[NP];
-      int4 raw[NP];
-      bool in[NP];
-      {
-        float ax = r.rx, ay = r.ry, az = r.rz, al = r.totalLength;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-          cx[k] = ax; cy[k] = ay; cz[k] = az; cl[k] = al;
-          in[k] = k < cnt && al < r.totalLengthMax;
-          ax += sx; ay += sy; az += sz; al += (float)kBlockSize;
-        }
-      }
-      // all bucket heads of the round requested together (a cached block needs none)
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        raw[k] = make_int4(0, 0, 0, -2);
-        if (in[k]) {
-          const int bx = f2i(roundf_itm(cx[k])) >> 3, by = f2i(roundf_itm(cy[k])) >> 3, bz = f2i(roundf_itm(cz[k])) >> 3;
-          if (!(bx == cache.bx && by == cache.by && bz == cache.bz))
-            raw[k] = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
-        }
-      }
-      // first candidate, in step order, that ends the run of misses
-      int f = -1, fptr = -1;
-#pragma unroll
-      for (int k = 0; k < NP; ++k) {
-        if (f >= 0 || k >= cnt) continue;
-        if (!in[k]) { f = k; fptr = -1; continue; }
-        const int bx = f2i(roundf_itm(cx[k])) >> 3, by = f2i(roundf_itm(cy[k])) >> 3, bz = f2i(roundf_itm(cz[k])) >> 3;
-        int ptr = -1;
-        if (bx == cache.bx && by == cache.by && bz == cache.bz) ptr = cache.ptr;
-        else {
-          int4 e4 = raw[k];
-          while (true) {  // ITMRepresentationAccess.h findVoxel
-            const int hx = (short)(e4.x & 0xffff), hy = (short)((uint32_t)e4.x >> 16), hz = (short)(e4.y & 0xffff);
-            if (hx == bx && hy == by && hz == bz && e4.w >= 0) { ptr = e4.w; break; }
-            if (e4.z < 1) break;
-            e4 = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + e4.z - 1));
-          }
-        }
-        if (ptr >= 0) { f = k; fptr = ptr; }
-      }
-      if (f < 0) {  // every candidate is an absent block inside the range
-        r.rx = (probe ? cx[NP - 1] : cx[0]) + sx; r.ry = (probe ? cy[NP - 1] : cy[0]) + sy; r.rz = (probe ? cz[NP - 1] : cz[0]) + sz;
-        r.totalLength = (probe ? cl[NP - 1] : cl[0]) + (float)kBlockSize;
-        probe = true;
-        continue;
-      }
-      // (a select chain instead of a dynamically indexed register array)
-      float fx = cx[0], fy = cy[0], fz = cz[0], fl = cl[0];
-#pragma unroll
-      for (int k = 1; k < NP; ++k) { const bool t = f == k; fx = t ? cx[k] : fx; fy = t ? cy[k] : fy; fz = t ? cz[k] : fz; fl = t ? cl[k] : fl; }
-      r.rx = fx; r.ry = fy; r.rz = fz; r.totalLength = fl;
-      if (fptr < 0) { done = true; continue; }  // left the range without a surface
-      const int vx = f2i(roundf_itm(fx)), vy = f2i(roundf_itm(fy)), vz = f2i(roundf_itm(fz));
-      cache.bx = vx >> 3; cache.by = vy >> 3; cache.bz = vz >> 3; cache.ptr = fptr;
-      const int lin = (vx & 7) + ((vy & 7) << 3) + ((vz & 7) << 6);
-      sdfValue = sdf_to_float_short((float)*reinterpret_cast<const short *>(s.vba + (size_t)fptr * kBlockBytes + kOffSdf + lin * 2));
-      if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f))
-        sdfValue = sdf_to_float_short(read_sdf_interpolated_raw<DeviceOps>(s, p, r.rx, r.ry, r.rz, cache, cache2));
-      if (sdfValue <= 0.0f) { done = true; continue; }
-      const float ss = sdfValue * stepScale;
-      const float stepLength = (ss > 1.0f) ? ss : 1.0f;  // MAX(sdfValue * stepScale, 1.0f)
-      r.rx += stepLength * r.dx; r.ry += stepLength * r.dy; r.rz += stepLength * r.dz;
-      r.totalLength += stepLength;
-      probe = false;
-    }
-    raycastResult[pix] = ray_finish<DeviceOps>(p, s, r, sdfValue, cache, cache2);
-  }
-}
-
 // ---------------------------------------------------------------- K8: ICP maps
 
 template <class Ops>

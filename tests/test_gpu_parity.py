@@ -262,8 +262,9 @@ def test_device_resident_view_equals_host_view(hip_api):
         e.close()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_PIPELINED_VIEW="1"),
-                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_RAYCAST_SPLIT="9", DSR_INTEGRATE_XLDS="1")])
+@pytest.mark.parametrize("env", [dict(), dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1"),
+                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1", DSR_PIPELINED_VIEW="1"),
+                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1", DSR_RAYCAST_SPLIT="9", DSR_INTEGRATE_XLDS="0")])
 def test_asynchronous_loop_bit_exact(hip_api, monkeypatch, env):
     """The steady loop UpdateView(dev) -> ProcessFrame -> Prepare with sync_status = 0, as bench.py
     drives it: nothing is read back and the host never waits in between; the final state must be
@@ -370,7 +371,6 @@ def test_free_view_cache(hip_api):
                                  # the raycast in two kernels (k_raycast cut after K loop trips, k_raycast_tail with 8 lanes per ray):
                                  # every ray through the tail kernel (K = 1), a cut in the middle of the march, a tiny tail grid
                                  dict(DSR_RAYCAST_SPLIT="1"), dict(DSR_RAYCAST_SPLIT="6", DSR_GRID_RAYCAST_TAIL="3"),
-                                 dict(DSR_RAYCAST_SPLIT="1", DSR_RAYCAST_TAIL_MODE="8"), dict(DSR_RAYCAST_SPLIT="3", DSR_RAYCAST_TAIL_MODE="4"),
                                  dict(DSR_RAYCAST_SPLIT="17", DSR_SMALL_VOLUME="1"), dict(DSR_RAYCAST_SPLIT="0"),
                                  # the side stream forced onto this small volume: range image under the integration, raycast + ICP
                                  # maps under the next frame's read-only prefix (and each of the two alone); one view buffer
