@@ -262,7 +262,7 @@ struct dsr_engine {
   // kernel reads; the status words are PUBLISHED by k_visible_write into a pinned, device-mapped word the host polls; previews
   // and view read-backs run on the I/O stream after the last kernel that wrote the view (evView) — none of them waits for
   // k_integrate or k_raycast.
-  // PIPELINED VIEW (engines with sync_status, i.e. driven by a host that waits for status words): everything that writes or
+  // PIPELINED VIEW (opt-in: env DSR_PIPELINED_VIEW=1, see dsr_engine_create for the measurements): everything that writes or
   // modifies the view — ingest, SetView, the silhouette kernels — runs on the engine's VIEW stream, and the view is double
   // buffered: a frame's view is built in the buffer fusion is not reading, so the next frame's view split (and with it the
   // instance volumes' whole frames) proceeds while this volume's integration and raycast are still running.  Without it the
@@ -795,7 +795,9 @@ int integrate_scene(dsr_engine *e) {
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
     else { if (plain) LAUNCH_INTEGRATE(false, true, VOX, OCC); else LAUNCH_INTEGRATE(false, false, VOX, OCC); }         \
   } while (0)
-  LAUNCH_INTEGRATE_V(8, 7);  // whole block per wave, 8 voxels per lane, 7 waves per SIMD (k_integrate.h)
+  // whole block per wave, 8 voxels per lane, register allocation for 7 waves per SIMD (k_integrate.h).  (The XLDS form needs 57
+  // VGPRs, so 8 waves are resident anyway; compiled FOR 8 the scalar-register budget shrinks: 40 instead of 23 spill writes.)
+  LAUNCH_INTEGRATE_V(8, 7);
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
@@ -1301,7 +1303,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (const char *sb = getenv("DSR_SLAB_BLOCKS")) e->scene.slabBlocks = std::max(1, atoi(sb));  // tests: force slab growth
     ALLOC(add_host_slab(e));  // the first slab, so that the first frames never wait for one
   }
-  e->pipelinedView = s.sync_status != 0;  // a host that waits for status words: see dsr_engine
+  // OFF by default.  Measured through the C++ host at configs[2] (5 mm map + 4 instance volumes, profiles/r04d_through_shim_queues.log):
+  // 453 frames/s with one stream per engine, 388 with the view streams at the runtime's default of 4 hardware queues (twice the
+  // streams share them: a stream's packets wait behind another stream's dependent chain in the same queue), 450 with the small
+  // streams at high priority, 488-498 with GPU_MAX_HW_QUEUES=16 (+ priority) — a gain only with a process-wide runtime setting
+  // the library cannot make.  env DSR_PIPELINED_VIEW=1 enables it; the parity suite runs both forms.
+  e->pipelinedView = false;
   if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
   if (e->pipelinedView && create_stream(&e->viewStream, true) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
@@ -2080,7 +2087,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     if (st) return st;
   }
   dsr_engine *e = main_engine;
-  static const bool forcePeerPath = getenv("DSR_FORCE_PEER_PATH") != nullptr;  // tests: the cross-GPU path on one GPU
+  const bool forcePeerPath = getenv("DSR_FORCE_PEER_PATH") != nullptr;  // tests: the cross-GPU path on one GPU
   const bool peer = instance->device != e->device || forcePeerPath;
   // Runs on the MAIN engine's view stream: ordered after the producer of its view and before any later blanking.  The kernel
   // REPLACES the instance's view: a pipelined instance takes it in its spare buffer (begin_view_replace: only the fusion that

@@ -152,6 +152,11 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
   uint32_t *pend = s_pend[wave];
   const int t0 = blockIdx.x * kIntegrateWaves + wave;  // this wave's first task; its k-th is t0 + k * stride
+  // Two uniforms of the per-voxel code that the register allocator keeps SPILLING (to lanes of a VGPR: a v_readlane — a half-rate
+  // VALU instruction — at every use, 8 + 3 per task; ISA of round 4): held in vector registers of their own instead (an opaque
+  // copy), where reading them is free.  The kernel has registers to spare since XLDS (57 of 64).
+  int maxWv = p.maxW;
+  asm volatile("" : "+v"(maxWv));
 
   // reciprocals of the constant divisors (uniform): correctly rounded for div_short, the refined
   // hardware reciprocal for the two-correction form
@@ -380,8 +385,10 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
         int newW = depthWeighting ? depth_weight(okx ? dm[x] : 1.0f) : 1;
         newF = (float)wDepth * oldF + (float)newW * newF;
         newW = wDepth + newW;
-        newF = PLAIN ? div_short(newF, (float)newW, s_rcpW[newW]) : fdiv_tame(newF, (float)newW);
-        newW = newW < p.maxW ? newW : p.maxW;
+        // (PLAIN: the new weight is wDepth + 1, and the float of that sum is the sum of the floats — a full-rate add where the
+        //  conversion is a half-rate instruction)
+        newF = PLAIN ? div_short(newF, (float)wDepth + 1.0f, s_rcpW[newW]) : fdiv_tame(newF, (float)newW);
+        newW = newW < maxWv ? newW : maxWv;
         const uint32_t sdfNew = (uint32_t)(uint16_t)sdf_from_float(newF);
         const uint32_t sw = (pl.sdf[x >> 1] & ~(0xffffu << ((x & 1) * 16))) | (sdfNew << ((x & 1) * 16));
         const uint32_t ww = (pl.wd[x >> 2] & ~(0xffu << ((x & 3) * 8))) | ((uint32_t)(newW & 0xff) << ((x & 3) * 8));

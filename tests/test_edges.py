@@ -193,11 +193,17 @@ def test_gpu_boundary_conversions(hip_api, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_gpu_instance_pipeline(hip_api, oracle_lib):
+@pytest.mark.parametrize("env", [dict(), dict(DSR_PIPELINED_VIEW="1"), dict(DSR_FORCE_PEER_PATH="1"),
+                                 dict(DSR_PIPELINED_VIEW="1", DSR_FORCE_PEER_PATH="1")])
+def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
     """Main view -> GPU split into an instance volume + blanked static map, both fused and
-    raycast: identical to the oracle running the reference's CPU loops."""
+    raycast: identical to the oracle running the reference's CPU loops.  Also with the view operations on the engines' view
+    streams and double-buffered views (DSR_PIPELINED_VIEW) and through the cross-GPU form of the split (cut-out produced on
+    the main engine's GPU, peer-copied to the instance's: DSR_FORCE_PEER_PATH runs that code on one GPU)."""
     from dynslam_amd.engine import OutOfBlocksError
     from tests.common import assert_render_equal, assert_scene_equal
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     W, H = 320, 96
     sc = StreetScene(W, H, n_instances=2)
     sc, gm, gi = make_engines(hip_factory, W, H)

@@ -482,13 +482,15 @@ def test_update_view_bgr_equals_the_two_step_form(hip_api, size):
         e.close()
 
 
-def test_host_buffer_frames_pipelined_without_waiting(hip_api):
+@pytest.mark.parametrize("pipelined_view", ["0", "1"])
+def test_host_buffer_frames_pipelined_without_waiting(hip_api, monkeypatch, pipelined_view):
     """Host-buffer frames (dsr_update_view: pinned double-buffered staging, upload on the I/O stream, landing buffer, ingest on the
     engine's stream) handed over back to back with sync_status = 0 — the host never waits, overwrites its own buffers right after
     every call, and asks for previews and the view in between (I/O-stream readers of the view) — the final state is the
     oracle's, several times over."""
     from tests.common import assert_render_equal
     import ctypes as C
+    monkeypatch.setenv("DSR_PIPELINED_VIEW", pipelined_view)  # "1": view operations on the view stream, the view double buffered
     for rep in range(3):
         sc, g, o = make_pair(sync_status=0)
         frames = [sc.frame(i) for i in range(9)]

@@ -42,7 +42,9 @@ def main():
         flags = [f for f in HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
         text = subprocess.check_output(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "-o", "-", src],
                                        stderr=subprocess.DEVNULL).decode()
-    m = re.search(r"^(_ZN3dsr11k_integrateILb1ELb1ELi8ELi7EE\w*):.*?s_endpgm", text, re.S | re.M)
+    # the instantiation the engine launches: <shared camera, plain weights, 8 voxels per lane, 7 waves, XLDS> (env ISA_MIX_XLDS=0: the round-3 form)
+    xl = "Lb0" if os.environ.get("ISA_MIX_XLDS") == "0" else "Lb1"
+    m = re.search(r"^(_ZN3dsr11k_integrateILb1ELb1ELi8ELi7E" + xl + r"EE\w*):.*?s_endpgm", text, re.S | re.M)
     body = m.group(0).split("\n")
     blocks, cur = [], ["entry", []]
     for l in body:
