@@ -205,7 +205,7 @@ def cpu_baseline_volumes(frames, w, h, n_volumes, has_static, preset, budget_s):
                       f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {t_total:.1f} s"}
 
 
-def through_shim(frames, w, h, intr, kw, warmup):
+def through_shim(frames, w, h, intr, kw, warmup, frames_instances=None):
     """SURVEY 8d "through-shim" rate: the C++ host shim/host_bench (our driver class over shim/ITMLib.h, the
     ITMLib names DynSLAM's InfiniTamDriver uses) fed with the SAME frames as pageable host buffers; per frame
     it pays what DynSLAM's host pays around the engine: BGR->RGBA conversion, the H2D copy of the frame,
@@ -217,9 +217,19 @@ def through_shim(frames, w, h, intr, kw, warmup):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from bench_through_shim import run
     r = run(exe, frames, w, h, intr, kw, warmup)
-    return {"frames_per_s": float(r["frames_per_s"]), "ms_per_frame": float(r["ms_per_frame"]), "host": "shim/host_bench.cpp (C++)",
-            "note": "same frames and table sizes, handed over as pageable host BGR + int16 buffers through shim/ITMLib.h; "
-                    "includes BGR->RGBA, H2D, one host synchronisation per frame, preview conversions + D2H (PCIe inclusive)"}
+    out = {"frames_per_s": float(r["frames_per_s"]), "ms_per_frame": float(r["ms_per_frame"]), "host": "shim/host_bench.cpp (C++)",
+           "note": "same frames and table sizes, handed over as pageable host BGR + int16 buffers through shim/ITMLib.h: the frame "
+                   "upload (BGR -> RGBA in the ingest kernel), the allocation status and both previews per frame, as "
+                   "InfiniTamDriver::UpdateView / Integrate / PrepareNextStep ask for them (PCIe inclusive)"}
+    if frames_instances is not None:  # configs[2] through the reference's call pattern: the map + 4 instance drivers, every call of every driver
+        try:
+            r2 = run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
+            out["configs2"] = {"frames_per_s": float(r2["frames_per_s"]), "ms_per_frame": float(r2["ms_per_frame"]),
+                               "note": "static map + 4 instance volumes (shim/host_bench --masks): GPU view split, per driver and frame one "
+                                       "allocation status and two previews back to the host"}
+        except Exception as ex:
+            out["configs2"] = {"frames_per_s": None, "note": f"failed: {ex}"}
+    return out
 
 
 def roofline_from_profile(prof, args, copy_gbs):
@@ -694,6 +704,7 @@ def run_rank(args):
     scaling_leg = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_scaling_leg and args.preset == "5mm"
                    and not (args.decay or args.swap or args.instances or args.host_views))
     frames8 = frames_for(args, SCALING_VOLUMES) if scaling_leg else None
+    frames4 = frames_for(args, 4) if (scaling_leg and not args.no_through_shim) else None  # configs[2] through the C++ host
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -804,7 +815,7 @@ def run_rank(args):
         shim = None
         if (not args.no_through_shim and world == 1 and not (args.decay or args.swap or args.instances or args.host_views)):
             try:  # the engines above are idle by now; the host process creates its own
-                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm)
+                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm, frames4)
             except Exception as ex:
                 shim = {"frames_per_s": None, "note": f"failed: {ex}"}
         out = {

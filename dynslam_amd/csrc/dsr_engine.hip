@@ -57,6 +57,10 @@ bool host_range_pinned(const void *p, size_t bytes) {
 }
 std::mutex g_ioMutex;
 hipStream_t g_ioStream[64] = {};                // per GPU: uploads, previews and view read-backs of every engine on it
+// DSR_PIPELINED_VIEW=2: per GPU ONE view stream for all engines and ONE fusion stream for all instance-sized volumes (a host drives
+// its instance volumes one after the other anyway): a map + N instances are then 4-5 streams instead of 2N + 4, and the map's
+// fusion stream need not share a hardware queue with anybody
+hipStream_t g_sharedViewStream[64] = {}, g_sharedSmallStream[64] = {};
 
 #define HIP_TRY(expr)                                                                              \
   do {                                                                                             \
@@ -269,6 +273,7 @@ struct dsr_engine {
   // view kernels of frame i + 1 queue behind the raycast of frame i on the one stream, and a host that waits for an instance's
   // allocation status waits for the map's whole previous frame (configs[2] through the reference's call pattern).
   bool pipelinedView = false;
+  bool ownsStream = true, ownsViewStream = true;  // false: the per-GPU shared streams (DSR_PIPELINED_VIEW=2)
   hipStream_t viewStream = nullptr;
   uchar4 *rgbAlt = nullptr;
   float *depthAlt = nullptr;
@@ -463,7 +468,7 @@ void free_all(dsr_engine *e) {
   F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth); F(e->tailState); F(e->tailPix); F(e->tailCount);
   F(e->rgbAlt); F(e->depthAlt);
   for (hipEvent_t ev : {e->evAltFree, e->evFusionRead}) if (ev) (void)hipEventDestroy(ev);
-  if (e->viewStream) (void)hipStreamDestroy(e->viewStream);
+  if (e->viewStream && e->ownsViewStream) (void)hipStreamDestroy(e->viewStream);
   if (e->pvPin) (void)hipHostFree(e->pvPin);
   if (e->statusHost) (void)hipHostFree(e->statusHost);
   for (hipEvent_t ev : {e->evUploaded, e->evIngested, e->evView, e->evViewRead}) if (ev) (void)hipEventDestroy(ev);
@@ -477,7 +482,7 @@ void free_all(dsr_engine *e) {
   if (e->evPrepareGo) (void)hipEventDestroy(e->evPrepareGo);
   if (e->evRenderDone) (void)hipEventDestroy(e->evRenderDone);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream && e->ownsStream) (void)hipStreamDestroy(e->stream);
 }
 
 // div_short(a, b, RN(1/b)) against a / b for every numerator mantissa (a in [1, 2): division is
@@ -1238,7 +1243,15 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   int st = set_device(e);
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
-  if (create_stream(&e->stream, s.sdf_local_block_num <= 16384) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
+  const int pvMode = getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : 0;
+  auto shared_stream = [&](hipStream_t *table) -> hipStream_t {
+    if (e->device < 0 || e->device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_ioMutex);
+    if (!table[e->device] && create_stream(&table[e->device], true) != hipSuccess) table[e->device] = nullptr;
+    return table[e->device];
+  };
+  if (pvMode == 2 && s.sdf_local_block_num <= 16384 && (e->stream = shared_stream(g_sharedSmallStream))) e->ownsStream = false;
+  else if (create_stream(&e->stream, s.sdf_local_block_num <= 16384) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
   // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
   // ones, not for a map at the reference's 5 cm / 2^18 blocks, whose whole frame is 0.24 ms), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
   // map + N instance volumes is N + 1 engines — with a (high-priority) side stream per engine `bench.py --instance-volumes 8`
@@ -1310,7 +1323,8 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   // the library cannot make.  env DSR_PIPELINED_VIEW=1 enables it; the parity suite runs both forms.
   e->pipelinedView = false;
   if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
-  if (e->pipelinedView && create_stream(&e->viewStream, true) != hipSuccess) {
+  if (e->pipelinedView && pvMode == 2 && (e->viewStream = shared_stream(g_sharedViewStream))) e->ownsViewStream = false;
+  else if (e->pipelinedView && create_stream(&e->viewStream, true) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
   }
   if (s.sync_status) {

@@ -194,7 +194,8 @@ def test_gpu_boundary_conversions(hip_api, oracle_lib):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(), dict(DSR_PIPELINED_VIEW="1"), dict(DSR_FORCE_PEER_PATH="1"),
-                                 dict(DSR_PIPELINED_VIEW="1", DSR_FORCE_PEER_PATH="1")])
+                                 dict(DSR_PIPELINED_VIEW="1", DSR_FORCE_PEER_PATH="1"), dict(DSR_PIPELINED_VIEW="2"),
+                                 dict(DSR_PIPELINED_VIEW="2", DSR_FORCE_PEER_PATH="1")])
 def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
     """Main view -> GPU split into an instance volume + blanked static map, both fused and
     raycast: identical to the oracle running the reference's CPU loops.  Also with the view operations on the engines' view

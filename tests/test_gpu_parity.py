@@ -482,7 +482,7 @@ def test_update_view_bgr_equals_the_two_step_form(hip_api, size):
         e.close()
 
 
-@pytest.mark.parametrize("pipelined_view", ["0", "1"])
+@pytest.mark.parametrize("pipelined_view", ["0", "1", "2"])
 def test_host_buffer_frames_pipelined_without_waiting(hip_api, monkeypatch, pipelined_view):
     """Host-buffer frames (dsr_update_view: pinned double-buffered staging, upload on the I/O stream, landing buffer, ingest on the
     engine's stream) handed over back to back with sync_status = 0 — the host never waits, overwrites its own buffers right after
