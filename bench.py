@@ -812,12 +812,6 @@ def run_rank(args):
                 cpu = cpu_baseline(frames, W, H, args.preset, args.cpu_budget_s)
             except Exception as ex:  # the baseline must never take the bench line down
                 cpu = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"failed: {ex}"}
-        shim = None
-        if (not args.no_through_shim and world == 1 and not (args.decay or args.swap or args.instances or args.host_views)):
-            try:  # the engines above are idle by now; the host process creates its own
-                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm, frames4)
-            except Exception as ex:
-                shim = {"frames_per_s": None, "note": f"failed: {ex}"}
         out = {
             "metric": "frames/sec TSDF integrate+raycast (KITTI 1242x375, 5mm voxels); HBM GB/s vs peak",
             "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -831,12 +825,23 @@ def run_rank(args):
                        "visible_blocks_last_frame": stats.no_visible_blocks,
                        "allocated_blocks": kw["sdf_local_block_num"] - 1 - stats.last_free_block_id,
                        "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
-            "roofline": roofline, "cpu_baseline": cpu, "through_shim": shim, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "through_shim": None, "kernels": kernels,
         }
     for ie in inst_eng:
         ie.close()
     eng.close()
     if rank == 0:
+        # the C++ host runs as a process of its own, AFTER this process has given its engines (streams, 32 GiB of voxels) back: with
+        # this process's queues still open the two processes' hardware queues are time-multiplexed (configs[2]'s five engines:
+        # 229 instead of 459 frames/s, profiles/r04f_bench_line.json)
+        shim = None
+        if (not args.no_through_shim and world == 1 and not (args.decay or args.swap or args.instances or args.host_views)):
+            torch.cuda.synchronize()
+            try:
+                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm, frames4)
+            except Exception as ex:
+                shim = {"frames_per_s": None, "note": f"failed: {ex}"}
+        out["through_shim"] = shim
         if scaling_leg:
             try:
                 calib = make_calib(*sc.intrinsics(), W, H)

@@ -313,6 +313,7 @@ struct dsr_engine {
   bool renderPending = false;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
+  bool xEvent2System = false;        // ... created with a system-scope release (an instance on another GPU has waited for it)
   hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
   uint8_t *decayFlags = nullptr;
 
@@ -540,8 +541,16 @@ int io_stream(dsr_engine *e, hipStream_t *out) {
   return DSR_OK;
 }
 
-int make_event(hipEvent_t *ev) {
-  if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+// Events that only order one stream of a GPU after another stream of the SAME GPU need a device-scope release; HIP's default is a
+// system-scope one (the XCD L2s written back and invalidated for the host's sake) at every record — there are 6-8 such records in
+// an instance volume's frame.  Events the HOST waits on before reading pinned memory (preview read-backs, the host store's
+// counter) and events waited for from another GPU keep the default.  env DSR_EVENT_SYSTEM_SCOPE=1: the default everywhere.
+unsigned order_event_flags() {
+  static const bool sys = getenv("DSR_EVENT_SYSTEM_SCOPE") != nullptr && atoi(getenv("DSR_EVENT_SYSTEM_SCOPE")) != 0;
+  return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
+}
+int make_event(hipEvent_t *ev, bool hostWaits = false) {
+  if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hostWaits ? hipEventDisableTiming : order_event_flags()));
   return DSR_OK;
 }
 
@@ -552,24 +561,32 @@ int before_view_write(dsr_engine *e, hipStream_t stream) {
 }
 // ... and after it
 int view_written(dsr_engine *e, hipStream_t stream) {
+  e->hasView = true;
+  if (!e->s.sync_status && !e->pipelinedView) {
+    // an engine driven without status waits (bench, the sharded scene): nobody reads its view back as a rule, and a record per
+    // view operation is a packet in the frame's dependent chain — the event is recorded when a reader turns up (io_reads_view)
+    e->viewEventValid = false;
+    return DSR_OK;
+  }
   int st = make_event(&e->evView);
   if (st) return st;
   HIP_TRY(hipEventRecord(e->evView, stream));
   e->viewEventValid = true;
-  e->hasView = true;
   return DSR_OK;
 }
 // the I/O stream becomes a reader of e's view as it is after everything queued so far that writes it
 int io_reads_view(dsr_engine *e, hipStream_t io) {
-  if (!e->viewEventValid) {  // written before this bookkeeping saw it (cannot happen through the C ABI): order after the whole stream
-    int st = view_written(e, e->stream);
+  if (!e->viewEventValid) {  // no record at write time (see view_written): after everything queued on the engine's streams so far
+    int st = make_event(&e->evView);
     if (st) return st;
+    HIP_TRY(hipEventRecord(e->evView, e->stream));
+    e->viewEventValid = true;
   }
   HIP_TRY(hipStreamWaitEvent(io, e->evView, 0));
   return DSR_OK;
 }
 int io_read_done(dsr_engine *e, hipStream_t io) {
-  int st = make_event(&e->evViewRead);
+  int st = make_event(&e->evViewRead, true);  // the host waits on it and then reads pinned memory
   if (st) return st;
   HIP_TRY(hipEventRecord(e->evViewRead, io));
   e->viewReadEver = true;
@@ -654,7 +671,8 @@ int upload_frame(dsr_engine *e, hipStream_t consumer, const void *colour, size_t
       HIP_TRY(hipEventCreateWithFlags(&e->upSlotFree[k], hipEventDisableTiming));
     }
     if ((st = dmalloc(&e->upDev, e->upBytes))) return st;
-    if ((st = make_event(&e->evUploaded)) || (st = make_event(&e->evIngested))) return st;
+    // (system scope: the two events stand between copy-engine transfers and kernels)
+    if ((st = make_event(&e->evUploaded, true)) || (st = make_event(&e->evIngested, true))) return st;
   }
   if (cBytes > e->upDepthOff || e->upDepthOff + dBytes > e->upBytes) return fail(DSR_E_ARG, "frame larger than the staging slot");
   const int s = e->upNext;
@@ -1260,10 +1278,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *ov = getenv("DSR_OVERLAP_EXPECTED")) e->overlapExpected = atoi(ov) != 0;
   if (e->overlapExpected &&
       (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evList, hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evExpected, hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evPrepareGo, hipEventDisableTiming) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evRenderDone, hipEventDisableTiming) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
+       hipEventCreateWithFlags(&e->evList, order_event_flags()) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evExpected, order_event_flags()) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evPrepareGo, order_event_flags()) != hipSuccess ||
+       hipEventCreateWithFlags(&e->evRenderDone, order_event_flags()) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
   if (const char *op = getenv("DSR_OVERLAP_PREPARE")) e->overlapPrepare = atoi(op) != 0;
   ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
@@ -1412,7 +1430,7 @@ int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 
 int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
   CHECK_E(e);
-  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, order_event_flags()));
   HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
   if (e->pipelinedView) HIP_TRY(hipStreamWaitEvent(e->viewStream, e->orderEvent, 0));  // "_dev" view inputs are read there
@@ -1421,7 +1439,7 @@ int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
 
 int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
   CHECK_E(e);
-  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, order_event_flags()));
   HIP_TRY(hipEventRecord(e->orderEvent, e->stream));
   HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->orderEvent, 0));
   if (e->pipelinedView && e->viewEventValid) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evView, 0));
@@ -2111,7 +2129,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   if (!instance->pipelinedView) {
     // (an event is created and recorded with its own stream's device current; WAITING for it works from any device)
     if (peer) HIP_TRY(hipSetDevice(instance->device));
-    if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, hipEventDisableTiming));
+    if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, instance->device != e->device ? hipEventDisableTiming : order_event_flags()));
     HIP_TRY(hipEventRecord(instance->xEvent, instance->stream));
     if (peer) HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamWaitEvent(ws, instance->xEvent, 0));
@@ -2143,7 +2161,12 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   }
   // the instance's side: its "view written" event is recorded on a stream of ITS device (its view stream / its only stream),
   // behind a wait for the main side — so every event is only ever recorded with its own device's streams
-  if (!e->xEvent2) HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, hipEventDisableTiming));
+  if (!e->xEvent2 || (instance->device != e->device && !e->xEvent2System)) {  // waited for from another GPU: system scope
+    if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
+    e->xEvent2 = nullptr;
+    e->xEvent2System = instance->device != e->device;
+    HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, e->xEvent2System ? hipEventDisableTiming : order_event_flags()));
+  }
   HIP_TRY(hipEventRecord(e->xEvent2, ws));
   if (peer) HIP_TRY(hipSetDevice(instance->device));
   int stv = DSR_OK;
