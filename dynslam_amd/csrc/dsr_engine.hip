@@ -176,6 +176,8 @@ struct dsr_engine {
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
+  bool foldScans = false;            // env DSR_FOLD_SCANS=1: the tile-sum scans run in the last workgroup of the producing sweep (k_alloc.h last_block_arrives)
+  bool fuseRender = false;           // small volumes: an uncached free-view raycast shades its pixels itself (k_raycast_render)
   // k_raycast leaves a ray after this many loop trips and k_raycast_tail resumes it, 8 lanes per ray (k_raycast.h); 0: one kernel.
   // OFF by default: measured on the bench workload (profiles/r04c_raycast_split_kernels_ab.log) the pair costs what the one
   // kernel costs at every cut — K = 64: 285 + 160 us against 444 — the work moves, the critical path does not get shorter
@@ -758,19 +760,31 @@ int allocate_scene(dsr_engine *e) {
   if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
   LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
          (const int4 *)rs.visBlocks, rs.visType);
-  LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
-         (const float *)e->depth, rs.visType);
-  // (up to here the frame has only READ the scene and written allocation scratch: it may run under the previous frame's raycast)
-  { int st = wait_render(e); if (st) return st; }
   int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
-  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
+  if (e->foldScans) {
+    // (the folded scan updates the free-list heads: behind a Prepare on the side stream that may still run)
+    { int st = wait_render(e); if (st) return st; }
+    LAUNCH(e, "alloc_mark", k_alloc_mark<true>, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
+           (const float *)e->depth, rs.visType, e->numTilesE);
+  } else {
+    LAUNCH(e, "alloc_mark", k_alloc_mark<false>, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
+           (const float *)e->depth, rs.visType, e->numTilesE);
+    // (up to here the frame has only READ the scene and written allocation scratch: it may run under the previous frame's raycast)
+    { int st = wait_render(e); if (st) return st; }
+    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
+  }
   LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, allocTile, e->allocWork);
   LAUNCH(e, "alloc_apply", k_alloc_apply, dim3(256), dim3(256), p, e->scene, (const float *)e->depth,
          (const int4 *)e->allocWork, rs.visType);
-  LAUNCH(e, "visible_count", (k_visible_count<false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
-         e->tileSums);
-  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
-         (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+  if (e->foldScans) {
+    LAUNCH(e, "visible_count", (k_visible_count<false, true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
+           e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+  } else {
+    LAUNCH(e, "visible_count", (k_visible_count<false, false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
+           e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+           (int)SCAN_VISIBLE_LIVE, e->noBlocks);
+  }
   if (e->statusDev) e->statusSeq++;
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
          (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks, e->statusDev,
@@ -1249,6 +1263,11 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (const char *gt = getenv("DSR_GRID_RAYCAST_TAIL")) e->gridRaycastTail = std::max(1, atoi(gt));
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
+  // (measured on an instance volume, profiles/r04i_instance_frame_fold_fuse_ab.log: three launches fewer, but the release every
+  //  wave of the producing sweep pays takes k_alloc_mark from 20 to 124 us and k_visible_count from 8 to 33 — off; kept for tests)
+  if (const char *fs = getenv("DSR_FOLD_SCANS")) e->foldScans = atoi(fs) != 0;
+  e->fuseRender = e->smallVolume;
+  if (const char *fr = getenv("DSR_FUSE_RENDER")) e->fuseRender = atoi(fr) != 0;
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
@@ -1785,16 +1804,36 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         // FindVisibleBlocks by ONE sweep over the table (frustum test inside) + ordered compaction: 3 launches where the
         // cached list of allocated entries below takes 7 — that list pays when a large, unchanged map is rendered from
         // several cameras; an instance volume changes every frame and its table sweep is a few microseconds
-        LAUNCH(e, "freeview_visible", (k_visible_count<true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
-               e->tileSums);
-        LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
-               (int)SCAN_VISIBLE_FREE, e->noBlocks);
+        if (e->foldScans) {
+          LAUNCH(e, "freeview_visible", (k_visible_count<true, true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
+                 rs.visType, e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_FREE, e->noBlocks);
+        } else {
+          LAUNCH(e, "freeview_visible", (k_visible_count<true, false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
+                 rs.visType, e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_FREE, e->noBlocks);
+          LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+                 (int)SCAN_VISIBLE_FREE, e->noBlocks);
+        }
         LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
                (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0, rs.visBlocks, (int32_t *)nullptr, 0);
         int st = expected_depths(e, rs, p);
         if (st) return st;
-        launch_raycast(e, "raycast_freeview", p, rs);
         e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+        if (e->fuseRender && e->raycastSplit <= 0) {
+          // the raycast shades its own pixels (k_raycast_render): one launch less in an instance volume's frame
+          if (outIsDevice) {
+            LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
+                   rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
+            HIP_TRY(hipGetLastError());
+            break;
+          }
+          LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
+                 rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+          HIP_TRY(hipGetLastError());
+          if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
+          if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
+          break;
+        }
+        launch_raycast(e, "raycast_freeview", p, rs);
       } else if (!cached) {
       // FindVisibleBlocks: the allocated entries (ascending list, rebuilt when the scene has changed)
       // are tested densely against the free camera's frustum, the visible ones compacted in order

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
     // (16 cells) nearly every block took the wave-cooperative path below — 64 SEQUENTIAL rounds of seven cross-lane
     // broadcasts per wave (measured: ~28 us for 539 blocks).  Here the owning lane fills boxes of up to 144 cells itself
     // (fire-and-forget LDS atomics, ~10 cycles a cell) and only a block right in front of the camera is shared.
-    // (Reading the cell first to skip atomics that cannot change it was measured too: slower, 35 us — the read's latency.)
+    // (Reading the cell first to skip atomics that cannot change it was measured too: slower, 35 us — the read's latency.
+    //  Eight lanes per block, every eighth cell of the box each — 128 blocks per pass of the workgroup — was measured in round 4:
+    //  28 us per launch against 19.6, the passes and the index arithmetic cost more than the short boxes save.)
     const bool big = valid && bw * bh > 144;
     auto fold = [&](int idx, int zmn, int zmx) {
       atomicMin(&cellsLds[idx].x, zmn);
@@ -991,6 +993,31 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
   if (x >= p.W || y >= p.H) return;
   const int locId = x + y * p.W;
   const float4 pt = pointsRay[locId];
+  const uchar4 out = render_pixel<DeviceOps>(p, s, type, pt, s_blocks[threadIdx.x]);
+  if (outRgba) outRgba[locId] = out;
+  if (outRgba2) outRgba2[locId] = out;
+  if (outDepth) outDepth[locId] = render_depth(p, pt);
+}
+
+// A free-view raycast that shades its own pixels (small volumes, round 4): an instance's preview was raycast + render, two
+// launches of a frame that is a chain of ~20 launches of a few microseconds — the render only ever looks at its own pixel's
+// ray.  The ray is k_raycast's plain path (same functions, same result, still written to raycastResult for later renders of
+// the same pose), the shading is k_render's.  Measured on an instance volume (profiles/r04i_instance_frame_fold_fuse_ab.log):
+// 34.4 + 12.2 us as two launches, 38.1 us as one.
+__global__ __launch_bounds__(256) void k_raycast_render(FrameP p, SceneP s, const float2 *__restrict__ minmax,
+                                                        float4 *__restrict__ raycastResult, int type, uchar4 *__restrict__ outRgba,
+                                                        float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2) {
+  __shared__ int s_blocks[256][9];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= p.W || y >= p.H) return;
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];
+  RC_STAT(RcStats st;)
+  const float4 pt = cast_ray<DeviceOps>(p, s, x, y, mm RC_STAT(, st));
+  const int locId = x + y * p.W;
+  raycastResult[locId] = pt;
   const uchar4 out = render_pixel<DeviceOps>(p, s, type, pt, s_blocks[threadIdx.x]);
   if (outRgba) outRgba[locId] = out;
   if (outRgba2) outRgba2[locId] = out;

@@ -377,7 +377,11 @@ def test_free_view_cache(hip_api):
                                  dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_RAYCAST_SPLIT="5"),
                                  dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="0"), dict(DSR_PIPELINED_VIEW="0"),
                                  # k_integrate with the wave-uniform x terms of the camera transform through LDS
-                                 dict(DSR_INTEGRATE_XLDS="1"), dict(DSR_INTEGRATE_XLDS="1", DSR_GRID_INTEGRATE="3")])
+                                 dict(DSR_INTEGRATE_XLDS="1"), dict(DSR_INTEGRATE_XLDS="1", DSR_GRID_INTEGRATE="3"),
+                                 # the tile-sum scans in the last workgroup of the producing sweep (opt-in) and the free-view raycast
+                                 # that shades its own pixels (the default of small volumes): on and off, large volume and small
+                                 dict(DSR_FOLD_SCANS="1"), dict(DSR_SMALL_VOLUME="1", DSR_FOLD_SCANS="0", DSR_FUSE_RENDER="0"),
+                                 dict(DSR_SMALL_VOLUME="1", DSR_FOLD_SCANS="1", DSR_FUSE_RENDER="1", DSR_RAYCAST_SPLIT="4")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
