@@ -109,6 +109,23 @@ def pmc_traffic(args, kernel, visible_blocks_per_launch):
     return None, None
 
 
+class _no_gc:
+    """The timed region runs with Python's cyclic collector paused: with torch imported a full collection walks a million objects
+    (40+ ms — longer than 35 steps of enqueueing) and where it lands is a matter of allocation counts: the no-flag 45-step run
+    read 485 frames/s with ONE such pause inside its timed loop, 880 without (profiles/r04x_bench_default.json: step 4 enqueued
+    after 43.75 ms).  Nothing is skipped: collection happens before the region and resumes after it."""
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+
+
 def settings_kwargs(preset):
     kw = dict(PRESETS[preset])
     kw.update(max_w=100, view_frustum_min=0.2, view_frustum_max=30.0)
@@ -216,6 +233,9 @@ def through_shim(frames, w, h, intr, kw, warmup, frames_instances=None):
         return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from bench_through_shim import run
+    r2 = None
+    if frames_instances is not None and os.environ.get("DSR_BENCH_SHIM_ORDER") == "configs2-first":  # diagnostic: which leg runs behind which
+        r2 = run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
     r = run(exe, frames, w, h, intr, kw, warmup)
     out = {"frames_per_s": float(r["frames_per_s"]), "ms_per_frame": float(r["ms_per_frame"]), "host": "shim/host_bench.cpp (C++)",
            "note": "same frames and table sizes, handed over as pageable host BGR + int16 buffers through shim/ITMLib.h: the frame "
@@ -223,7 +243,7 @@ def through_shim(frames, w, h, intr, kw, warmup, frames_instances=None):
                    "InfiniTamDriver::UpdateView / Integrate / PrepareNextStep ask for them (PCIe inclusive)"}
     if frames_instances is not None:  # configs[2] through the reference's call pattern: the map + 4 instance drivers, every call of every driver
         try:
-            r2 = run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
+            r2 = r2 or run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
             out["configs2"] = {"frames_per_s": float(r2["frames_per_s"]), "ms_per_frame": float(r2["ms_per_frame"]),
                                "note": "static map + 4 instance volumes (shim/host_bench --masks): GPU view split, per driver and frame one "
                                        "allocation status and two previews back to the host"}
@@ -551,12 +571,13 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
         if getattr(scene, "after_warmup", None):
             scene.after_warmup()
         barrier()
-        t0 = time.perf_counter()
-        for i in range(Wm, Wm + K):
-            step(i)
-        t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (nothing has been waited for yet)
-        barrier()
-        return time.perf_counter() - t0, t_enq
+        with _no_gc():
+            t0 = time.perf_counter()
+            for i in range(Wm, Wm + K):
+                step(i)
+            t_enq = time.perf_counter() - t0  # host time to enqueue the K steps (nothing has been waited for yet)
+            barrier()
+            return time.perf_counter() - t0, t_enq
 
     scene = ShardedScene(make_engine, W, H, V, world, rank, dev, has_static=has_static)
     scene.exchange.host_api = host_api
@@ -789,11 +810,14 @@ def run_rank(args):
         eng.profile_enable(1 if args.profile_all else 2)
         eng.profile_reset()
     barrier()
-    t0 = time.perf_counter()
-    for i in range(Wm, Wm + K):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    enq = []  # DSR_BENCH_STEP_TIMES=1: when the host had enqueued each step (ms since t0) — a diagnostic, not part of the contract
+    with _no_gc():
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            step(i)
+            enq.append(round(1e3 * (time.perf_counter() - t0), 3))
+        barrier()
+        elapsed = time.perf_counter() - t0
     prof = eng.profile_get() if not args.no_profile else []
     eng.profile_enable(False)
     stats = eng.get_stats()
@@ -827,6 +851,8 @@ def run_rank(args):
                        "status": stats.sticky_status, "decay": bool(args.decay), "swap": bool(args.swap), "instances": args.instances},
             "roofline": roofline, "cpu_baseline": cpu, "through_shim": None, "kernels": kernels,
         }
+        if os.environ.get("DSR_BENCH_STEP_TIMES"):
+            out["step_enqueued_ms"] = enq
     for ie in inst_eng:
         ie.close()
     eng.close()
