@@ -222,28 +222,37 @@ def cpu_baseline_volumes(frames, w, h, n_volumes, has_static, preset, budget_s):
                       f"oracle/dsr_oracle.cpp with OpenMP on {cores} threads, {t_total:.1f} s"}
 
 
-def through_shim(frames, w, h, intr, kw, warmup, frames_instances=None):
+def through_shim(args, with_instances):
     """SURVEY 8d "through-shim" rate: the C++ host shim/host_bench (our driver class over shim/ITMLib.h, the
     ITMLib names DynSLAM's InfiniTamDriver uses) fed with the SAME frames as pageable host buffers; per frame
     it pays what DynSLAM's host pays around the engine: BGR->RGBA conversion, the H2D copy of the frame,
     ProcessFrame, one status / noVisibleBlocks synchronisation, Prepare, the two preview conversions with their
-    D2H copies.  PCIe inclusive — never `value`."""
+    D2H copies.  PCIe inclusive — never `value`.
+    Each leg is tools/bench_through_shim.py run as a process of its own (it generates the same frames, writes them to /dev/shm and
+    starts the C++ host): started from THIS process the identical host_bench command line on the identical input files read
+    223-275 frames/s for configs[2] where the tool reads 439-460 on the same box (profiles/r04t_cfg2_through_host_where.log;
+    configs[1] reads the same either way) — not understood yet, so the line reports what the tool measures."""
     exe = os.path.join(ROOT, "shim", "host_bench")
     if not os.path.exists(exe):
         return None
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from bench_through_shim import run
-    r2 = None
-    if frames_instances is not None and os.environ.get("DSR_BENCH_SHIM_ORDER") == "configs2-first":  # diagnostic: which leg runs behind which
-        r2 = run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
-    r = run(exe, frames, w, h, intr, kw, warmup)
+    import ast
+    import subprocess
+
+    def leg(instances):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_through_shim.py"), "--preset", args.preset, "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--width", str(args.width), "--height", str(args.height)]
+        if instances:
+            cmd += ["--instances", str(instances)]
+        lines = subprocess.check_output(cmd, timeout=900, stderr=subprocess.DEVNULL).decode().strip().splitlines()
+        return ast.literal_eval(lines[-1])
+    r = leg(0)
     out = {"frames_per_s": float(r["frames_per_s"]), "ms_per_frame": float(r["ms_per_frame"]), "host": "shim/host_bench.cpp (C++)",
            "note": "same frames and table sizes, handed over as pageable host BGR + int16 buffers through shim/ITMLib.h: the frame "
                    "upload (BGR -> RGBA in the ingest kernel), the allocation status and both previews per frame, as "
                    "InfiniTamDriver::UpdateView / Integrate / PrepareNextStep ask for them (PCIe inclusive)"}
-    if frames_instances is not None:  # configs[2] through the reference's call pattern: the map + 4 instance drivers, every call of every driver
+    if with_instances:  # configs[2] through the reference's call pattern: the map + 4 instance drivers, every call of every driver
         try:
-            r2 = r2 or run(exe, frames_instances, w, h, intr, kw, warmup, instances=4)
+            r2 = leg(4)
             out["configs2"] = {"frames_per_s": float(r2["frames_per_s"]), "ms_per_frame": float(r2["ms_per_frame"]),
                                "note": "static map + 4 instance volumes (shim/host_bench --masks): GPU view split, per driver and frame one "
                                        "allocation status and two previews back to the host"}
@@ -718,14 +727,24 @@ def run_rank(args):
     if legs:
         return main_volumes(args, legs)
 
-    # synthetic frames first: the worker pool forks, which must happen before HIP / RCCL start
+    # The C++ host (SURVEY 8d "through-shim") first, as processes of their own, before this process has generated a frame or
+    # opened the device (the state in which profiles/r04s_through_shim_via_tool.log was measured).
+    shim = None
+    if (int(os.environ.get("RANK", "0")) == 0 and world_env == 1 and not args.no_through_shim
+            and not (args.decay or args.swap or args.instances or args.host_views)):
+        try:
+            shim = through_shim(args, with_instances=args.preset == "5mm")
+        except Exception as ex:
+            shim = {"frames_per_s": None, "note": f"failed: {ex}"}
+
+    # synthetic frames: the worker pool forks, which must happen before HIP / RCCL start
     frames = frames_for(args, args.instances)
     # the N = 1 line also carries north_star's scaling workload (8 instance volumes) on this one GPU: the N = 1 point of the curve
     # whose N > 1 points are `python bench.py --gpus N`
     scaling_leg = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_scaling_leg and args.preset == "5mm"
                    and not (args.decay or args.swap or args.instances or args.host_views))
     frames8 = frames_for(args, SCALING_VOLUMES) if scaling_leg else None
-    frames4 = frames_for(args, 4) if (scaling_leg and not args.no_through_shim) else None  # configs[2] through the C++ host
+
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -857,17 +876,7 @@ def run_rank(args):
         ie.close()
     eng.close()
     if rank == 0:
-        # the C++ host runs as a process of its own, AFTER this process has given its engines (streams, 32 GiB of voxels) back: with
-        # this process's queues still open the two processes' hardware queues are time-multiplexed (configs[2]'s five engines:
-        # 229 instead of 459 frames/s, profiles/r04f_bench_line.json)
-        shim = None
-        if (not args.no_through_shim and world == 1 and not (args.decay or args.swap or args.instances or args.host_views)):
-            torch.cuda.synchronize()
-            try:
-                shim = through_shim(frames, W, H, sc.intrinsics(), kw, Wm, frames4)
-            except Exception as ex:
-                shim = {"frames_per_s": None, "note": f"failed: {ex}"}
-        out["through_shim"] = shim
+        out["through_shim"] = shim  # measured before this process opened the device (above)
         if scaling_leg:
             try:
                 calib = make_calib(*sc.intrinsics(), W, H)
