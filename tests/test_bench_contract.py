@@ -216,3 +216,55 @@ def test_cli_gpus_2_with_hip_engines_on_one_gpu(hip_api):
     assert line["config"]["status"] == 0 and line["config"]["preview_hit_fraction"] > 0.001
     assert line["time_sliced_1gpu"]["value"] > 0 and line["configs3"]["config"]["static_visible_blocks_last_frame"] > 100
     assert line["configs3"]["config"]["preview_hit_fraction"] > 0.3
+
+
+def test_through_shim_legs_are_the_stand_alone_tool(monkeypatch):
+    """bench.py's through-shim legs are `tools/bench_through_shim.py` run as processes of their own (the same host
+    command read half the rate for configs[2] when bench.py's own process started it): the command lines carry the job's sizes,
+    the tool's last line is what the keys are made of, a failing configs[2] leg does not take the configs[1] figure down."""
+    import subprocess
+    calls = []
+
+    def fake(cmd, **kw):
+        calls.append(cmd)
+        if "--instances" in cmd:
+            if os.environ.get("FAKE_CFG2_FAILS"):
+                raise subprocess.CalledProcessError(1, cmd)
+            return b"noise\n{'driver': 'shim', 'frames_per_s': '458.312', 'ms_per_frame': '2.1819'}\n"
+        return b"{'driver': 'shim', 'frames_per_s': '852.78', 'ms_per_frame': '1.1726'}\n"
+    monkeypatch.setattr(subprocess, "check_output", fake)
+    monkeypatch.setattr(os.path, "exists", lambda p: True)
+    a = bench.parse_args(["--steps", "20", "--warmup", "5"])
+    r = bench.through_shim(a, True)
+    assert r["frames_per_s"] == 852.78 and r["configs2"]["frames_per_s"] == 458.312 and r["configs2"]["ms_per_frame"] == 2.1819
+    assert all(c[1].endswith(os.path.join("tools", "bench_through_shim.py")) for c in calls) and len(calls) == 2
+    assert calls[0][calls[0].index("--steps") + 1] == "20" and calls[0][calls[0].index("--warmup") + 1] == "5"
+    assert "--instances" not in calls[0] and calls[1][calls[1].index("--instances") + 1] == "4"
+    assert "configs2" not in bench.through_shim(a, False)
+    monkeypatch.setenv("FAKE_CFG2_FAILS", "1")
+    r = bench.through_shim(a, True)
+    assert r["frames_per_s"] == 852.78 and r["configs2"]["frames_per_s"] is None and "failed" in r["configs2"]["note"]
+    json.dumps(r)
+
+
+def test_timed_regions_run_with_the_cyclic_collector_paused():
+    """A full collection inside the timed loop cost the no-flag run 44 ms: the collector is paused for the region
+    and back afterwards, also when the region raises."""
+    import gc
+    assert gc.isenabled()
+    with bench._no_gc():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with bench._no_gc():
+            raise RuntimeError("step failed")
+    except RuntimeError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with bench._no_gc():
+            pass
+        assert not gc.isenabled()  # a caller that runs without the collector keeps running without it
+    finally:
+        gc.enable()
