@@ -38,6 +38,8 @@
 #include <memory>
 #include <vector>
 
+#include <sched.h>  // sched_getcpu: where the host thread ran (diagnostic keys of the output line)
+
 #ifdef DSR_HOST_REFERENCE_DRIVER
 #include "InfiniTamDriver.h"  // the reference's own header (-I /root/reference/src/DynSLAM)
 using RefDriver = dynslam::drivers::InfiniTamDriver;
@@ -279,9 +281,20 @@ int main(int argc, char **argv) {
       }
     };
 #endif
+    // where the host's time goes, per call site, over the timed frames (diagnostic keys host_ms_*: a clock read per call)
+    enum { H_UPDATE, H_SPLIT, H_INST_INTEGRATE, H_INST_PREPARE, H_INTEGRATE, H_PREPARE, H_N };
+    double hostMs[H_N] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](std::chrono::steady_clock::time_point &from, int slot, bool timed) {
+      const auto now = std::chrono::steady_clock::now();
+      if (timed) hostMs[slot] += std::chrono::duration<double, std::milli>(now - from).count();
+      from = now;
+    };
+    const int cpuFirst = sched_getcpu();
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < nFrames; i++) {
       if (i == warmup) t0 = std::chrono::steady_clock::now();
+      const bool timed = i >= warmup;
+      auto tl = std::chrono::steady_clock::now();
       const float *T = &poses[(size_t)i * 16];
 #ifdef DSR_HOST_REFERENCE_DRIVER
       std::memcpy(rgbCv.data, bgr[i].data(), P * 3);
@@ -290,10 +303,12 @@ int main(int argc, char **argv) {
       for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) pose(r, c) = T[r * 4 + c];
       drv.UpdateView(rgbCv, depthCv);
       drv.SetPose(pose);
+      lap(tl, H_UPDATE, timed);
 #else
       Matrix4f invM;
       for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) invM.at(c, r) = T[r * 4 + c];
       drv.UpdateView(bgr[i].data(), dep[i].data());
+      lap(tl, H_UPDATE, timed);
       for (const auto &m : masks[i]) {  // the view split of InstanceReconstructor::ProcessFrame (:238-263), on the GPU
         HostDriver &id = *inst[m.k];
         ITMLib::Engine::dsr_throw(dsr_view_extract_silhouette(drv.GetDsrEngine(), id.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh));
@@ -302,14 +317,19 @@ int main(int argc, char **argv) {
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) rel.at(c, r) = m.rel[r * 4 + c];
         id.AdoptDeviceView();
         id.SetPose(rel);
+        lap(tl, H_SPLIT, timed);
         id.Integrate();
+        lap(tl, H_INST_INTEGRATE, timed);
         id.PrepareNextStep();
+        lap(tl, H_INST_PREPARE, timed);
       }
       drv.SetPose(invM);
 #endif
       drv.Integrate();
+      lap(tl, H_INTEGRATE, timed);
       drv.PrepareNextStep();
       drv.Decay();
+      lap(tl, H_PREPARE, timed);
 #ifndef DSR_HOST_REFERENCE_DRIVER
       if (previewEveryFrame && masksPath) {
         Matrix4f Mv;
@@ -374,7 +394,7 @@ int main(int argc, char **argv) {
     }
     if (xch) dsr_exchange_destroy(xch);
 #endif
-    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu instances=%d inst_used_bytes=%zu composite_hash=%016llx ranks=%d hash=%016llx\n",
+    printf("driver=%s frames=%d timed=%d frames_per_s=%.3f ms_per_frame=%.4f used_bytes=%zu saved_bytes=%zu instances=%d inst_used_bytes=%zu composite_hash=%016llx ranks=%d hash=%016llx",
 #ifdef DSR_HOST_REFERENCE_DRIVER
            "reference",
 #else
@@ -382,6 +402,12 @@ int main(int argc, char **argv) {
 #endif
            nFrames, nFrames - warmup, (nFrames - warmup) / secs, 1e3 * secs / (nFrames - warmup), used, drv.GetSavedDecayMemoryBytes(),
            nInstances, instUsed, compositeHash, (int)(devices.empty() ? 1 : devices.size()), (unsigned long long)h);
+    {
+      const int nTimed = nFrames - warmup > 0 ? nFrames - warmup : 1;
+      printf(" host_ms_update=%.4f host_ms_split=%.4f host_ms_inst_integrate=%.4f host_ms_inst_prepare=%.4f host_ms_integrate=%.4f host_ms_prepare=%.4f cpu=%d-%d\n",
+             hostMs[H_UPDATE] / nTimed, hostMs[H_SPLIT] / nTimed, hostMs[H_INST_INTEGRATE] / nTimed, hostMs[H_INST_PREPARE] / nTimed,
+             hostMs[H_INTEGRATE] / nTimed, hostMs[H_PREPARE] / nTimed, cpuFirst, sched_getcpu());
+    }
   } catch (const std::exception &ex) {
     fprintf(stderr, "error: %s\n", ex.what());
     return 1;
