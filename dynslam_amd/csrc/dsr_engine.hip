@@ -546,7 +546,9 @@ int io_stream(dsr_engine *e, hipStream_t *out) {
 // Events that only order one stream of a GPU after another stream of the SAME GPU need a device-scope release; HIP's default is a
 // system-scope one (the XCD L2s written back and invalidated for the host's sake) at every record — there are 6-8 such records in
 // an instance volume's frame.  Events the HOST waits on before reading pinned memory (preview read-backs, the host store's
-// counter) and events waited for from another GPU keep the default.  env DSR_EVENT_SYSTEM_SCOPE=1: the default everywhere.
+// counter), events that stand between kernels and COPY-ENGINE transfers (the view event the I/O stream's read-backs wait for, the
+// upload events), events handed to streams that are not ours (dsr_wait_for_stream / dsr_stream_wait_for_engine) and events waited
+// for from another GPU keep the default.  env DSR_EVENT_SYSTEM_SCOPE=1: the default everywhere.
 unsigned order_event_flags() {
   static const bool sys = getenv("DSR_EVENT_SYSTEM_SCOPE") != nullptr && atoi(getenv("DSR_EVENT_SYSTEM_SCOPE")) != 0;
   return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
@@ -570,7 +572,7 @@ int view_written(dsr_engine *e, hipStream_t stream) {
     e->viewEventValid = false;
     return DSR_OK;
   }
-  int st = make_event(&e->evView);
+  int st = make_event(&e->evView, true);  // system scope: what waits for it on the I/O stream are copy-engine reads of the view
   if (st) return st;
   HIP_TRY(hipEventRecord(e->evView, stream));
   e->viewEventValid = true;
@@ -579,7 +581,7 @@ int view_written(dsr_engine *e, hipStream_t stream) {
 // the I/O stream becomes a reader of e's view as it is after everything queued so far that writes it
 int io_reads_view(dsr_engine *e, hipStream_t io) {
   if (!e->viewEventValid) {  // no record at write time (see view_written): after everything queued on the engine's streams so far
-    int st = make_event(&e->evView);
+    int st = make_event(&e->evView, true);
     if (st) return st;
     HIP_TRY(hipEventRecord(e->evView, e->stream));
     e->viewEventValid = true;
@@ -1449,7 +1451,7 @@ int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 
 int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
   CHECK_E(e);
-  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, order_event_flags()));
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));  // system scope: the other side is not ours
   HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
   if (e->pipelinedView) HIP_TRY(hipStreamWaitEvent(e->viewStream, e->orderEvent, 0));  // "_dev" view inputs are read there
@@ -1458,7 +1460,7 @@ int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
 
 int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
   CHECK_E(e);
-  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, order_event_flags()));
+  if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));  // system scope: the other side is not ours
   HIP_TRY(hipEventRecord(e->orderEvent, e->stream));
   HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->orderEvent, 0));
   if (e->pipelinedView && e->viewEventValid) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evView, 0));
