@@ -1,5 +1,5 @@
 # One box, the instance-frame tool at several commits (worktrees under build_variants/, built beforehand): which change moved
-# the free-running frame.  bash tools/gpu_call_bisect.sh <tag> <sha>...
+# the free-running frame.  bash tools/round4_gpu_calls/gpu_call_bisect.sh <tag> <sha>...
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
