@@ -53,7 +53,6 @@ enum Ctr {
   CTR_SWAP_FIRST_SLOT = 15,   // first host slot of the running swap-out batch
   CTR_NO_ALLOCATED = 16,      // length of the cached list of allocated entries (free-view culling)
   CTR_VIS_OVERFLOW = 17,      // the live visible list was cut at its capacity: entries of type 3 exist outside the list (k_alloc.h K0b)
-  CTR_SCAN_TICKET = 18,       // workgroups of the running sweep that have delivered their tile sum (k_alloc.h last_block_arrives)
   CTR_COUNT = 32
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)

@@ -169,27 +169,10 @@ struct dsr_engine {
   // for small volumes.
   // env DSR_GRID_INTEGRATE overrides.
   int gridIntegrate = 8192;
-  // k_integrate<..., XLDS>: the wave-uniform x terms of the camera transform through LDS (k_integrate.h): 562 -> 540-545 us on the
-  // bench workload, bit-identical (profiles/r04b_integrate_xlds_ab.log).  env DSR_INTEGRATE_XLDS=0: the round-3 kernel.
-  bool integrateXLds = true;
   // a volume of instance size (7142 blocks in the reference, InstanceReconstructor.cpp:379): its frames are bound by the number
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
-  bool foldScans = false;            // env DSR_FOLD_SCANS=1: the tile-sum scans run in the last workgroup of the producing sweep (k_alloc.h last_block_arrives)
-  bool fuseRender = false;           // small volumes: an uncached free-view raycast shades its pixels itself (k_raycast_render)
-  // k_raycast leaves a ray after this many loop trips and k_raycast_tail resumes it, 8 lanes per ray (k_raycast.h); 0: one kernel.
-  // OFF by default: measured on the bench workload (profiles/r04c_raycast_split_kernels_ab.log) the pair costs what the one
-  // kernel costs at every cut — K = 64: 285 + 160 us against 444 — the work moves, the critical path does not get shorter
-  // (DESIGN.md 6.3).  env DSR_RAYCAST_SPLIT=K enables it (the parity suite runs it at K = 1, 6, 17).
-  int raycastSplit = 0;
-  int gridRaycastTail = 2048;   // env DSR_GRID_RAYCAST_TAIL
-  float4 *tailState = nullptr;
-  int *tailPix = nullptr;
-  uint32_t *tailCount = nullptr;
-  unsigned long long raycastLaunches = 0;
-  int threadsExpected = 1024;   // ... and their size (env DSR_EXPECTED_THREADS: a multiple of 64 up to 1024)
-  bool expectedFilter = false;  // k_expected_depth_lds<FILTER> (env DSR_EXPECTED_FILTER)
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
@@ -303,16 +286,6 @@ struct dsr_engine {
   uchar4 *xferRgb = nullptr;
   float *xferDepth = nullptr;
   bool sidePending = false;          // evExpected has been recorded and not been waited for by the main stream since
-  // Prepare (raycast + ICP maps) on the SIDE stream (round 4): the last third of a raycast launch runs on a few per cent of the
-  // waves (k_raycast.h), and what the next frame does first — view ingest, the frustum re-test of the visible list, the
-  // per-pixel allocation mark — only READS the scene: it runs on the engine's stream under that tail, and the first kernel that
-  // modifies anything the raycast reads (the allocation's scan / commit) waits for evRenderDone.  Same policy as the range image:
-  // volumes of at least 2^20 blocks that have the GPU to themselves.  MEASURED AND OFF BY DEFAULT (profiles/r04c_overlap_prepare_ab.log):
-  // the kernels do overlap, and the raycast pays for it — 422 -> 444 us, 1.121 -> 1.130 ms per frame, the result round 1 got with a
-  // second stream for the prefix.  env DSR_OVERLAP_PREPARE=1 enables it (the parity suite does).
-  bool overlapPrepare = false;
-  hipEvent_t evPrepareGo = nullptr, evRenderDone = nullptr;
-  bool renderPending = false;
   hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
   hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
   bool xEvent2System = false;        // ... created with a system-scope release (an instance on another GPU has waited for it)
@@ -417,10 +390,7 @@ void depth_proj(const dsr_engine *e, float proj[4]) {
   proj[0] = e->calib.depth.fx; proj[1] = e->calib.depth.fy; proj[2] = e->calib.depth.cx; proj[3] = e->calib.depth.cy;
 }
 
-int wait_render(dsr_engine *e);
-
 int reset_scene(dsr_engine *e) {
-  { int st = wait_render(e); if (st) return st; }
   e->sceneVersion++;
   e->noVisibleValid = false;
   e->listVersion++;
@@ -444,6 +414,11 @@ int reset_scene(dsr_engine *e) {
   HIP_TRY(hipMemsetAsync(e->scene.allocTile, 0, ((size_t)e->numTilesE + 1) * 8, e->stream));
   e->fifoHead = 0; e->fifoLen = 0;
   HIP_TRY(hipGetLastError());
+  if (e->statusHost) {
+    // the published words describe a scene that no longer exists; the next allocation publishes number statusSeq + 1
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->statusHost[0] = 0; e->statusHost[1] = DSR_OK;
+  }
   return DSR_OK;
 }
 
@@ -468,7 +443,7 @@ void free_all(dsr_engine *e) {
     if (e->upPin[k]) (void)hipHostFree(e->upPin[k]);
     if (e->upSlotFree[k]) (void)hipEventDestroy(e->upSlotFree[k]);
   }
-  F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth); F(e->tailState); F(e->tailPix); F(e->tailCount);
+  F(e->upDev); F(e->pvDev); F(e->xferRgb); F(e->xferDepth);
   F(e->rgbAlt); F(e->depthAlt);
   for (hipEvent_t ev : {e->evAltFree, e->evFusionRead}) if (ev) (void)hipEventDestroy(ev);
   if (e->viewStream && e->ownsViewStream) (void)hipStreamDestroy(e->viewStream);
@@ -482,8 +457,6 @@ void free_all(dsr_engine *e) {
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->evList) (void)hipEventDestroy(e->evList);
   if (e->evExpected) (void)hipEventDestroy(e->evExpected);
-  if (e->evPrepareGo) (void)hipEventDestroy(e->evPrepareGo);
-  if (e->evRenderDone) (void)hipEventDestroy(e->evRenderDone);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream && e->ownsStream) (void)hipStreamDestroy(e->stream);
 }
@@ -522,23 +495,14 @@ int dmalloc(T **p, size_t n) {
 
 // ---- host buffers in and out without draining the engine's stream (see dsr_engine) ---------------------------------
 
-// Streams of small work that must not queue behind a large volume's long kernels (instance volumes, view operations, I/O):
-// created at the device's highest priority when DSR_STREAM_PRIORITY is set — the runtime keeps separate hardware queues per
-// priority, so such a stream never shares one with a map's integration (measurement knob, see DESIGN.md "through the host").
-hipError_t create_stream(hipStream_t *out, bool small) {
-  static const bool prio = getenv("DSR_STREAM_PRIORITY") != nullptr && atoi(getenv("DSR_STREAM_PRIORITY")) != 0;
-  if (prio && small) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-      return hipStreamCreateWithPriority(out, hipStreamNonBlocking, greatest);
-  }
-  return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}
+// (Round 4 measured the small streams — instance volumes, view operations, I/O — at the device's highest priority: no gain at the
+//  runtime's default number of hardware queues, profiles/r04d_through_shim_queues.log.)
+hipError_t create_stream(hipStream_t *out) { return hipStreamCreateWithFlags(out, hipStreamNonBlocking); }
 
 int io_stream(dsr_engine *e, hipStream_t *out) {
   if (e->device < 0 || e->device >= 64) return fail(DSR_E_ARG, "device ordinal beyond the I/O stream table");
   std::lock_guard<std::mutex> lock(g_ioMutex);
-  if (!g_ioStream[e->device]) HIP_TRY(create_stream(&g_ioStream[e->device], true));
+  if (!g_ioStream[e->device]) HIP_TRY(create_stream(&g_ioStream[e->device]));
   *out = g_ioStream[e->device];
   return DSR_OK;
 }
@@ -548,11 +512,8 @@ int io_stream(dsr_engine *e, hipStream_t *out) {
 // an instance volume's frame.  Events the HOST waits on before reading pinned memory (preview read-backs, the host store's
 // counter), events that stand between kernels and COPY-ENGINE transfers (the view event the I/O stream's read-backs wait for, the
 // upload events), events handed to streams that are not ours (dsr_wait_for_stream / dsr_stream_wait_for_engine) and events waited
-// for from another GPU keep the default.  env DSR_EVENT_SYSTEM_SCOPE=1: the default everywhere.
-unsigned order_event_flags() {
-  static const bool sys = getenv("DSR_EVENT_SYSTEM_SCOPE") != nullptr && atoi(getenv("DSR_EVENT_SYSTEM_SCOPE")) != 0;
-  return sys ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice);
-}
+// for from another GPU keep the default.  (Free-running instance frame 348 -> 295 us, profiles/r04g_instance_frame_sysscope.json.)
+unsigned order_event_flags() { return hipEventDisableTiming | hipEventReleaseToDevice; }
 int make_event(hipEvent_t *ev, bool hostWaits = false) {
   if (!*ev) HIP_TRY(hipEventCreateWithFlags(ev, hostWaits ? hipEventDisableTiming : order_event_flags()));
   return DSR_OK;
@@ -644,16 +605,6 @@ int after_fusion(dsr_engine *e) {
   if (e->pipelinedView && e->evFusionRead) {
     HIP_TRY(hipEventRecord(e->evFusionRead, e->stream));
     e->fusionReadDepth = e->depth;
-  }
-  return DSR_OK;
-}
-
-// the engine's stream is about to touch what a Prepare on the side stream reads or writes (table, voxels, range image, raycast
-// result, ICP maps, the tail list of the split raycast): behind it
-int wait_render(dsr_engine *e) {
-  if (e->renderPending) {
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->evRenderDone, 0));
-    e->renderPending = false;
   }
   return DSR_OK;
 }
@@ -763,30 +714,15 @@ int allocate_scene(dsr_engine *e) {
   LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
          (const int4 *)rs.visBlocks, rs.visType);
   int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
-  if (e->foldScans) {
-    // (the folded scan updates the free-list heads: behind a Prepare on the side stream that may still run)
-    { int st = wait_render(e); if (st) return st; }
-    LAUNCH(e, "alloc_mark", k_alloc_mark<true>, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
-           (const float *)e->depth, rs.visType, e->numTilesE);
-  } else {
-    LAUNCH(e, "alloc_mark", k_alloc_mark<false>, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
-           (const float *)e->depth, rs.visType, e->numTilesE);
-    // (up to here the frame has only READ the scene and written allocation scratch: it may run under the previous frame's raycast)
-    { int st = wait_render(e); if (st) return st; }
-    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
-  }
+  LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
+         (const float *)e->depth, rs.visType);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
   LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, allocTile, e->allocWork);
   LAUNCH(e, "alloc_apply", k_alloc_apply, dim3(256), dim3(256), p, e->scene, (const float *)e->depth,
          (const int4 *)e->allocWork, rs.visType);
-  if (e->foldScans) {
-    LAUNCH(e, "visible_count", (k_visible_count<false, true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
-           e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_LIVE, e->noBlocks);
-  } else {
-    LAUNCH(e, "visible_count", (k_visible_count<false, false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType,
-           e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_LIVE, e->noBlocks);
-    LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
-           (int)SCAN_VISIBLE_LIVE, e->noBlocks);
-  }
+  LAUNCH(e, "visible_count", k_visible_count<false>, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType, e->tileSums);
+  LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+         (int)SCAN_VISIBLE_LIVE, e->noBlocks);
   if (e->statusDev) e->statusSeq++;
   LAUNCH(e, "visible_write", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
          (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, (int)e->s.use_swapping, rs.visBlocks, e->statusDev,
@@ -819,16 +755,11 @@ int integrate_scene(dsr_engine *e) {
   FrameP p = make_frame_params(e, e->M_d, e->invM_d, proj);
   const bool plain = !p.depthWeighting && !p.stopAtMaxW && e->shortDivMuExact;
   { int st = before_fusion(e); if (st) return st; }
-  { int st = wait_render(e); if (st) return st; }
+  // (XLDS: the wave-uniform x terms of the camera transform through LDS, k_integrate.h — 562 -> 540-545 us on the bench workload,
+  //  bit-identical, profiles/r04b_integrate_xlds_ab.log; the round-3 form is no longer instantiated)
 #define LAUNCH_INTEGRATE(A, B, VOX, OCC)                                                                     \
-  do {                                                                                                       \
-    if (e->integrateXLds)                                                                                    \
-      LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, true>), dim3(e->gridIntegrate), dim3(256), p, e->scene, \
-             (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats); \
-    else                                                                                                     \
-      LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, false>), dim3(e->gridIntegrate), dim3(256), p, e->scene, \
-             (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats); \
-  } while (0)
+  LAUNCH(e, "integrate", (k_integrate<A, B, VOX, OCC, true>), dim3(e->gridIntegrate), dim3(256), p, e->scene, \
+         (const float *)e->depth, (const uchar4 *)e->rgb, (const int4 *)e->live.visBlocks, e->integrateStats)
 #define LAUNCH_INTEGRATE_V(VOX, OCC)                                                                         \
   do {                                                                                                       \
     if (p.rgbSame) { if (plain) LAUNCH_INTEGRATE(true, true, VOX, OCC); else LAUNCH_INTEGRATE(true, false, VOX, OCC); } \
@@ -859,12 +790,8 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
   if (ldsBytes <= 64 * 1024) {
     // range image privatised in LDS by a few large workgroups (k_raycast.h)
     ProfScope _ps(e, "expected_depth");
-    if (e->expectedFilter)
-      hipLaunchKernelGGL(k_expected_depth_lds<true>, dim3(e->gridExpected), dim3(e->threadsExpected), ldsBytes, e->stream, p, e->scene,
-                         (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
-    else
-      hipLaunchKernelGGL(k_expected_depth_lds<false>, dim3(e->gridExpected), dim3(e->threadsExpected), ldsBytes, e->stream, p, e->scene,
-                         (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
+    hipLaunchKernelGGL(k_expected_depth_lds, dim3(e->gridExpected), dim3(1024), ldsBytes, e->stream, p, e->scene,
+                       (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
   } else {
     LAUNCH(e, "expected_depth", k_expected_depth, dim3(1024), dim3(256), p, e->scene, (const int4 *)rs.visBlocks,
            rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax));
@@ -874,24 +801,7 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
 
 int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderStateDev &rs) {
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  if (e->raycastSplit > 0) {
-    // the march in two kernels (k_raycast.h "the tail of the launch taken out of the kernel"): the counters alternate between
-    // launches — k_raycast appends to tailCount[parity], k_raycast_tail reads it and clears the other one for the next launch
-    if (!e->tailState) {
-      int st = dmalloc(&e->tailState, (size_t)e->P);
-      if (st || (st = dmalloc(&e->tailPix, (size_t)e->P)) || (st = dmalloc(&e->tailCount, (size_t)2))) return st;
-      HIP_TRY(hipMemsetAsync(e->tailCount, 0, 8, e->stream));
-    }
-    uint32_t *cur = e->tailCount + (e->raycastLaunches & 1), *next = e->tailCount + ((e->raycastLaunches + 1) & 1);
-    e->raycastLaunches++;
-    LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult,
-           e->raycastSplit, e->tailState, e->tailPix, cur);
-    LAUNCH(e, "raycast_tail", k_raycast_tail, dim3(e->gridRaycastTail), dim3(256), p, e->scene, (const float2 *)rs.minmax,
-           rs.raycastResult, (const float4 *)e->tailState, (const int *)e->tailPix, (const uint32_t *)cur, next);
-    return DSR_OK;
-  }
-  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, 0,
-         (float4 *)nullptr, (int *)nullptr, (uint32_t *)nullptr);
+  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
   return DSR_OK;
 }
 
@@ -920,11 +830,12 @@ int published_status(dsr_engine *e, int *status) {
   if (!e->statusHost) return sticky_status(e, status);
   const int seq = e->statusSeq;
   for (unsigned spins = 1;; ++spins) {
-    if (__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) == seq) break;
+    // (>= in wrap-safe arithmetic: a second allocation queued before this wait has published a later number already)
+    if ((int)((unsigned)__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) - (unsigned)seq) >= 0) break;
     if ((spins & 0xfff) == 0) {
       const hipError_t q = hipStreamQuery(e->stream);
       if (q == hipSuccess) {
-        if (__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) == seq) break;
+        if ((int)((unsigned)__atomic_load_n(e->statusHost + 2, __ATOMIC_ACQUIRE) - (unsigned)seq) >= 0) break;
         return sticky_status(e, status);
       }
       if (q != hipErrorNotReady) return fail(DSR_E_DEVICE, std::string("engine stream: ") + hipGetErrorString(q));
@@ -1050,7 +961,11 @@ RcclApi *rccl_api() {
     const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char *n : paths)
       if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!api.lib) { api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+    if (!api.lib) {
+      const char *why = dlerror();  // (dlerror() clears the message: one call)
+      api.error = std::string("librccl not found: ") + (why ? why : "");
+      return;
+    }
 #define RCCL_SYM(field, name)                                                           \
     api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name));            \
     if (!api.field && api.error.empty()) api.error = std::string("librccl lacks ") + name;
@@ -1063,7 +978,9 @@ RcclApi *rccl_api() {
 }
 // RCCL prints a version banner on STDOUT when a process's first communicator comes up; a host that reports on stdout (a bench
 // line, DynSLAM's own logs piped to a tool) must not find it there: fd 1 points at stderr while the communicator is created.
+std::mutex g_stdoutSwapMutex;  // the descriptor swap is process-wide: one communicator creation at a time
 struct StdoutToStderr {
+  std::lock_guard<std::mutex> lock{g_stdoutSwapMutex};
   int saved = -1;
   StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
   ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); dup2(saved, 1); close(saved); } }
@@ -1259,22 +1176,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     e->maxSteps = (uint32_t)S;
   }
   if (const char *ge = getenv("DSR_GRID_EXPECTED")) e->gridExpected = std::max(1, atoi(ge));
-  if (const char *ef = getenv("DSR_EXPECTED_FILTER")) e->expectedFilter = atoi(ef) != 0;
-  if (const char *et = getenv("DSR_EXPECTED_THREADS")) e->threadsExpected = std::min(1024, std::max(64, (atoi(et) / 64) * 64));
-  if (const char *rs = getenv("DSR_RAYCAST_SPLIT")) e->raycastSplit = std::max(0, atoi(rs));
-  if (const char *gt = getenv("DSR_GRID_RAYCAST_TAIL")) e->gridRaycastTail = std::max(1, atoi(gt));
   e->smallVolume = s.sdf_local_block_num <= 16384;
   if (const char *sv = getenv("DSR_SMALL_VOLUME")) e->smallVolume = atoi(sv) != 0;  // tests: both paths on any volume
-  // (measured on an instance volume, profiles/r04i_instance_frame_fold_fuse_ab.log: three launches fewer, but the release every
-  //  wave of the producing sweep pays takes k_alloc_mark from 20 to 124 us and k_visible_count from 8 to 33 — off; kept for tests)
-  if (const char *fs = getenv("DSR_FOLD_SCANS")) e->foldScans = atoi(fs) != 0;
-  e->fuseRender = e->smallVolume;
-  if (const char *fr = getenv("DSR_FUSE_RENDER")) e->fuseRender = atoi(fr) != 0;
   e->gridDecay = std::min(32768, std::max(256, s.sdf_local_block_num / 16));
   if (const char *gd = getenv("DSR_GRID_DECAY")) e->gridDecay = std::max(1, atoi(gd));
   e->gridIntegrate = std::min(16384, std::max(256, s.sdf_local_block_num / 4));
   if (const char *gi = getenv("DSR_GRID_INTEGRATE")) e->gridIntegrate = std::max(1, atoi(gi));
-  if (const char *xl = getenv("DSR_INTEGRATE_XLDS")) e->integrateXLds = atoi(xl) != 0;
   Mat4 trafo; memcpy(trafo.m, calib->trafo_rgb_to_depth, sizeof trafo.m);
   if (!m4_inv(trafo, e->calibInv)) { delete e; return fail(DSR_E_ARG, "singular trafo_rgb_to_depth"); }
   e->M_d = m4_identity(); e->invM_d = m4_identity();
@@ -1286,11 +1193,11 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   auto shared_stream = [&](hipStream_t *table) -> hipStream_t {
     if (e->device < 0 || e->device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_ioMutex);
-    if (!table[e->device] && create_stream(&table[e->device], true) != hipSuccess) table[e->device] = nullptr;
+    if (!table[e->device] && create_stream(&table[e->device]) != hipSuccess) table[e->device] = nullptr;
     return table[e->device];
   };
   if (pvMode == 2 && s.sdf_local_block_num <= 16384 && (e->stream = shared_stream(g_sharedSmallStream))) e->ownsStream = false;
-  else if (create_stream(&e->stream, s.sdf_local_block_num <= 16384) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
+  else if (create_stream(&e->stream) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
   // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
   // ones, not for a map at the reference's 5 cm / 2^18 blocks, whose whole frame is 0.24 ms), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
   // map + N instance volumes is N + 1 engines — with a (high-priority) side stream per engine `bench.py --instance-volumes 8`
@@ -1300,10 +1207,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (e->overlapExpected &&
       (hipStreamCreateWithFlags(&e->sideStream, hipStreamNonBlocking) != hipSuccess ||
        hipEventCreateWithFlags(&e->evList, order_event_flags()) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evExpected, order_event_flags()) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evPrepareGo, order_event_flags()) != hipSuccess ||
-       hipEventCreateWithFlags(&e->evRenderDone, order_event_flags()) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
-  if (const char *op = getenv("DSR_OVERLAP_PREPARE")) e->overlapPrepare = atoi(op) != 0;
+       hipEventCreateWithFlags(&e->evExpected, order_event_flags()) != hipSuccess)) { free_all(e); delete e; return fail(DSR_E_DEVICE, "side stream creation failed"); }
   ALLOC(dmalloc(&e->scene.table, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.vba, (size_t)e->noBlocks * kBlockBytes));
   ALLOC(dmalloc(&e->scene.voxelAllocList, (size_t)e->noBlocks));
@@ -1363,7 +1267,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   e->pipelinedView = false;
   if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
   if (e->pipelinedView && pvMode == 2 && (e->viewStream = shared_stream(g_sharedViewStream))) e->ownsViewStream = false;
-  else if (e->pipelinedView && create_stream(&e->viewStream, true) != hipSuccess) {
+  else if (e->pipelinedView && create_stream(&e->viewStream) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
   }
   if (s.sync_status) {
@@ -1464,7 +1368,6 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream) {
   HIP_TRY(hipEventRecord(e->orderEvent, e->stream));
   HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->orderEvent, 0));
   if (e->pipelinedView && e->viewEventValid) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evView, 0));
-  if (e->renderPending) HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, e->evRenderDone, 0));
   return DSR_OK;
 }
 
@@ -1653,6 +1556,7 @@ int dsr_process_frame(dsr_engine *e) {
     if (status != DSR_OK) {
       // the fork throws per failing frame: clear the sticky word after reporting it
       (void)hipMemsetAsync(e->scene.ctr + CTR_STATUS, 0, 4, e->stream);
+      if (e->statusHost) e->statusHost[1] = DSR_OK;  // the published copy of the word just cleared
       return fail(status, status_text(status));
     }
   }
@@ -1672,32 +1576,20 @@ int dsr_prepare(dsr_engine *e) {
   } else {
     // a stale one may still be writing the image — whether or not it is still marked valid
     if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
-    { int st = wait_render(e); if (st) return st; }  // a previous Prepare on the side stream reads the image this one rewrites
     e->liveExp.valid = false;
     int st = expected_depths(e, rs, p);
     if (st) return st;
   }
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  const bool onSide = e->overlapPrepare && e->sideStream && e->evRenderDone &&
-                      (e->device >= 64 || g_enginesOnDevice[e->device].load(std::memory_order_relaxed) <= 1);
-  if (onSide) {
-    // raycast + ICP maps on the side stream, behind everything queued on the engine's stream so far (the integration); the
-    // engine's stream goes on with the next frame's read-only prefix and waits at its first write (wait_render)
-    HIP_TRY(hipEventRecord(e->evPrepareGo, e->stream));
-    HIP_TRY(hipStreamWaitEvent(e->sideStream, e->evPrepareGo, 0));
-  }
+  // (Round 4 measured the raycast + ICP maps on the side stream with the next frame's read-only prefix under them: the kernels
+  //  overlap and the raycast pays for it, 422 -> 444 us.  Archived: profiles/r05_pruned_variants.diff, r04c_overlap_prepare_ab.log.)
   {
-    StreamSwap sw(e, onSide ? e->sideStream : e->stream);
     int st = launch_raycast(e, "raycast", p, rs);
     if (st) return st;
     LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
            e->normalsMap, rs.raycastImage);
   }
   HIP_TRY(hipGetLastError());
-  if (onSide) {
-    HIP_TRY(hipEventRecord(e->evRenderDone, e->sideStream));
-    e->renderPending = true;
-  }
   return DSR_OK;
 }
 
@@ -1708,7 +1600,6 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
   e->noVisibleValid = false;
   e->listVersion++;
   if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
-  { int st = wait_render(e); if (st) return st; }
   RenderStateDev &rs = e->live;
   const int32_t *cand = nullptr;
   const int32_t *nCandPtr = nullptr;
@@ -1772,7 +1663,6 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
 static int render_common(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out,
                          void *depth_out, bool outIsDevice) {
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
-  { int st = wait_render(e); if (st) return st; }
   const hipMemcpyKind kind = outIsDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   const size_t P = (size_t)e->P;
   switch (type) {
@@ -1801,41 +1691,32 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       RenderStateDev &rs = e->freeview;
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
       const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
-                          memcmp(e->fvProj, proj, sizeof proj) == 0 && !getenv("DSR_NO_FREEVIEW_CACHE");
+                          memcmp(e->fvProj, proj, sizeof proj) == 0;
       if (!cached && e->smallVolume) {
         // FindVisibleBlocks by ONE sweep over the table (frustum test inside) + ordered compaction: 3 launches where the
         // cached list of allocated entries below takes 7 — that list pays when a large, unchanged map is rendered from
         // several cameras; an instance volume changes every frame and its table sweep is a few microseconds
-        if (e->foldScans) {
-          LAUNCH(e, "freeview_visible", (k_visible_count<true, true>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
-                 rs.visType, e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_FREE, e->noBlocks);
-        } else {
-          LAUNCH(e, "freeview_visible", (k_visible_count<true, false>), dim3(e->numTilesE), dim3(kTileThreads), p, e->scene,
-                 rs.visType, e->tileSums, e->numTilesE, (int)SCAN_VISIBLE_FREE, e->noBlocks);
-          LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
-                 (int)SCAN_VISIBLE_FREE, e->noBlocks);
-        }
+        LAUNCH(e, "freeview_visible", k_visible_count<true>, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, rs.visType, e->tileSums);
+        LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene,
+               (int)SCAN_VISIBLE_FREE, e->noBlocks);
         LAUNCH(e, "freeview_visible", k_visible_write, dim3(e->numTilesE), dim3(kTileThreads), e->E, (const uint8_t *)rs.visType,
                (const int2 *)e->tileSums, rs.visibleIDs, e->noBlocks, e->scene, 0, rs.visBlocks, (int32_t *)nullptr, 0);
         int st = expected_depths(e, rs, p);
         if (st) return st;
         e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
-        if (e->fuseRender && e->raycastSplit <= 0) {
-          // the raycast shades its own pixels (k_raycast_render): one launch less in an instance volume's frame
-          if (outIsDevice) {
-            LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-                   rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
-            HIP_TRY(hipGetLastError());
-            break;
-          }
+        // the raycast shades its own pixels (k_raycast_render): one launch less in an instance volume's frame
+        if (outIsDevice) {
           LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-                 rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
           HIP_TRY(hipGetLastError());
-          if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
-          if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
           break;
         }
-        launch_raycast(e, "raycast_freeview", p, rs);
+        LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
+               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+        HIP_TRY(hipGetLastError());
+        if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
+        if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
+        break;
       } else if (!cached) {
       // FindVisibleBlocks: the allocated entries (ascending list, rebuilt when the scene has changed)
       // are tested densely against the free camera's frustum, the visible ones compacted in order
@@ -2176,7 +2057,18 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     HIP_TRY(hipStreamWaitEvent(ws, instance->xEvent, 0));
   }
   ViewTarget t;
-  { int st = begin_view_replace(instance, ws, &t); if (st) return st; }
+  {
+    // (a pipelined instance allocates its spare view buffers and their events on first use: on ITS GPU, not on main's)
+    if (peer) HIP_TRY(hipSetDevice(instance->device));
+    if (instance->pipelinedView && !instance->rgbAlt) {
+      int st = dmalloc(&instance->rgbAlt, (size_t)instance->Wr * instance->Hr);
+      if (st || (st = dmalloc(&instance->depthAlt, (size_t)instance->P)) || (st = make_event(&instance->evAltFree, instance->device != e->device)) ||
+          (st = make_event(&instance->evFusionRead, instance->device != e->device))) { if (peer) (void)hipSetDevice(e->device); return st; }
+    }
+    if (peer) HIP_TRY(hipSetDevice(e->device));
+    int st = begin_view_replace(instance, ws, &t);
+    if (st) return st;
+  }
   uchar4 *dstRgb = t.rgb;
   float *dstDepth = t.depth;
   if (peer) {
@@ -2574,7 +2466,6 @@ int dsr_exchange_sync(dsr_exchange *x) {
 
 int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored) {
   CHECK_E(e);
-  { int st = wait_render(e); if (st) return st; }
   if (!e->scene.swapState) return fail(DSR_E_ARG, "swapping is not enabled");
   if (states) HIP_TRY(hipMemcpyAsync(states, e->scene.swapState, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
   if (has_stored) HIP_TRY(hipMemcpyAsync(has_stored, e->scene.swapStored, (size_t)e->E, hipMemcpyDeviceToHost, e->stream));
@@ -2621,7 +2512,7 @@ int dsr_mesh_free(dsr_engine *e) {
 int dsr_mesh_scene(dsr_engine *e, uint64_t *n_triangles) {
   CHECK_E(e);
   int st = dsr_mesh_free(e);
-  if (st || (st = wait_render(e))) return st;
+  if (st) return st;
   // ascending list of the allocated entries (shared with Decay(forceAllVoxels))
   LAUNCH(e, "mesh_candidates", k_allocated_count, dim3(e->numTilesE), dim3(kTileThreads), e->scene, e->E, e->tileSums);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), e->tileSums, e->numTilesE, e->scene, (int)SCAN_NCAND, e->noBlocks);
@@ -2782,16 +2673,6 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
   return DSR_OK;
 }
 
-// measurement only (tools/ab_raycast_split.py; not part of include/dsr.h): rays the last two launches of k_raycast handed to k_raycast_tail
-int dsr_debug_tail_rays(dsr_engine *e, uint32_t out[2]) {
-  CHECK_E(e);
-  out[0] = out[1] = 0;
-  if (!e->tailCount) return DSR_OK;
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  HIP_TRY(hipMemcpy(out, e->tailCount, 8, hipMemcpyDeviceToHost));
-  return DSR_OK;
-}
-
 #ifdef DSR_RAYCAST_STATS
 // measurement builds only (tools/raycast_wave_stats.py): where k_raycast writes its 12 words per wave
 int dsr_debug_raycast_stats(void *dev_buf) {
@@ -2935,7 +2816,6 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
 
 int dsr_dump_hash_table(dsr_engine *e, dsr_hash_entry *out) {
   CHECK_E(e);
-  { int st = wait_render(e); if (st) return st; }
   if (!out) return fail(DSR_E_ARG, "null");
   HIP_TRY(hipMemcpyAsync(out, e->scene.table, (size_t)e->E * sizeof(dsr_hash_entry), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2967,7 +2847,6 @@ int dsr_dump_visible_types(dsr_engine *e, uint8_t *out) {
 
 int dsr_dump_voxel_blocks(dsr_engine *e, int first_block, int n_blocks, dsr_voxel *out) {
   CHECK_E(e);
-  { int st = wait_render(e); if (st) return st; }
   if (!out || first_block < 0 || n_blocks < 0 || (long long)first_block + n_blocks > e->noBlocks) return fail(DSR_E_ARG, "bad block range");
   const int chunk = 16384;  // 64 MiB of AoS voxels per pass
   if (e->aosScratchBlocks < std::min(chunk, n_blocks)) {
@@ -2999,7 +2878,6 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result, float *points, float *normals,
                           uint8_t *raycast_image) {
   CHECK_E(e);
-  { int st = wait_render(e); if (st) return st; }
   RenderStateDev &rs = which ? e->freeview : e->live;
   const size_t P = (size_t)e->P;
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;

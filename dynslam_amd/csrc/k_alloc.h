@@ -228,7 +228,7 @@ __device__ __forceinline__ void alloc_winner_pos(const FrameP &p, const float *_
 
 // Exclusive scan of the tile sums by ONE workgroup of 1024 threads; mode selects the epilogue.
 enum ScanMode { SCAN_ALLOC = 0, SCAN_VISIBLE_LIVE = 1, SCAN_VISIBLE_FREE = 2, SCAN_DECAY = 3, SCAN_COMPACT_LIVE = 4, SCAN_NCAND = 5, SCAN_SWAP_IN = 6, SCAN_SWAP_OUT = 7, SCAN_MESH = 8, SCAN_ALLOCATED = 9 };
-// (the body, by a workgroup of NT threads: the scan launch below, or the LAST workgroup of the kernel that produced the sums)
+// (the body, by a workgroup of NT threads: the scan launch below, or a phase of the one-workgroup kernels of k_small.h)
 template <int NT>
 __device__ __forceinline__ void scan_tile_sums_body(int2 *__restrict__ tileSums, int numTiles, const SceneP &s, int mode,
                                                     int capacity, int2 *lds) {
@@ -314,45 +314,17 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
   scan_tile_sums_body<1024>(tileSums, numTiles, s, mode, capacity, lds);
 }
 
-// The scan WITHOUT its own launch (round 4, measured and left OFF: env DSR_FOLD_SCANS=1).  An instance volume's frame is a
-// chain of ~20 launches of a few microseconds each, and three of them are this one-workgroup scan between a sweep that produces
-// per-tile sums and the sweep that consumes the offsets.  Here the workgroups of the producing kernel take a ticket when their
-// sums are out, and the one that draws the last ticket runs the scan (the same body, the same arithmetic: nothing about the
-// result changes).  Every thread releases its own writes at agent scope before the workgroup's ticket is drawn (the L2s of the
-// eight XCDs are not coherent with each other inside a kernel), the last workgroup acquires before it reads the sums.  Call
-// with ALL threads of the workgroup; true in every thread of the last workgroup.  What it costs
-// (profiles/r04i_instance_frame_fold_fuse_ab.log): the release is an L2 write-back per WAVE — k_alloc_mark 20 -> 124 us,
-// k_visible_count 8 -> 33 us on an instance volume, against three ~7 us launches saved.
-__device__ __forceinline__ bool last_block_arrives(const SceneP &s) {
-  __shared__ int s_isLast;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t blocks = gridDim.x * gridDim.y * gridDim.z;
-    uint32_t *ticket = reinterpret_cast<uint32_t *>(s.ctr + CTR_SCAN_TICKET);
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_isLast = (t == blocks - 1u) ? 1 : 0;
-    if (s_isLast) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next sweep's tickets
-  }
-  __syncthreads();
-  const bool last = s_isLast != 0;
-  if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return last;
-}
+// (Round 4 measured the scan WITHOUT its own launch — the workgroups of the producing sweep draw a ticket, the last one scans:
+//  three launches fewer per instance frame and slower, because every wave pays an agent-scope release, an L2 write-back
+//  (k_alloc_mark 20 -> 124 us).  Archived: profiles/r05_pruned_fold_scans.diff, profiles/r04i_instance_frame_fold_fuse_ab.log.
+//  Instance-sized volumes now run these steps inside ONE workgroup, where a barrier is all it takes: k_small.h.)
 
-// K1, the kernel.  FOLD: the last workgroup scans the per-tile totals the marks accumulated (SCAN_ALLOC), see above.
-template <bool FOLD>
+// K1, the kernel.
 __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                    uint8_t *__restrict__ visType, int numTiles) {
+                                                    uint8_t *__restrict__ visType) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
-  if (!FOLD) {
-    if (x >= p.W || y >= p.H) return;
-    alloc_mark_pixel(p, s, depth, visType, x, y);
-  } else {
-    __shared__ int2 lds[256 / 64];
-    if (x < p.W && y < p.H) alloc_mark_pixel(p, s, depth, visType, x, y);
-    if (last_block_arrives(s)) scan_tile_sums_body<256>(reinterpret_cast<int2 *>(s.allocTile), numTiles, s, (int)SCAN_ALLOC, 0, lds);
-  }
+  if (x >= p.W || y >= p.H) return;
+  alloc_mark_pixel(p, s, depth, visType, x, y);
 }
 
 // K2: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two
@@ -521,10 +493,9 @@ __global__ __launch_bounds__(256) void k_retest_previous_visible(FrameP p, Scene
 
 // K3a (live view): count the visible entries per tile (types were settled by K0b / K1 / K2).
 // K5a (free view): visible iff ptr >= 0 and inside the frustum (FindVisibleBlocks).
-// FOLD: the last workgroup scans the tile sums (`mode`, `capacity`: k_scan_tile_sums' arguments), see last_block_arrives.
-template <bool FREEVIEW, bool FOLD>
+template <bool FREEVIEW>
 __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP s, uint8_t *__restrict__ visType,
-                                                                int2 *__restrict__ tileSums, int numTiles, int mode, int capacity) {
+                                                                int2 *__restrict__ tileSums) {
   __shared__ int2 lds[kTileThreads / 64];
   const int base = blockIdx.x * kTile + threadIdx.x * kTileItems;
   int2 c = make_int2(0, 0);
@@ -567,9 +538,6 @@ __global__ __launch_bounds__(kTileThreads) void k_visible_count(FrameP p, SceneP
   int2 total;
   wg_exclusive_scan2<kTileThreads>(c, total, lds);
   if (threadIdx.x == 0) tileSums[blockIdx.x] = total;
-  if (FOLD) {
-    if (last_block_arrives(s)) scan_tile_sums_body<kTileThreads>(tileSums, numTiles, s, mode, capacity, lds);
-  }
 }
 
 // K3b: ordered compaction -> ascending visibleEntryIDs; with swapping also the "reallocate

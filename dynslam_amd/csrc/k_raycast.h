@@ -254,8 +254,6 @@ __global__ __launch_bounds__(256) void k_expected_depth(FrameP p, SceneP s, cons
 // image in LDS, folds its share of the visible blocks into it with ds_min/ds_max (no global
 // same-address atomic traffic at all during the fold), then flushes the cells it touched with
 // filtered global atomics.  min/max are order independent, so the image is identical.
-// FILTER: read the cell first and skip the LDS atomic when it cannot change it (k_expected_depth_one below explains)
-template <bool FILTER>
 __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s, const int4 *__restrict__ visBlocks,
                                                              int ctrIdx, int2 *__restrict__ minmax) {
   extern __shared__ int2 cellsLds[];
@@ -285,15 +283,9 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
     // kernel shared with the global-atomics one, coarse voxels (5 cm: a block covers ~5 x 5 cells at 10 m) sent nearly
     // every block down that path (32 us for ~5 k blocks at the reference's own operating point)
     const bool big = valid && bw * bh > 144;
-    auto fold = [&](int idx, int zmn, int zmx) {
-      if (FILTER) {
-        const int2 cur = cellsLds[idx];
-        if (zmn < cur.x) atomicMin(&cellsLds[idx].x, zmn);
-        if (zmx > cur.y) atomicMax(&cellsLds[idx].y, zmx);
-      } else {
-        atomicMin(&cellsLds[idx].x, zmn);
-        atomicMax(&cellsLds[idx].y, zmx);
-      }
+    auto fold = [&](int idx, int zmn, int zmx) {  // (reading the cell first to skip atomics that cannot change it: slower)
+      atomicMin(&cellsLds[idx].x, zmn);
+      atomicMax(&cellsLds[idx].y, zmx);
     };
     if (valid && !big)
       for (int y = ul.y; y <= lr.y; ++y)
@@ -385,9 +377,8 @@ struct RcStats { unsigned nIter = 0, nLook = 0, nVox = 0, nBand = 0, wLook = 0, 
 #define RC_STAT(...)
 #endif
 
-// ITMVisualisationEngine.h castRay, in three parts — the ray's segment, the march, the refinement of a hit — so that the march can
-// be CUT after a number of loop trips and resumed by another kernel from the exact state (k_raycast_tail below).  cast_ray<Ops>
-// composes them into the reference's function.  (Templates over Ops only so that tests/ can run these very functions on the CPU.)
+// ITMVisualisationEngine.h castRay, in three parts — the ray's segment, the march, the refinement of a hit; cast_ray<Ops> composes
+// them into the reference's function.  (Templates over Ops only so that tests/ can run these very functions on the CPU.)
 struct RayState {
   float rx, ry, rz;       // current sample position, voxel units
   float dx, dy, dz;       // unit direction
@@ -416,11 +407,10 @@ __host__ __device__ __forceinline__ void ray_setup(const FrameP &p, int x, int y
   r.rx = sx; r.ry = sy; r.rz = sz;
 }
 
-// The while loop of castRay for at most `maxIter` trips.  Returns the sdf value of the last sample (1.0 before the first);
-// the ray is still under way — to be resumed from `r` — iff that value is > 0 and r.totalLength < r.totalLengthMax.
+// The while loop of castRay.  Returns the sdf value of the last sample (1.0 before the first).
 template <class Ops>
-__host__ __device__ __forceinline__ float ray_march(const FrameP &p, const SceneP &s, RayState &r, VoxCache &cache, VoxCache &cache2,
-                                                    int maxIter RC_STAT(, RcStats &st)) {
+__host__ __device__ __forceinline__ float ray_march(const FrameP &p, const SceneP &s, RayState &r, VoxCache &cache, VoxCache &cache2
+                                                    RC_STAT(, RcStats &st)) {
   const float stepScale = p.mu * (1.0f / p.voxelSize);
   const float dx = r.dx, dy = r.dy, dz = r.dz;
   float rx = r.rx, ry = r.ry, rz = r.rz, totalLength = r.totalLength;
@@ -429,8 +419,7 @@ __host__ __device__ __forceinline__ float ray_march(const FrameP &p, const Scene
   bool hash_found;
   uint32_t pfIdx = 0xffffffffu;  // table index of the prefetched entry
   int4 pfRaw = make_int4(0, 0, 0, -2);
-  // (the trip counter is the same number for every ray of a wave that is still in the loop: a scalar register)
-  for (int trip = 0; trip < maxIter && totalLength < totalLengthMax; ++trip) {
+  while (totalLength < totalLengthMax) {
     // (sample_sdf_march — one lookup + the 8 corner loads for every step — was measured: 937 us vs
     //  666 us.  The march is bound by gather-request throughput, not by the number of dependent
     //  phases, so the single uninterpolated load per far step stays.)
@@ -558,7 +547,7 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
   ray_setup<Ops>(p, x, y, mm, r);
   VoxCache cache; cache_init(cache);
   VoxCache cache2; cache_init(cache2);  // neighbour block of two-block trilinear cells
-  const float sdfValue = ray_march<Ops>(p, s, r, cache, cache2, 0x7fffffff RC_STAT(, st));
+  const float sdfValue = ray_march<Ops>(p, s, r, cache, cache2 RC_STAT(, st));
   return ray_finish<Ops>(p, s, r, sdfValue, cache, cache2);
 }
 
@@ -567,15 +556,12 @@ __host__ __device__ __forceinline__ float4 cast_ray(const FrameP &p, const Scene
 //  neighbouring workgroups so that rays sharing voxel and table lines share an L2: 427 / 413 / 443 vs 403 us,
 //  profiles/r03w_raycast_xcd_patches.log — the working set of a patch is far beyond 4 MB either way.)
 //
-// Round 4 — the tail of the launch taken OUT of the kernel.  What a launch is made of (profiles/r03zz_raycast_wave_stats.json):
-// a wave runs 52 loop trips on average, 92 at p90, 256 at most, and the last third of the launch runs with < 5 % of the waves —
-// rays that cross metres of empty space block by block, each trip a dependent table read.  With splitTrips > 0 a wave leaves the
-// march after that many trips; rays still under way are appended (wave ballot + ONE atomic per wave) to a compact list of
-// {pixel, position, length} and k_raycast_tail resumes them, EIGHT LANES PER RAY, probing eight empty-space steps per round.
-// Nothing about a ray's samples changes (the same sequential float additions, the same lookups): the result is bit-identical.
+// Round 4 measured the tail of the launch taken OUT of the kernel (a wave leaves the march after K trips, the rays still under way go
+// to a compact list and a second kernel resumes them with eight lanes per ray): bit-identical at every K and no faster at any
+// (K = 64: 285 + 160 us against 444 in one kernel).  The code is archived as profiles/r05_pruned_raycast_split.diff with its logs
+// (profiles/r04c_raycast_split_kernels_ab.log, r04b_raycast_split_tail_rays.log); DESIGN.md 6.3.
 __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
-                                                 float4 *__restrict__ raycastResult, int splitTrips, float4 *__restrict__ tailState,
-                                                 int *__restrict__ tailPix, uint32_t *__restrict__ tailCount) {
+                                                 float4 *__restrict__ raycastResult) {
   if (s.ctr[ctrIdx] <= 0 && ctrIdx == CTR_NO_VISIBLE_LIVE) return;  // Prepare() is skipped without visible blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wgx = blockIdx.x, wgy = blockIdx.y;
@@ -604,117 +590,8 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
     o[4] = iter; o[5] = st.wLook; o[6] = own; o[7] = look; o[8] = st.wHead; o[9] = st.wChain; o[10] = sumIter; o[11] = nLanes | (st.wBand << 8);
   }
 #else
-  RayState r;
-  ray_setup<DeviceOps>(p, x, y, mm, r);
-  VoxCache cache; cache_init(cache);
-  VoxCache cache2; cache_init(cache2);
-  const float sdfValue = ray_march<DeviceOps>(p, s, r, cache, cache2, splitTrips > 0 ? splitTrips : 0x7fffffff);
-  const bool cut = splitTrips > 0 && sdfValue > 0.0f && r.totalLength < r.totalLengthMax;  // still under way: for k_raycast_tail
-  if (!cut) raycastResult[x + y * p.W] = ray_finish<DeviceOps>(p, s, r, sdfValue, cache, cache2);
-  if (splitTrips > 0) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(cut);
-    if (m) {
-      const int first = __builtin_ctzll(m);
-      uint32_t base = 0;
-      if (lane == first) base = atomicAdd(tailCount, (uint32_t)__popcll(m));
-      base = (uint32_t)__shfl((int)base, first);
-      if (cut) {
-        const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        tailState[slot] = make_float4(r.rx, r.ry, r.rz, r.totalLength);
-        tailPix[slot] = x + y * p.W;
-      }
-    }
-  }
+  raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm);
 #endif
-}
-
-// The rays k_raycast cut: 8 lanes per ray, 8 rays per wave.  A ray in empty space advances 8 voxels per trip and every trip is a
-// dependent table read — the reference's hash chains, walked one after the other.  Here lane j of a ray's group replays j such
-// steps ARITHMETICALLY (the same sequential float additions the serial loop performs, so the same positions bit for bit), all
-// eight look their block up at once, and the first lane (in step order) whose block exists — or whose length leaves the range —
-// is where the serial loop would be after that many misses: the group takes that lane's state and goes on from there.  A found
-// block is sampled exactly like in ray_march (all eight lanes redundantly: same addresses, one request); after a found sample the
-// next trip looks at the ray's own position only (no speculation inside allocated space), after a miss it probes again.
-__global__ __launch_bounds__(256) void k_raycast_tail(FrameP p, SceneP s, const float2 *__restrict__ minmax,
-                                                      float4 *__restrict__ raycastResult, const float4 *__restrict__ tailState,
-                                                      const int *__restrict__ tailPix, const uint32_t *__restrict__ tailCount,
-                                                      uint32_t *__restrict__ nextCount) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *nextCount = 0u;  // the counter the NEXT launch of k_raycast appends to
-  const uint32_t n = *tailCount;
-  const int lane = threadIdx.x & 63, j = lane & 7, groupBase = lane & ~7;
-  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
-  const float stepScale = p.mu * (1.0f / p.voxelSize);
-  for (uint32_t ray = blockIdx.x * 32u + (threadIdx.x >> 3); ray < n; ray += gridDim.x * 32u) {
-    const int pix = tailPix[ray];
-    const float4 st = tailState[ray];
-    const int y = pix / p.W, x = pix - y * p.W;
-    RayState r;
-    ray_setup<DeviceOps>(p, x, y, minmax[(x >> 3) + (y >> 3) * mw], r);  // direction and range as k_raycast computed them
-    r.rx = st.x; r.ry = st.y; r.rz = st.z; r.totalLength = st.w;
-    const float sx = (float)kBlockSize * r.dx, sy = (float)kBlockSize * r.dy, sz = (float)kBlockSize * r.dz;  // stepLength * direction of a miss
-    VoxCache cache; cache_init(cache);
-    VoxCache cache2; cache_init(cache2);
-    float sdfValue = 1.0f;
-    bool probe = true;  // the main kernel left the ray wherever its last trip put it: look ahead from the start
-    bool done = false;
-    while (!done) {
-      // this lane's candidate: the ray's state after jj further misses
-      const int jj = probe ? j : 0;
-      float cx = r.rx, cy = r.ry, cz = r.rz, cl = r.totalLength;
-#pragma unroll
-      for (int i = 0; i < 7; ++i)
-        if (i < jj) { cx += sx; cy += sy; cz += sz; cl += (float)kBlockSize; }
-      const bool inRange = cl < r.totalLengthMax;
-      const int vx = f2i(roundf_itm(cx)), vy = f2i(roundf_itm(cy)), vz = f2i(roundf_itm(cz));
-      const int bx = vx >> 3, by = vy >> 3, bz = vz >> 3;
-      int ptr = -1;
-      if (inRange) {
-        if (bx == cache.bx && by == cache.by && bz == cache.bz) ptr = cache.ptr;
-        else {
-          int4 raw = *reinterpret_cast<const int4 *>(s.table + hash_index(bx, by, bz, p.hashMask));
-          while (true) {  // ITMRepresentationAccess.h findVoxel
-            const int hx = (short)(raw.x & 0xffff), hy = (short)((uint32_t)raw.x >> 16), hz = (short)(raw.y & 0xffff);
-            if (hx == bx && hy == by && hz == bz && raw.w >= 0) { ptr = raw.w; break; }
-            if (raw.z < 1) break;
-            raw = *reinterpret_cast<const int4 *>(s.table + (uint32_t)(p.noBuckets + raw.z - 1));
-          }
-        }
-      }
-      const bool stop = !inRange || ptr >= 0;
-      const uint32_t gm = (uint32_t)(__builtin_amdgcn_ballot_w64(stop) >> groupBase) & 0xffu;  // this ray's eight lanes
-      if (gm == 0u) {
-        // every candidate is an absent block inside the range: the serial loop would have stepped past all of them
-        const int last = groupBase + (probe ? 7 : 0);
-        r.rx = __shfl(cx, last) + sx; r.ry = __shfl(cy, last) + sy; r.rz = __shfl(cz, last) + sz;
-        r.totalLength = __shfl(cl, last) + (float)kBlockSize;
-        probe = true;
-      } else {
-        const int f = groupBase + __builtin_ctz(gm);  // the first candidate (in step order) that ends the run of misses
-        r.rx = __shfl(cx, f); r.ry = __shfl(cy, f); r.rz = __shfl(cz, f); r.totalLength = __shfl(cl, f);
-        const int fptr = __shfl(ptr, f);
-        if (fptr < 0) done = true;  // left the range without a surface (sdfValue: the last sample's, > 0)
-        else {
-          // the sample of ray_march at a block that exists
-          const int fvx = __shfl(vx, f), fvy = __shfl(vy, f), fvz = __shfl(vz, f);
-          cache.bx = fvx >> 3; cache.by = fvy >> 3; cache.bz = fvz >> 3; cache.ptr = fptr;
-          const int lin = (fvx & 7) + ((fvy & 7) << 3) + ((fvz & 7) << 6);
-          sdfValue = sdf_to_float_short((float)*reinterpret_cast<const short *>(s.vba + (size_t)fptr * kBlockBytes + kOffSdf + lin * 2));
-          if ((sdfValue <= 0.1f) && (sdfValue >= -0.5f))
-            sdfValue = sdf_to_float_short(read_sdf_interpolated_raw<DeviceOps>(s, p, r.rx, r.ry, r.rz, cache, cache2));
-          if (sdfValue <= 0.0f) done = true;
-          else {
-            const float ss = sdfValue * stepScale;
-            const float stepLength = (ss > 1.0f) ? ss : 1.0f;  // MAX(sdfValue * stepScale, 1.0f)
-            r.rx += stepLength * r.dx; r.ry += stepLength * r.dy; r.rz += stepLength * r.dz;
-            r.totalLength += stepLength;
-            probe = false;
-          }
-        }
-      }
-    }
-    const float4 out = ray_finish<DeviceOps>(p, s, r, sdfValue, cache, cache2);
-    if (j == 0) raycastResult[pix] = out;
-  }
 }
 
 // ---------------------------------------------------------------- K8: ICP maps

@@ -262,15 +262,14 @@ def test_device_resident_view_equals_host_view(hip_api):
         e.close()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1"),
-                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1", DSR_PIPELINED_VIEW="1"),
-                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="1", DSR_RAYCAST_SPLIT="9", DSR_INTEGRATE_XLDS="0")])
+@pytest.mark.parametrize("env", [dict(), dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_PIPELINED_VIEW="1"),
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_PIPELINED_VIEW="2")])
 def test_asynchronous_loop_bit_exact(hip_api, monkeypatch, env):
     """The steady loop UpdateView(dev) -> ProcessFrame -> Prepare with sync_status = 0, as bench.py
     drives it: nothing is read back and the host never waits in between; the final state must be
     the oracle's, several times over (a missing dependency would show as a flaky difference).  With the side stream forced on
-    (a small volume does not get one by itself) the range image runs under the integration and the raycast + ICP maps under the
-    next frame's ingest / re-test / mark: the hazards wait_render / evExpected guard."""
+    (a small volume does not get one by itself) the range image runs under the integration: the hazard evExpected guards.
+    DSR_SMALL_VOLUME: the one-workgroup kernels of instance-sized volumes (k_small.h) on this volume."""
     import torch
     from tests.common import assert_render_equal
     for k, v in env.items():
@@ -365,23 +364,14 @@ def test_free_view_cache(hip_api):
 
 @pytest.mark.parametrize("env", [dict(DSR_GRID_INTEGRATE="1"), dict(DSR_GRID_INTEGRATE="37", DSR_GRID_EXPECTED="1", DSR_GRID_DECAY="3"),
                                  dict(DSR_GRID_INTEGRATE="16384", DSR_GRID_EXPECTED="257", DSR_GRID_DECAY="32768"),
-                                 # the small-volume paths (expected depths by one workgroup, free-view list by one sweep) forced
-                                 # onto this 40000-block volume; the large-volume paths are what the other cases run
-                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5"),
-                                 # the raycast in two kernels (k_raycast cut after K loop trips, k_raycast_tail with 8 lanes per ray):
-                                 # every ray through the tail kernel (K = 1), a cut in the middle of the march, a tiny tail grid
-                                 dict(DSR_RAYCAST_SPLIT="1"), dict(DSR_RAYCAST_SPLIT="6", DSR_GRID_RAYCAST_TAIL="3"),
-                                 dict(DSR_RAYCAST_SPLIT="17", DSR_SMALL_VOLUME="1"), dict(DSR_RAYCAST_SPLIT="0"),
-                                 # the side stream forced onto this small volume: range image under the integration, raycast + ICP
-                                 # maps under the next frame's read-only prefix (and each of the two alone); one view buffer
-                                 dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_RAYCAST_SPLIT="5"),
-                                 dict(DSR_OVERLAP_EXPECTED="1", DSR_OVERLAP_PREPARE="0"), dict(DSR_PIPELINED_VIEW="0"),
-                                 # k_integrate with the wave-uniform x terms of the camera transform through LDS
-                                 dict(DSR_INTEGRATE_XLDS="1"), dict(DSR_INTEGRATE_XLDS="1", DSR_GRID_INTEGRATE="3"),
-                                 # the tile-sum scans in the last workgroup of the producing sweep (opt-in) and the free-view raycast
-                                 # that shades its own pixels (the default of small volumes): on and off, large volume and small
-                                 dict(DSR_FOLD_SCANS="1"), dict(DSR_SMALL_VOLUME="1", DSR_FOLD_SCANS="0", DSR_FUSE_RENDER="0"),
-                                 dict(DSR_SMALL_VOLUME="1", DSR_FOLD_SCANS="1", DSR_FUSE_RENDER="1", DSR_RAYCAST_SPLIT="4")])
+                                 # the paths of instance-sized volumes (k_small.h: commit + visible list + range image in ONE workgroup,
+                                 # the free-view list from the allocated bits, the raycast that shades its own pixels) forced onto this
+                                 # 40000-block volume, and explicitly off; the large-volume paths are what the other cases run
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", DSR_GRID_INTEGRATE="5"), dict(DSR_SMALL_VOLUME="0"),
+                                 # the side stream forced onto this small volume: range image under the integration; view stream forms
+                                 dict(DSR_OVERLAP_EXPECTED="1"), dict(DSR_OVERLAP_EXPECTED="1", DSR_SMALL_VOLUME="1"),
+                                 dict(DSR_PIPELINED_VIEW="0"), dict(DSR_PIPELINED_VIEW="1", DSR_SMALL_VOLUME="1"),
+                                 dict(DSR_GRID_INTEGRATE="3")])
 def test_results_do_not_depend_on_the_launch_geometry(hip_api, monkeypatch, env):
     """The tuning knobs an engine reads from the environment at creation (grid sizes of k_integrate, of the range-image
     kernel and of the GC kernel: tools/bench_variants.py sweeps them) change how the work is split over waves — the colour
