@@ -8,7 +8,7 @@ import ctypes as C
 import os
 from types import SimpleNamespace
 
-ABI_VERSION = 3  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
+ABI_VERSION = 4  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
 BLOCK_SIZE = 8
 BLOCK_SIZE3 = 512
 
@@ -97,6 +97,7 @@ SIGNATURES = {
     "device_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "wait_for_stream": (C.c_int, [_H, _P]),
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
+    "engine_share_stream": (C.c_int, [_H, _H]),
     "update_view": (C.c_int, [_H, _P, _P]),
     "update_view_dev": (C.c_int, [_H, _P, _P]),
     "update_view_bgr": (C.c_int, [_H, _P, _P]),
@@ -134,6 +135,8 @@ SIGNATURES = {
     "view_remove_silhouette": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "view_extract_silhouette_dev": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "view_remove_silhouette_dev": (C.c_int, [_H, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "view_split_silhouette": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "view_split_silhouette_dev": (C.c_int, [_H, _H, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "composite_layer_ptrs_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances_dev": (C.c_int, [C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
     "composite_instances": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_int]),
@@ -194,13 +197,16 @@ def preload_hip_runtime():
                 pass
 
 
-def bind(lib, prefix):
+def bind(lib, prefix, allow_missing=False):
     """Return a namespace of typed functions `prefix + name` looked up in `lib`.
 
-    Raises AttributeError when the library does not export a declared symbol.
+    Raises AttributeError when the library does not export a declared symbol (`allow_missing`: measurement tools that load
+    an OLDER build of the library for an A/B skip the entry points it lacks).
     """
     ns = SimpleNamespace()
     for name, (res, args) in SIGNATURES.items():
+        if allow_missing and not hasattr(lib, prefix + name):
+            continue
         fn = getattr(lib, prefix + name)
         fn.restype = res
         fn.argtypes = args

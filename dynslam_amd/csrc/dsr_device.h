@@ -97,6 +97,9 @@ struct SceneP {
   int32_t *swapSlot;      // ... in this slot of it (most recent copy)
   uint8_t **hostSlabs;    // device-visible table of the pinned host slabs (slabBlocks blocks each)
   int slabBlocks;
+  // instance-sized volumes only (k_small.h; null otherwise): one bit per entry, kSmallBitWords words each
+  uint32_t *visBits;      // entries whose visible type the running frame's mark / commit set (cleared by the list kernel)
+  uint32_t *allocBits;    // entries that own a voxel block (ptr >= 0): set by the commit, cleared by the voxel GC
 };
 
 // ------------------------------------------------------------------ conversions

@@ -36,6 +36,7 @@
 #include "k_raycast.h"
 #include "k_swap.h"
 #include "k_mesh.h"
+#include "k_small.h"
 
 using namespace dsr;
 
@@ -157,7 +158,7 @@ struct dsr_engine {
   hipEvent_t evList = nullptr, evExpected = nullptr;
   bool overlapExpected = true;
   unsigned long long listVersion = 0;  // bumped by every call that rewrites the live visible list
-  struct { bool valid = false; unsigned long long version = 0; Mat4 M; float proj[4] = {0, 0, 0, 0}; } liveExp;
+  struct { bool valid = false; bool onSide = false; unsigned long long version = 0; Mat4 M; float proj[4] = {0, 0, 0, 0}; } liveExp;
   int W = 0, H = 0, Wr = 0, Hr = 0, P = 0;
   int noBuckets = 0, noExcess = 0, E = 0, noBlocks = 0;
   int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
@@ -173,6 +174,13 @@ struct dsr_engine {
   // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
   // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
   bool smallVolume = false;
+  // ... and, when the table is no larger than upstream's (1 179 648 entries) and nothing is swapped: the one-workgroup kernels of
+  // k_small.h — commit + visible list + range image as ONE launch, the free-view list + range image as one (21 -> 9 launches
+  // per instance frame); results identical, both paths under test
+  bool smallPath = false;
+  // the box (pixels, end exclusive) outside which the current view's depth is known to be 0: set by the silhouette cut-out
+  // that produced an instance's view, the whole image after any other writer.  The allocation's per-pixel mark runs over it.
+  int viewBox[4] = {0, 0, 0, 0};
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
@@ -259,6 +267,7 @@ struct dsr_engine {
   // allocation status waits for the map's whole previous frame (configs[2] through the reference's call pattern).
   bool pipelinedView = false;
   bool ownsStream = true, ownsViewStream = true;  // false: the per-GPU shared streams (DSR_PIPELINED_VIEW=2)
+  bool borrowedStream = false;                    // dsr_engine_share_stream: the stream is another engine's (which may be gone by now)
   hipStream_t viewStream = nullptr;
   uchar4 *rgbAlt = nullptr;
   float *depthAlt = nullptr;
@@ -412,6 +421,10 @@ int reset_scene(dsr_engine *e) {
   HIP_TRY(hipMemsetAsync(e->freeview.visType, 0, (size_t)e->E, e->stream));
   HIP_TRY(hipMemsetAsync(e->scene.allocGrp, 0, (size_t)e->numTilesE * (kTile / 32) * 4, e->stream));
   HIP_TRY(hipMemsetAsync(e->scene.allocTile, 0, ((size_t)e->numTilesE + 1) * 8, e->stream));
+  if (e->scene.visBits) {
+    HIP_TRY(hipMemsetAsync(e->scene.visBits, 0, (size_t)kSmallBitWords * 4, e->stream));
+    HIP_TRY(hipMemsetAsync(e->scene.allocBits, 0, (size_t)kSmallBitWords * 4, e->stream));
+  }
   e->fifoHead = 0; e->fifoLen = 0;
   HIP_TRY(hipGetLastError());
   if (e->statusHost) {
@@ -426,6 +439,7 @@ void free_all(dsr_engine *e) {
   auto F = [](void *p) { if (p) (void)hipFree(p); };
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
   F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
+  F(e->scene.visBits); F(e->scene.allocBits);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
@@ -567,6 +581,7 @@ struct ViewTarget { uchar4 *rgb; float *depth; };
 int begin_view_replace(dsr_engine *e, hipStream_t ws, ViewTarget *t) {
   int st = before_view_write(e, ws);  // readers on the I/O stream
   if (st) return st;
+  e->viewBox[0] = 0; e->viewBox[1] = 0; e->viewBox[2] = e->W; e->viewBox[3] = e->H;  // (a cut-out narrows it afterwards)
   if (!e->pipelinedView) { t->rgb = e->rgb; t->depth = e->depth; return DSR_OK; }
   if (!e->rgbAlt) {
     if ((st = dmalloc(&e->rgbAlt, (size_t)e->Wr * e->Hr)) || (st = dmalloc(&e->depthAlt, (size_t)e->P))) return st;
@@ -711,11 +726,33 @@ int allocate_scene(dsr_engine *e) {
   // a range image of the PREVIOUS list may still be running on the side stream (back-to-back fusion calls without a Prepare in
   // between): it reads the list and the count this call rewrites
   if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
+  if (e->smallPath) {
+    // an instance-sized volume: the mark over the box the view is not empty in, then ONE workgroup for everything that needs the
+    // whole table in order — commit, visible list, range image (k_small.h)
+    const int tx0 = e->viewBox[0] / 16, ty0 = e->viewBox[1] / 16;
+    const int tx1 = div_up(std::min(e->viewBox[2], e->W), 16), ty1 = div_up(std::min(e->viewBox[3], e->H), 16);
+    if (tx1 > tx0 && ty1 > ty0)
+      LAUNCH(e, "alloc_mark", k_alloc_mark<true>, dim3(tx1 - tx0, ty1 - ty0), dim3(256), p, e->scene, (const float *)e->depth,
+             rs.visType, tx0, ty0);
+    if (e->statusDev) e->statusSeq++;
+    const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
+    {
+      ProfScope _ps(e, "small_alloc_visible");
+      hipLaunchKernelGGL(k_small_alloc_visible, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene,
+                         (const float *)e->depth, rs.visType, e->numTilesE, e->allocWork, rs.visibleIDs, rs.visBlocks, e->noBlocks,
+                         e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax));
+    }
+    HIP_TRY(hipGetLastError());
+    { int st = after_fusion(e); if (st) return st; }
+    e->liveExp.valid = true; e->liveExp.onSide = false; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
+    memcpy(e->liveExp.proj, proj, sizeof proj);
+    return DSR_OK;
+  }
   LAUNCH(e, "retest_prev_visible", k_retest_previous_visible, dim3(1024), dim3(256), p, e->scene,
          (const int4 *)rs.visBlocks, rs.visType);
   int2 *allocTile = reinterpret_cast<int2 *>(e->scene.allocTile);
-  LAUNCH(e, "alloc_mark", k_alloc_mark, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
-         (const float *)e->depth, rs.visType);
+  LAUNCH(e, "alloc_mark", k_alloc_mark<false>, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), p, e->scene,
+         (const float *)e->depth, rs.visType, 0, 0);
   LAUNCH(e, "scan_tiles", k_scan_tile_sums, dim3(1), dim3(1024), allocTile, e->numTilesE, e->scene, (int)SCAN_ALLOC, 0);
   LAUNCH(e, "alloc_commit", k_alloc_commit, dim3(e->numTilesE), dim3(kTileThreads), p, e->scene, allocTile, e->allocWork);
   LAUNCH(e, "alloc_apply", k_alloc_apply, dim3(256), dim3(256), p, e->scene, (const float *)e->depth,
@@ -743,7 +780,7 @@ int allocate_scene(dsr_engine *e) {
     }
     HIP_TRY(hipEventRecord(e->evExpected, e->sideStream));
     e->sidePending = true;
-    e->liveExp.valid = true; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
+    e->liveExp.valid = true; e->liveExp.onSide = true; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
     memcpy(e->liveExp.proj, proj, sizeof proj);
   }
   return DSR_OK;
@@ -1217,6 +1254,15 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->scene.allocKey, (size_t)e->E));
   ALLOC(dmalloc(&e->scene.allocGrp, (size_t)e->numTilesE * (kTile / 32)));
   ALLOC(dmalloc(&e->scene.allocTile, (size_t)e->numTilesE + 1));
+  {
+    const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
+    e->smallPath = e->smallVolume && !s.use_swapping && e->E <= kSmallMaxEntries && e->numTilesE <= kSmallMaxTiles &&
+                   small_lds_bytes(cells) <= 64 * 1024;
+    if (e->smallPath) {
+      ALLOC(dmalloc(&e->scene.visBits, (size_t)kSmallBitWords));
+      ALLOC(dmalloc(&e->scene.allocBits, (size_t)kSmallBitWords));
+    }
+  }
   ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
@@ -1301,7 +1347,8 @@ void dsr_engine_destroy(dsr_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
-  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->borrowedStream) (void)hipDeviceSynchronize();  // (its owner may have been destroyed already: the handle is not touched)
+  else if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
   if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
   if (e->device < 64) g_enginesOnDevice[e->device].fetch_sub(1);
@@ -1571,8 +1618,10 @@ int dsr_prepare(dsr_engine *e) {
   RenderStateDev &rs = e->live;
   if (e->liveExp.valid && e->liveExp.version == e->listVersion && memcmp(e->liveExp.M.m, e->M_d.m, sizeof e->M_d.m) == 0 &&
       memcmp(e->liveExp.proj, proj, sizeof proj) == 0) {
-    HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // computed under the integration (allocate_scene)
-    e->sidePending = false;
+    if (e->liveExp.onSide) {
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0));  // computed under the integration (allocate_scene)
+      e->sidePending = false;
+    }  // (else: k_small_alloc_visible wrote it on this stream)
   } else {
     // a stale one may still be writing the image — whether or not it is still marked valid
     if (e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }
@@ -1692,7 +1741,28 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
       const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
                           memcmp(e->fvProj, proj, sizeof proj) == 0;
-      if (!cached && e->smallVolume) {
+      if (!cached && e->smallPath) {
+        // FindVisibleBlocks + CreateExpectedDepths in ONE workgroup (k_small.h), then the raycast that shades its own pixels
+        const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
+        {
+          ProfScope _ps(e, "small_freeview");
+          hipLaunchKernelGGL(k_small_freeview, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene, e->allocList,
+                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax));
+        }
+        e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+        if (outIsDevice) {
+          LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
+                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
+          HIP_TRY(hipGetLastError());
+          break;
+        }
+        LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
+               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+        HIP_TRY(hipGetLastError());
+        if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
+        if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
+        break;
+      } else if (!cached && e->smallVolume) {
         // FindVisibleBlocks by ONE sweep over the table (frustum test inside) + ordered compaction: 3 launches where the
         // cached list of allocated entries below takes 7 — that list pays when a large, unchanged map is rendered from
         // several cameras; an instance volume changes every frame and its table sweep is a few microseconds
@@ -2026,19 +2096,28 @@ static int enable_peer_access(int from, int to) {
   return DSR_OK;
 }
 
-// maskDev == nullptr: `mask` is a host buffer, staged through the engine's pinned ring (no synchronisation)
+// maskDev == nullptr: `mask` is a host buffer, staged through the engine's pinned ring (no synchronisation).
+// rbw > 0: the same launch also blanks the silhouette `rmask` in the main view (dsr_view_split_silhouette) — the cut-out reads
+// the pixel first, as the two host loops would (InstanceReconstructor.cpp:238-263).
 static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *mask, const uint8_t *maskDev,
-                              int x0, int y0, int box_w, int box_h) {
+                              int x0, int y0, int box_w, int box_h, const uint8_t *rmask = nullptr, const uint8_t *rmaskDev = nullptr,
+                              int rx0 = 0, int ry0 = 0, int rbw = 0, int rbh = 0) {
   CHECK_E(main_engine);
   if (!instance || (!mask && !maskDev) || box_w <= 0 || box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+  const bool blank = rbw > 0 || rbh > 0 || rmask || rmaskDev;
+  if (blank && ((!rmask && !rmaskDev) || rbw <= 0 || rbh <= 0)) return fail(DSR_E_ARG, "bad silhouette arguments");
   if (!main_engine->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   if (instance->W != main_engine->W || instance->H != main_engine->H ||
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
     return fail(DSR_E_ARG, "main and instance engines must share the image size");
-  int maskSlot = -1;
+  int maskSlot = -1, rmaskSlot = -1;
   if (!maskDev) {
     int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
+  }
+  if (blank && !rmaskDev) {
+    if (rmask == mask && rbw == box_w && rbh == box_h) rmaskDev = maskDev;  // one mask for both (the sharded scene): staged once
+    else { int st = upload_mask(main_engine, rmask, rbw, rbh, &rmaskDev, &rmaskSlot); if (st) return st; }
   }
   dsr_engine *e = main_engine;
   const bool forcePeerPath = getenv("DSR_FORCE_PEER_PATH") != nullptr;  // tests: the cross-GPU path on one GPU
@@ -2046,9 +2125,11 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   // Runs on the MAIN engine's view stream: ordered after the producer of its view and before any later blanking.  The kernel
   // REPLACES the instance's view: a pipelined instance takes it in its spare buffer (begin_view_replace: only the fusion that
   // last read that buffer is waited for); otherwise work queued on the instance's stream (the previous frame's integration) may
-  // still be reading the one buffer, and the main side first waits for all of it.
+  // still be reading the one buffer, and the main side first waits for all of it.  An instance that SHARES the main engine's
+  // stream (dsr_engine_share_stream: one volume per GPU next to its view engine) is ordered by that stream alone: no event.
   hipStream_t ws = vstream(e);
-  if (!instance->pipelinedView) {
+  const bool sameStream = !instance->pipelinedView && instance->stream == ws;
+  if (!instance->pipelinedView && !sameStream) {
     // (an event is created and recorded with its own stream's device current; WAITING for it works from any device)
     if (peer) HIP_TRY(hipSetDevice(instance->device));
     if (!instance->xEvent) HIP_TRY(hipEventCreateWithFlags(&instance->xEvent, instance->device != e->device ? hipEventDisableTiming : order_event_flags()));
@@ -2056,6 +2137,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     if (peer) HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamWaitEvent(ws, instance->xEvent, 0));
   }
+  if (blank) { int st = begin_view_modify(e); if (st) return st; }
   ViewTarget t;
   {
     // (a pipelined instance allocates its spare view buffers and their events on first use: on ITS GPU, not on main's)
@@ -2082,34 +2164,47 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
   }
   {
     StreamSwap sw(e, ws);
-    LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
-           (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
-           maskDev, x0, y0, box_w, box_h);
+    if (blank)
+      LAUNCH(e, "split_silhouette", k_split_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), e->rgb, e->depth, dstRgb,
+             dstDepth, e->W, e->H, maskDev, x0, y0, box_w, box_h, rmaskDev, rx0, ry0, rbw, rbh);
+    else
+      LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
+             (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
+             maskDev, x0, y0, box_w, box_h);
   }
   HIP_TRY(hipGetLastError());
   if (maskSlot >= 0) { int st = mask_slot_used(e, maskSlot); if (st) return st; }
+  if (rmaskSlot >= 0) { int st = mask_slot_used(e, rmaskSlot); if (st) return st; }
+  if (blank) { int st = view_written(e, ws); if (st) return st; }
   if (peer) {
     HIP_TRY(hipMemcpyPeerAsync(t.rgb, instance->device, e->xferRgb, e->device, (size_t)e->P * 4, ws));
     HIP_TRY(hipMemcpyPeerAsync(t.depth, instance->device, e->xferDepth, e->device, (size_t)e->P * 4, ws));
   }
-  // the instance's side: its "view written" event is recorded on a stream of ITS device (its view stream / its only stream),
-  // behind a wait for the main side — so every event is only ever recorded with its own device's streams
-  if (!e->xEvent2 || (instance->device != e->device && !e->xEvent2System)) {  // waited for from another GPU: system scope
-    if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
-    e->xEvent2 = nullptr;
-    e->xEvent2System = instance->device != e->device;
-    HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, e->xEvent2System ? hipEventDisableTiming : order_event_flags()));
-  }
-  HIP_TRY(hipEventRecord(e->xEvent2, ws));
-  if (peer) HIP_TRY(hipSetDevice(instance->device));
   int stv = DSR_OK;
-  {
-    hipStream_t is = vstream(instance);
-    const hipError_t werr = hipStreamWaitEvent(is, e->xEvent2, 0);
-    if (werr != hipSuccess) stv = fail(DSR_E_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(werr));
-    else stv = end_view_replace(instance, is);  // buffers swapped; the instance's view is final once `is` has passed this point
+  if (sameStream) {
+    stv = end_view_replace(instance, ws);
+  } else {
+    // the instance's side: its "view written" event is recorded on a stream of ITS device (its view stream / its only stream),
+    // behind a wait for the main side — so every event is only ever recorded with its own device's streams
+    if (!e->xEvent2 || (instance->device != e->device && !e->xEvent2System)) {  // waited for from another GPU: system scope
+      if (e->xEvent2) (void)hipEventDestroy(e->xEvent2);
+      e->xEvent2 = nullptr;
+      e->xEvent2System = instance->device != e->device;
+      HIP_TRY(hipEventCreateWithFlags(&e->xEvent2, e->xEvent2System ? hipEventDisableTiming : order_event_flags()));
+    }
+    HIP_TRY(hipEventRecord(e->xEvent2, ws));
+    if (peer) HIP_TRY(hipSetDevice(instance->device));
+    {
+      hipStream_t is = vstream(instance);
+      const hipError_t werr = hipStreamWaitEvent(is, e->xEvent2, 0);
+      if (werr != hipSuccess) stv = fail(DSR_E_DEVICE, std::string("hipStreamWaitEvent: ") + hipGetErrorString(werr));
+      else stv = end_view_replace(instance, is);  // buffers swapped; the instance's view is final once `is` has passed this point
+    }
+    if (peer) HIP_TRY(hipSetDevice(e->device));
   }
-  if (peer) HIP_TRY(hipSetDevice(e->device));
+  // outside the mask's box the cut-out is empty (depth 0): the instance's allocation mark need not look there
+  instance->viewBox[0] = std::max(0, x0); instance->viewBox[1] = std::max(0, y0);
+  instance->viewBox[2] = std::min(e->W, x0 + box_w); instance->viewBox[3] = std::min(e->H, y0 + box_h);
   return stv;
 }
 
@@ -2121,6 +2216,37 @@ int dsr_view_extract_silhouette_dev(dsr_engine *main_engine, dsr_engine *instanc
                                     int box_w, int box_h) {
   if (!mask_dev) return fail(DSR_E_ARG, "bad silhouette arguments");
   return extract_silhouette(main_engine, instance, nullptr, (const uint8_t *)mask_dev, x0, y0, box_w, box_h);
+}
+int dsr_view_split_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *copy_mask, int x0, int y0, int box_w,
+                              int box_h, const uint8_t *delete_mask, int dx0, int dy0, int dbox_w, int dbox_h) {
+  if (!delete_mask) return fail(DSR_E_ARG, "bad silhouette arguments");
+  return extract_silhouette(main_engine, instance, copy_mask, nullptr, x0, y0, box_w, box_h, delete_mask, nullptr, dx0, dy0, dbox_w, dbox_h);
+}
+int dsr_view_split_silhouette_dev(dsr_engine *main_engine, dsr_engine *instance, const void *copy_mask_dev, int x0, int y0, int box_w,
+                                  int box_h, const void *delete_mask_dev, int dx0, int dy0, int dbox_w, int dbox_h) {
+  if (!copy_mask_dev || !delete_mask_dev) return fail(DSR_E_ARG, "bad silhouette arguments");
+  return extract_silhouette(main_engine, instance, nullptr, (const uint8_t *)copy_mask_dev, x0, y0, box_w, box_h, nullptr,
+                            (const uint8_t *)delete_mask_dev, dx0, dy0, dbox_w, dbox_h);
+}
+
+// One volume per GPU next to the engine that holds the full frame: `e` gives up its own stream and queues its work on `owner`'s —
+// the view split, the fusion and the renders of the pair are then ordered by ONE queue, with no cross-stream event in the frame
+// (an unsatisfied cross-queue dependency costs tens of microseconds each time the host runs ahead: DESIGN.md 6.5).  Both engines
+// must live on one GPU and be driven from one thread; `e` must be idle.
+int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner) {
+  CHECK_E(e);
+  if (!owner || owner == e) return fail(DSR_E_ARG, "bad stream owner");
+  if (owner->device != e->device) return fail(DSR_E_ARG, "engines on different GPUs cannot share a stream");
+  if (e->pipelinedView || owner->pipelinedView) return fail(DSR_E_ARG, "not with pipelined views (they have streams of their own)");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->sideStream) HIP_TRY(hipStreamSynchronize(e->sideStream));
+  if (e->ownsStream && e->stream) (void)hipStreamDestroy(e->stream);
+  e->stream = owner->stream;
+  e->ownsStream = false;
+  e->borrowedStream = true;
+  e->overlapExpected = false;  // (the side stream's events assume a stream of the engine's own)
+  e->liveExp.valid = false;
+  return DSR_OK;
 }
 
 static int remove_silhouette(dsr_engine *e, const uint8_t *mask, const uint8_t *maskDev, int x0, int y0, int box_w, int box_h) {

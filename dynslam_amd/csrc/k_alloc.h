@@ -127,6 +127,10 @@ __host__ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float 
 
 // K1: per-pixel mark.  16x16 pixel tiles (a wave covers 16x4 pixels: neighbouring rays
 // probe the same buckets, which keeps the 16-byte entry gathers in L2).
+// BITS (instance-sized volumes, k_small.h): every entry whose visible type is set here also gets its bit in s.visBits — the
+// one-workgroup list kernel that follows finds the frame's visible entries in 147 KB of bits instead of 1.18 MB of types.
+// (An atomic OR without a result is a store as far as the wave is concerned: nothing waits for it.)
+template <bool BITS>
 __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
                                                  uint8_t *__restrict__ visType, int x, int y) {
   AllocRay r;
@@ -169,6 +173,7 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
       dsr_hash_entry he = head[k];
       if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
         visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
+        if (BITS) atomicOr(&s.visBits[hashIdx >> 5], 1u << (hashIdx & 31u));
         isFound = true;
       }
       if (!isFound) {
@@ -178,6 +183,7 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
           he = load_entry(s.table, hashIdx);
           if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
             visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
+            if (BITS) atomicOr(&s.visBits[hashIdx >> 5], 1u << (hashIdx & 31u));
             isFound = true;
             break;
           }
@@ -186,7 +192,10 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
         if (!isFound) {
           const bool isExcess = firstFree < 0;
           const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
-          if (!isExcess) visType[target] = 1;
+          if (!isExcess) {
+            visType[target] = 1;
+            if (BITS) atomicOr(&s.visBits[target >> 5], 1u << (target & 31u));
+          }
           tgt[k] = target; exc[k] = isExcess;
         }
       }
@@ -319,12 +328,14 @@ __global__ __launch_bounds__(1024) void k_scan_tile_sums(int2 *__restrict__ tile
 //  (k_alloc_mark 20 -> 124 us).  Archived: profiles/r05_pruned_fold_scans.diff, profiles/r04i_instance_frame_fold_fuse_ab.log.
 //  Instance-sized volumes now run these steps inside ONE workgroup, where a barrier is all it takes: k_small.h.)
 
-// K1, the kernel.
+// K1, the kernel.  (tileX0, tileY0): first 16x16 tile of the grid — an instance's view is empty outside the box its silhouette
+// was cut from (dsr_view_extract_silhouette), and the order keys are made of pixel indices, not of the launch geometry.
+template <bool BITS>
 __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                    uint8_t *__restrict__ visType) {
-  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+                                                    uint8_t *__restrict__ visType, int tileX0, int tileY0) {
+  const int x = (blockIdx.x + tileX0) * 16 + (threadIdx.x & 15), y = (blockIdx.y + tileY0) * 16 + (threadIdx.x >> 4);
   if (x >= p.W || y >= p.H) return;
-  alloc_mark_pixel(p, s, depth, visType, x, y);
+  alloc_mark_pixel<BITS>(p, s, depth, visType, x, y);
 }
 
 // K2: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two
@@ -381,30 +392,40 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP 
   }
 }
 
+// one item of the ordered work list: the winner's block position (its ray replayed), the table written.  BITS: k_small.h
+template <bool BITS>
+__device__ __forceinline__ void alloc_apply_item(const FrameP &p, const SceneP &s, const float *__restrict__ depth, const int4 w,
+                                                 uint8_t *__restrict__ visType) {
+  const int t = w.x;
+  if (t < 0) return;
+  short bx, by, bz;
+  alloc_winner_pos(p, depth, (uint32_t)w.y, bx, by, bz);
+  const int px = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
+  const int pz = (int)(uint32_t)(uint16_t)bz;
+  const int ptr = s.voxelAllocList[w.z];
+  if (w.w < 0) {  // type 1: in place (free head or tombstone); the chain link is kept
+    dsr_hash_entry *he = s.table + t;
+    *reinterpret_cast<int2 *>(he) = make_int2(px, pz);
+    he->ptr = ptr;
+    if (BITS) atomicOr(&s.allocBits[t >> 5], 1u << (t & 31));
+  } else {  // type 2: append a child from the excess list to this chain tail
+    const int exlOffset = s.excessAllocList[w.w];
+    s.table[t].offset = exlOffset + 1;
+    const int child = p.noBuckets + exlOffset;
+    *reinterpret_cast<int4 *>(s.table + child) = make_int4(px, pz, 0, ptr);
+    visType[child] = 1;
+    if (BITS) {
+      atomicOr(&s.visBits[child >> 5], 1u << (child & 31));
+      atomicOr(&s.allocBits[child >> 5], 1u << (child & 31));
+    }
+  }
+}
 __global__ __launch_bounds__(256) void k_alloc_apply(FrameP p, SceneP s, const float *__restrict__ depth,
                                                      const int4 *__restrict__ workList, uint8_t *__restrict__ visType) {
   const int total = s.ctr[CTR_ALLOC_TOTAL12], avail = s.ctr[CTR_ALLOC_OLD_HEAD_VBA] + 1;
   const int n = total < avail ? total : avail;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int4 w = workList[i];
-    const int t = w.x;
-    if (t < 0) continue;
-    short bx, by, bz;
-    alloc_winner_pos(p, depth, (uint32_t)w.y, bx, by, bz);
-    const int px = (int)((uint32_t)(uint16_t)bx | ((uint32_t)(uint16_t)by << 16));
-    const int pz = (int)(uint32_t)(uint16_t)bz;
-    const int ptr = s.voxelAllocList[w.z];
-    if (w.w < 0) {  // type 1: in place (free head or tombstone); the chain link is kept
-      dsr_hash_entry *he = s.table + t;
-      *reinterpret_cast<int2 *>(he) = make_int2(px, pz);
-      he->ptr = ptr;
-    } else {  // type 2: append a child from the excess list to this chain tail
-      const int exlOffset = s.excessAllocList[w.w];
-      s.table[t].offset = exlOffset + 1;
-      *reinterpret_cast<int4 *>(s.table + p.noBuckets + exlOffset) = make_int4(px, pz, 0, ptr);
-      visType[p.noBuckets + exlOffset] = 1;
-    }
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    alloc_apply_item<false>(p, s, depth, workList[i], visType);
 }
 
 // ------------------------------------------------------------- block visibility

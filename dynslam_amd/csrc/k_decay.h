@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kTileThreads) void k_decay_commit(SceneP s, const i
       s.voxelAllocList[oldHead + 1 + rank] = he->ptr;
       he->ptr = -2;
       visType[t] = 0;
+      if (s.allocBits) atomicAnd(&s.allocBits[t >> 5], ~(1u << (t & 31)));  // (k_small.h: the free-view list of an instance-sized volume)
       if (s.swapState) { s.swapState[t] = 0; s.swapStored[t] = 0; }
       rank++;
     }

@@ -83,6 +83,31 @@ __global__ __launch_bounds__(256) void k_extract_silhouette(const uchar4 *__rest
   extract_silhouette_px(x, y, srcRgb, srcDepth, dstRgb, dstDepth, W, mask, x0, y0, bw, bh);
 }
 
+// ProcessSilhouette_CPU + RemoveSilhouette_CPU of one instance in ONE pass over the frame (dsr_view_split_silhouette): the
+// cut-out is taken from the pixel as it is BEFORE this instance's blanking, which is the order of the two host loops
+// (InstanceReconstructor.cpp:238-263).  The two masks differ in the reference (copy mask x1.0, delete mask x1.2: Utils/Mask.cpp).
+__global__ __launch_bounds__(256) void k_split_silhouette(uchar4 *srcRgb, float *srcDepth, uchar4 *__restrict__ dstRgb,
+                                                          float *__restrict__ dstDepth, int W, int H,
+                                                          const uint8_t *__restrict__ mask, int x0, int y0, int bw, int bh,
+                                                          const uint8_t *__restrict__ rmask, int rx0, int ry0, int rbw, int rbh) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= W || y >= H) return;
+  const int idx = x + y * W;
+  const int col = x - x0, row = y - y0;
+  if (col >= 0 && col < bw && row >= 0 && row < bh && mask[row * bw + col] == 1) {
+    dstRgb[idx] = srcRgb[idx];
+    dstDepth[idx] = srcDepth[idx];
+  } else {
+    dstRgb[idx] = make_uchar4(255, 255, 255, 255);
+    dstDepth[idx] = 0.0f;
+  }
+  const int rcol = x - rx0, rrow = y - ry0;
+  if (rcol >= 0 && rcol < rbw && rrow >= 0 && rrow < rbh && rmask[rrow * rbw + rcol] == 1) {
+    srcRgb[idx] = make_uchar4(0, 0, 0, 0);
+    srcDepth[idx] = 0.0f;
+  }
+}
+
 // (col, row): a cell of the mask's box
 __host__ __device__ __forceinline__ void remove_silhouette_px(int col, int row, uchar4 *__restrict__ rgb, float *__restrict__ depth, int W, int H,
                                                               const uint8_t *__restrict__ mask, int x0, int y0, int bw) {

@@ -309,6 +309,35 @@ __global__ __launch_bounds__(1024) void k_expected_depth_lds(FrameP p, SceneP s,
   }
 }
 
+// The boxes of a wave's (up to) 64 projected blocks folded into a range image in LDS; call with all lanes of the wave.
+// An instance is seen from close: a 0.28 m block at 8 m covers ~5 x 5 cells, so with the global-atomics kernel's threshold
+// (16 cells) nearly every block took the wave-cooperative path below — 64 SEQUENTIAL rounds of seven cross-lane
+// broadcasts per wave (measured: ~28 us for 539 blocks).  Here the owning lane fills boxes of up to 144 cells itself
+// (fire-and-forget LDS atomics, ~10 cycles a cell) and only a block right in front of the camera is shared.
+// (Reading the cell first to skip atomics that cannot change it was measured too: slower, 35 us — the read's latency.
+//  Eight lanes per block, every eighth cell of the box each — 128 blocks per pass of the workgroup — was measured in round 4:
+//  28 us per launch against 19.6, the passes and the index arithmetic cost more than the short boxes save.)
+__device__ __forceinline__ void fold_wave_boxes(int2 *cellsLds, int mw, bool valid, int2 ul, int2 lr, float2 zr, int lane) {
+  const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
+  const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
+  const bool big = valid && bw * bh > 144;
+  auto fold = [&](int idx, int zmn, int zmx) {
+    atomicMin(&cellsLds[idx].x, zmn);
+    atomicMax(&cellsLds[idx].y, zmx);
+  };
+  if (valid && !big)
+    for (int y = ul.y; y <= lr.y; ++y)
+      for (int x = ul.x; x <= lr.x; ++x) fold(x + y * mw, zmin, zmax);
+  unsigned long long m = __ballot(big);
+  while (m) {  // large boxes (coarse voxels seen from close: hundreds of cells) are filled by the whole wave
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int x0 = __shfl(ul.x, src), y0 = __shfl(ul.y, src), w = __shfl(bw, src), cells = w * __shfl(bh, src);
+    const int zmn = __shfl(zmin, src), zmx = __shfl(zmax, src);
+    for (int c = lane; c < cells; c += 64) fold((x0 + c % w) + (y0 + c / w) * mw, zmn, zmx);
+  }
+}
+
 // K6 for SMALL volumes (an instance volume: a few hundred visible blocks): ONE workgroup owns the whole range image —
 // initialise it in LDS, fold every visible block, store every cell.  No global atomics, no separate initialisation
 // launch (k_minmax_init), no 128 workgroups that each clear and flush a 58 KB image for nothing: on an instance volume
@@ -336,31 +365,7 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
       const dsr_hash_entry he = entry_of_record(visBlocks[i]);
       if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
     }
-    const int zmin = __float_as_int(zr.x), zmax = __float_as_int(zr.y);
-    const int bw = lr.x - ul.x + 1, bh = lr.y - ul.y + 1;
-    // An instance is seen from close: a 0.28 m block at 8 m covers ~5 x 5 cells, so with the other kernels' threshold
-    // (16 cells) nearly every block took the wave-cooperative path below — 64 SEQUENTIAL rounds of seven cross-lane
-    // broadcasts per wave (measured: ~28 us for 539 blocks).  Here the owning lane fills boxes of up to 144 cells itself
-    // (fire-and-forget LDS atomics, ~10 cycles a cell) and only a block right in front of the camera is shared.
-    // (Reading the cell first to skip atomics that cannot change it was measured too: slower, 35 us — the read's latency.
-    //  Eight lanes per block, every eighth cell of the box each — 128 blocks per pass of the workgroup — was measured in round 4:
-    //  28 us per launch against 19.6, the passes and the index arithmetic cost more than the short boxes save.)
-    const bool big = valid && bw * bh > 144;
-    auto fold = [&](int idx, int zmn, int zmx) {
-      atomicMin(&cellsLds[idx].x, zmn);
-      atomicMax(&cellsLds[idx].y, zmx);
-    };
-    if (valid && !big)
-      for (int y = ul.y; y <= lr.y; ++y)
-        for (int x = ul.x; x <= lr.x; ++x) fold(x + y * mw, zmin, zmax);
-    unsigned long long m = __ballot(big);
-    while (m) {  // large boxes (coarse voxels seen from close: hundreds of cells) are filled by the whole wave
-      const int src = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int x0 = __shfl(ul.x, src), y0 = __shfl(ul.y, src), w = __shfl(bw, src), cells = w * __shfl(bh, src);
-      const int zmn = __shfl(zmin, src), zmx = __shfl(zmax, src);
-      for (int c = lane; c < cells; c += 64) fold((x0 + c % w) + (y0 + c / w) * mw, zmn, zmx);
-    }
+    fold_wave_boxes(cellsLds, mw, valid, ul, lr, zr, lane);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < nCells; c += blockDim.x) minmax[c] = cellsLds[c];

@@ -1,0 +1,342 @@
+// k_small.h — instance-sized volumes: the table sweeps of a frame inside ONE workgroup.
+//
+// An instance volume (InstanceReconstructor.cpp:363-392: 7142 blocks of 0.035 m voxels behind upstream's 1 179 648-entry
+// table) holds a few hundred to a few thousand entries.  Its frame is bound by the NUMBER of launches: round 4 ran it as 21
+// launches (232-295 us), of which the ordered table sweeps — scan, commit, apply, count, scan, write, range image, and again for
+// the preview camera — were 12, each a grid of 576 workgroups that finds a handful of entries, separated by kernel boundaries
+// because their ordered ranks need every workgroup's total.  Folding the scans into the sweeps by tickets lost (an agent-scope
+// release per wave, profiles/r04i_*).  Here the dependency disappears instead: the sweeps read BIT planes (one bit per entry,
+// 147 KB for the whole table — the mark sets `visBits`, the commit sets `allocBits`), which ONE workgroup of 1024 threads reads
+// in nine 16-byte loads per lane, so the ordered ranks are a wave scan + sixteen wave totals in LDS and a barrier is all the
+// synchronisation there is:
+//   k_small_alloc_visible = k_scan_tile_sums + k_alloc_commit + k_alloc_apply + k_retest_previous_visible + k_visible_count +
+//                           k_scan_tile_sums + k_visible_write + k_expected_depth_one              (8 launches -> 1)
+//   k_small_freeview      = k_visible_count<FREEVIEW> + k_scan_tile_sums + k_visible_write + k_expected_depth_one   (4 -> 1)
+// The arithmetic is the general path's, function for function (alloc_apply_item, check_block_visibility,
+// project_single_block, fold_wave_boxes), and so is every result: hash table, free lists, visible list and stream, types,
+// range image, status — the parity suite runs both paths against the oracle.
+#pragma once
+#include "k_alloc.h"
+#include "k_raycast.h"
+
+namespace dsr {
+
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallWaves = kSmallThreads / 64;
+constexpr int kSmallRows = 9;                                              // 16-byte loads per lane in a sweep of a bit plane
+constexpr int kSmallBitWords = kSmallWaves * kSmallRows * 64 * 4;          // 36864 words = 1 179 648 entries: upstream's table
+constexpr int kSmallMaxEntries = kSmallBitWords * 32;
+constexpr int kSmallMaxTiles = kSmallThreads;                              // one allocation tile total per thread
+
+struct SmallShared {  // head of the dynamic LDS; the range image follows
+  int2 scan[kSmallWaves];
+  int waveTotal[kSmallWaves];
+  int oldV, oldE, nPrev, overflowPrev, nVisible, pad0, pad1, pad2;
+};
+static_assert(sizeof(SmallShared) % sizeof(int2) == 0, "the range image behind it is an int2 array");
+constexpr size_t small_lds_bytes(int nCells) { return sizeof(SmallShared) + (size_t)nCells * sizeof(int2); }
+
+// (agent scope: served by L2, never allocates a line in this CU's L1 — the planes are also updated by L2 atomics of this very
+//  workgroup, and the 16-byte sweep that follows must not find a line an earlier phase left in L1)
+__device__ __forceinline__ uint32_t small_bit_word(const uint32_t *plane, int entry) {
+  return __hip_atomic_load(plane + (entry >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Ordered compaction of the set bits of a plane of kSmallBitWords words into `ids` (ascending entry index), by the whole
+// workgroup: wave w owns words [w * 2304, (w + 1) * 2304), a lane reads 4 consecutive words of each of the 9 rows of 256 —
+// every load instruction of a wave is 1 KB of consecutive bytes.  CLEAR: the words are zeroed behind the sweep (visBits is
+// per-frame scratch).  Returns the number of set bits; ids beyond `capacity` are dropped.
+template <bool CLEAR>
+__device__ __forceinline__ int small_sweep_bits(uint32_t *plane, int32_t *ids, int capacity, SmallShared &sh) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint4 *rows = reinterpret_cast<uint4 *>(plane) + wave * (kSmallRows * 64) + lane;
+  int c[kSmallRows], inc[kSmallRows];
+  {
+    uint4 v[kSmallRows];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) v[j] = rows[j * 64];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) inc[j] = c[j] = __popc(v[j].x) + __popc(v[j].y) + __popc(v[j].z) + __popc(v[j].w);
+  }
+  // inclusive scans over the lanes, the nine rows side by side (independent shuffles: their latencies overlap)
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o[kSmallRows];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) o[j] = __shfl_up(inc[j], d);
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) if (lane >= d) inc[j] += o[j];
+  }
+  int run = 0;  // inc[j] becomes the lane's first rank within the wave: rows before + lanes before in its row
+#pragma unroll
+  for (int j = 0; j < kSmallRows; ++j) { const int rowTotal = __shfl(inc[j], 63); inc[j] += run - c[j]; run += rowTotal; }
+  if (lane == 0) sh.waveTotal[wave] = run;
+  __syncthreads();
+  int waveOff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kSmallWaves; ++w) {
+    const int t = sh.waveTotal[w];
+    if (w < wave) waveOff += t;
+    total += t;
+  }
+  __syncthreads();  // waveTotal may be written again by the next sweep
+  // the few lanes that hold bits read their words again (from L1 / L2 now) instead of keeping 36 registers alive across the scans
+#pragma unroll
+  for (int j = 0; j < kSmallRows; ++j) {
+    if (c[j] == 0) continue;
+    const uint4 v = rows[j * 64];
+    if (CLEAR) rows[j * 64] = make_uint4(0u, 0u, 0u, 0u);
+    int rank = waveOff + inc[j];
+    const int firstEntry = ((wave * (kSmallRows * 64) + j * 64 + lane) * 4) * 32;
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t w = words[k];
+      while (w) {
+        const int b = __ffs((int)w) - 1;
+        w &= w - 1u;
+        if (rank < capacity) ids[rank] = firstEntry + k * 32 + b;
+        rank++;
+      }
+    }
+  }
+  return total;
+}
+
+// AllocateSceneFromDepth behind the per-pixel mark, for an instance-sized volume, + the live view's range image.
+//   A  tile totals of the marks -> offsets, free-list heads (k_scan_tile_sums SCAN_ALLOC)
+//   B  commit: a thread per sweep tile that holds marks ranks them into the ordered work list (k_alloc_commit)
+//   C  apply: the work list densely (k_alloc_apply)
+//   D  the previous frame's visible entries the mark did not touch: frustum test, type 3 / 0 (k_retest_previous_visible)
+//   E  only after a frame whose visible entries did not fit the list: the type sweep over the whole table (K0b's rare branch)
+//   F  ordered compaction of visBits -> visibleEntryIDs, counts, published status (k_visible_count / scan / k_visible_write)
+//   G  the visible-block stream + the range image (k_visible_write's gather, k_expected_depth_one)
+__global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                                       uint8_t *visType, int numTiles, int4 *workList,
+                                                                       int32_t *visibleIDs, int4 *visBlocks, int capacity,
+                                                                       int32_t *__restrict__ publish, int publishSeq,
+                                                                       int2 *__restrict__ minmax) {
+  extern __shared__ int2 smallLds[];
+  SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
+  int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const int nCells = mw * mh;
+  const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
+  for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
+  if (tid == 0) {
+    sh.oldV = s.ctr[CTR_LAST_FREE_BLOCK]; sh.oldE = s.ctr[CTR_LAST_FREE_EXCESS];
+    sh.nPrev = s.ctr[CTR_NO_VISIBLE_LIVE]; sh.overflowPrev = s.ctr[CTR_VIS_OVERFLOW];
+  }
+  // ---- A
+  int2 *allocTile = reinterpret_cast<int2 *>(s.allocTile);
+  const int2 tv = (tid < numTiles) ? allocTile[tid] : make_int2(0, 0);  // {marked entries, excess-list ones among them} of tile `tid`
+  int2 total;
+  const int2 tileOff = wg_exclusive_scan2<kSmallThreads>(tv, total, sh.scan);  // (its barriers also publish sh.* and the image's reset)
+  const int oldV = sh.oldV, oldE = sh.oldE;
+  if (tid == 0) {
+    int32_t *ctr = s.ctr;
+    ctr[CTR_ALLOC_OLD_HEAD_VBA] = oldV; ctr[CTR_ALLOC_OLD_HEAD_EXC] = oldE;
+    ctr[CTR_ALLOC_TOTAL12] = total.x; ctr[CTR_ALLOC_TOTAL2] = total.y;
+    const int nv = oldV - total.x, ne = oldE - total.y;
+    ctr[CTR_LAST_FREE_BLOCK] = nv < -1 ? -1 : nv;
+    ctr[CTR_LAST_FREE_EXCESS] = ne < -1 ? -1 : ne;
+    if (total.x > oldV + 1 || total.y > oldE + 1) ctr[CTR_STATUS] = DSR_E_OUT_OF_BLOCKS;
+  }
+  // ---- B: the tile's 64 group words (a byte per 8 entries) in four rounds of four 16-byte loads
+  if (tv.x != 0) {
+    allocTile[tid] = make_int2(0, 0);  // k_alloc_mark accumulates into it again
+    int rank12 = tileOff.x, rank2 = tileOff.y;
+    const int tileBase = tid * kTile;
+    uint4 *grp4 = reinterpret_cast<uint4 *>(s.allocGrp + (tileBase >> 5));
+    for (int q = 0; q < kTile / 32 / 16; ++q) {
+      uint4 g4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) g4[r] = grp4[q * 4 + r];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if ((g4[r].x | g4[r].y | g4[r].z | g4[r].w) == 0u) continue;
+        grp4[q * 4 + r] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame
+        const uint32_t gw[4] = {g4[r].x, g4[r].y, g4[r].z, g4[r].w};
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+          if (gw[wi] == 0u) continue;
+          for (int gi = 0; gi < 4; ++gi) {
+            if (((gw[wi] >> (gi * 8)) & 15u) == 0u) continue;
+            const int base = tileBase + ((q * 4 + r) * 4 + wi) * 32 + gi * 8;  // this group of 8 entries
+            uint32_t key[kTileItems];
+            int ptrOf[kTileItems];
+#pragma unroll
+            for (int j = 0; j < kTileItems; ++j) {
+              const int t = base + j < p.noTotalEntries ? base + j : p.noTotalEntries - 1;
+              key[j] = s.allocKey[t];
+              ptrOf[j] = s.table[t].ptr;
+            }
+#pragma unroll
+            for (int j = 0; j < kTileItems; ++j)
+              if (base + j >= p.noTotalEntries) key[j] = 0u;
+#pragma unroll
+            for (int j = 0; j < kTileItems; ++j) {
+              const int t = base + j;
+              const uint32_t k = key[j];
+              if (!k) continue;
+              const bool isExc = ptrOf[j] >= -1;
+              s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
+              const int vbaIdx = oldV - rank12;
+              int exlIdx = 0;
+              if (isExc) { exlIdx = oldE - rank2; rank2++; }
+              // out of voxel blocks: nothing is written past the list end; out of excess entries: a hole
+              if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k, vbaIdx, isExc ? exlIdx : -1);
+              rank12++;
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- C
+  {
+    const int avail = oldV + 1;
+    const int n = total.x < avail ? total.x : avail;
+    for (int i = tid; i < n; i += kSmallThreads) alloc_apply_item<true>(p, s, depth, workList[i], visType);
+  }
+  // ---- D (independent of C: an entry C creates was not visible before, an entry the mark touched is skipped)
+  const int nPrev = sh.nPrev;
+  for (int i = tid; i < nPrev; i += kSmallThreads) {
+    const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the previous frame's stream
+    const int t = he.offset;
+    const uint32_t m = 1u << (t & 31);
+    if (small_bit_word(s.visBits, t) & m) continue;  // type 1 / 2 from this frame's mark
+    bool isVisible, isVisibleEnlarged;
+    check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+    visType[t] = isVisible ? 3 : 0;
+    if (isVisible) atomicOr(&s.visBits[t >> 5], m);
+  }
+  // ---- E
+  if (sh.overflowPrev) {
+    __syncthreads();
+    auto leftover = [&](int t, uint32_t v) {
+      if (v == 0u) return;
+      const uint32_t m = 1u << (t & 31);
+      if (small_bit_word(s.visBits, t) & m) return;
+      if (v == 3u) {  // an entry the list had no room for keeps its 3 and is re-tested like every type-3 entry of the serial sweep
+        const dsr_hash_entry he = load_entry(s.table, (uint32_t)t);
+        bool isVisible, isVisibleEnlarged;
+        check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+        if (!isVisible) { visType[t] = 0; return; }
+      }
+      atomicOr(&s.visBits[t >> 5], m);
+    };
+    const uint4 *vt4 = reinterpret_cast<const uint4 *>(visType);
+    const int n16 = p.noTotalEntries >> 4;
+    for (int b0 = tid; b0 < n16; b0 += kSmallThreads * 4) {  // 16 types per load, four loads in flight
+      uint4 q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int idx = b0 + r * kSmallThreads; q[r] = vt4[idx < n16 ? idx : n16 - 1]; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = b0 + r * kSmallThreads;
+        if (idx >= n16 || (q[r].x | q[r].y | q[r].z | q[r].w) == 0u) continue;
+        const uint32_t w4[4] = {q[r].x, q[r].y, q[r].z, q[r].w};
+        for (int k = 0; k < 16; ++k) leftover(idx * 16 + k, (w4[k >> 2] >> ((k & 3) * 8)) & 0xffu);
+      }
+    }
+    for (int t = (n16 << 4) + tid; t < p.noTotalEntries; t += kSmallThreads) leftover(t, visType[t]);
+  }
+  __syncthreads();
+  // ---- F
+  const int totalVisible = small_sweep_bits<true>(s.visBits, visibleIDs, capacity, sh);
+  const int n = totalVisible < capacity ? totalVisible : capacity;
+  if (tid == 0) {
+    int32_t *ctr = s.ctr;
+    ctr[CTR_NO_VISIBLE_LIVE] = n;
+    ctr[CTR_VIS_OVERFLOW] = totalVisible > capacity ? 1 : 0;
+    ctr[CTR_ALLOC_OLD_HEAD_VBA] = ctr[CTR_LAST_FREE_BLOCK];  // (SCAN_VISIBLE_LIVE's bookkeeping; no swapped-out entries here)
+    if (publish) {  // k_visible_write's hand-over of {noVisibleBlocks, status} to a host that polls
+      publish[0] = n;
+      publish[1] = ctr[CTR_STATUS];
+      __hip_atomic_store(publish + 2, publishSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (n > 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+  }
+  __syncthreads();
+  // ---- G
+  for (int base = tid & ~63; base < n; base += kSmallThreads) {  // wave-uniform trip count
+    const int i = base + lane;
+    bool valid = false;
+    int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
+    float2 zr = make_float2(0.f, 0.f);
+    if (i < n) {
+      const int t = visibleIDs[i];
+      const int4 raw = *reinterpret_cast<const int4 *>(s.table + t);
+      const int4 rec = make_vis_record(raw, t);
+      visBlocks[i] = rec;
+      const dsr_hash_entry he = entry_of_record(rec);
+      if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+    }
+    fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
+  }
+  if (n <= 0) return;  // Prepare() is skipped without visible blocks: the image keeps its previous contents
+  __syncthreads();
+  for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
+}
+
+// FindVisibleBlocks + CreateExpectedDepths of a free camera for an instance-sized volume: the allocated entries come from
+// allocBits (ascending), are tested against the frustum densely, compacted in order; the range image is folded on the way.
+__global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, SceneP s, int32_t *stage, int32_t *__restrict__ visibleIDs,
+                                                                  int4 *__restrict__ visBlocks, int capacity,
+                                                                  int2 *__restrict__ minmax) {
+  extern __shared__ int2 smallLds[];
+  SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
+  int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const int nCells = mw * mh;
+  const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
+  for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
+  const int totalAlloc = small_sweep_bits<false>(s.allocBits, stage, capacity, sh);  // (its barriers publish the image's reset)
+  const int nAlloc = totalAlloc < capacity ? totalAlloc : capacity;
+  __syncthreads();  // the ids
+  int carry = 0;
+  for (int base = 0; base < nAlloc; base += kSmallThreads) {  // uniform trip count
+    const int i = base + tid;
+    bool vis = false;
+    int t = 0;
+    int4 raw = make_int4(0, 0, 0, -2);
+    if (i < nAlloc) {
+      t = stage[i];
+      raw = *reinterpret_cast<const int4 *>(s.table + t);
+      if (raw.w >= 0) {
+        const dsr_hash_entry he = entry_of_record(raw);
+        bool isVisible, isVisibleEnlarged;
+        check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+        vis = isVisible;
+      }
+    }
+    int2 tot;
+    const int2 ex = wg_exclusive_scan2<kSmallThreads>(make_int2(vis ? 1 : 0, 0), tot, sh.scan);
+    const int rank = carry + ex.x;
+    bool valid = false;
+    int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
+    float2 zr = make_float2(0.f, 0.f);
+    if (vis && rank < capacity) {
+      const int4 rec = make_vis_record(raw, t);
+      visibleIDs[rank] = t;
+      visBlocks[rank] = rec;
+      const dsr_hash_entry he = entry_of_record(rec);
+      valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+    }
+    fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
+    carry += tot.x;
+  }
+  if (tid == 0) {
+    const int n = carry < capacity ? carry : capacity;
+    s.ctr[CTR_NO_VISIBLE_FREE] = n;
+    atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+  }
+  __syncthreads();
+  for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
+}
+
+}  // namespace dsr

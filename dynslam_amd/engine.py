@@ -49,8 +49,9 @@ def load_hip_api():
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the product path.")
         _capi.preload_hip_runtime()
         lib = C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL)
-        api = _capi.bind(lib, "dsr_")
-        if api.abi_version() != _capi.ABI_VERSION:
+        older = bool(os.environ.get("DSR_HIP_LIB")) and bool(os.environ.get("DSR_HIP_LIB_OLDER_ABI"))  # A/B tools only
+        api = _capi.bind(lib, "dsr_", allow_missing=older)
+        if api.abi_version() != _capi.ABI_VERSION and not older:
             raise ImportError("libdsr_hip.so ABI version mismatch")
         _hip_api = api
     return _hip_api
@@ -287,6 +288,29 @@ class EngineCore:
 
     def remove_silhouette_dev(self, mask_dev_ptr, x0, y0, box_w, box_h):
         self._check(self.api.view_remove_silhouette_dev(self._h, C.c_void_p(mask_dev_ptr), int(x0), int(y0), int(box_w), int(box_h)))
+
+    def split_silhouette(self, instance, mask, x0, y0, delete_mask=None, dx0=None, dy0=None):
+        """ProcessSilhouette + RemoveSilhouette of one instance in one launch (dsr_view_split_silhouette); `delete_mask`
+        defaults to the copy mask at the same place."""
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        dm = mask if delete_mask is None else np.ascontiguousarray(delete_mask, dtype=np.uint8)
+        dx0, dy0 = (x0 if dx0 is None else dx0), (y0 if dy0 is None else dy0)
+        self._check(self.api.view_split_silhouette(self._h, instance._h, _ptr(mask), int(x0), int(y0), mask.shape[1], mask.shape[0],
+                                                   _ptr(dm), int(dx0), int(dy0), dm.shape[1], dm.shape[0]))
+
+    def split_silhouette_dev(self, instance, mask_dev_ptr, x0, y0, box_w, box_h, delete_mask_dev_ptr=None, dx0=None, dy0=None,
+                             dbox_w=None, dbox_h=None):
+        """... with the masks already in HBM."""
+        if delete_mask_dev_ptr is None:
+            delete_mask_dev_ptr, dx0, dy0, dbox_w, dbox_h = mask_dev_ptr, x0, y0, box_w, box_h
+        self._check(self.api.view_split_silhouette_dev(self._h, instance._h, C.c_void_p(mask_dev_ptr), int(x0), int(y0), int(box_w),
+                                                       int(box_h), C.c_void_p(delete_mask_dev_ptr), int(dx0), int(dy0), int(dbox_w),
+                                                       int(dbox_h)))
+
+    def share_stream(self, owner):
+        """Queue this engine's work on `owner`'s stream from now on (dsr_engine_share_stream): one volume next to its view engine
+        on a GPU of their own needs no cross-stream event per frame."""
+        self._check(self.api.engine_share_stream(self._h, owner._h))
 
     def remove_silhouette(self, mask, x0, y0):
         """RemoveSilhouette (InstanceReconstructor.cpp:135-170)."""

@@ -243,7 +243,7 @@ class ShardedScene:
     """
 
     def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None, local_only=False,
-                 has_static=True):
+                 has_static=True, share_streams=True):
         import torch
         self.torch = torch
         self.W, self.H, self.P = int(width), int(height), int(width) * int(height)
@@ -256,6 +256,10 @@ class ShardedScene:
         self.instances = {k: make_engine("instance") for k in instances_of_rank(rank, n_volumes, world_size, self.has_static)}
         # the full frame the instance views are cut from
         self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
+        # one instance volume next to its view engine on a GPU of their own (north_star's layout at 8 GPUs): ONE stream for the pair,
+        # no cross-stream event in the frame (dsr_engine_share_stream)
+        if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1:
+            next(iter(self.instances.values())).share_stream(self.source)
         # GPUs: the C ABI's exchange (RCCL called by the library) whenever RCCL can host the ranks — a process group on "nccl", or a
         # single rank; several ranks on ONE GPU (gloo, tests) and CPU tensors (the oracle, tests) go through torch.distributed
         import torch.distributed as dist
@@ -307,14 +311,14 @@ class ShardedScene:
         for k, x0, y0, mask, rel in masks:
             ie = self.instances.get(k)
             dev_mask = isinstance(mask, tuple)
-            if ie is not None:
+            # every rank that holds the frame blanks every silhouette, in order, like the one main view of the
+            # reference: a later instance's cut-out must not see pixels an earlier (overlapping) mask removed
+            if ie is not None:  # cut-out + blanking of an instance this rank owns: one launch (dsr_view_split_silhouette)
                 if dev_mask:
-                    self.source.extract_silhouette_dev(ie, mask[0], x0, y0, mask[1], mask[2])
+                    self.source.split_silhouette_dev(ie, mask[0], x0, y0, mask[1], mask[2])
                 else:
-                    self.source.extract_silhouette(ie, mask, x0, y0)
-            if self.source is not None:
-                # every rank that holds the frame blanks every silhouette, in order, like the one main view of the
-                # reference: a later instance's cut-out must not see pixels an earlier (overlapping) mask removed
+                    self.source.split_silhouette(ie, mask, x0, y0)
+            elif self.source is not None:
                 if dev_mask:
                     self.source.remove_silhouette_dev(mask[0], x0, y0, mask[1], mask[2])
                 else:

@@ -38,7 +38,7 @@ extern "C" {
  * different sides of the change refuse each other at load (2: dsr_kernel_time grew bytes_layout/units, dsr_stats was
  * extended, DSR_E_IO; 3: the multi-GPU exchange (dsr_exchange_*), dsr_update_view_bgr, host-buffer calls no longer
  * synchronise with the engine's stream) */
-#define DSR_ABI_VERSION 3
+#define DSR_ABI_VERSION 4
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
 #define DSR_BLOCK_SIZE 8
@@ -202,6 +202,11 @@ int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
  * blocking alternative. */
 int dsr_wait_for_stream(dsr_engine *e, void *hip_stream);
 int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
+/* (ABI 4) `e` queues its work on `owner`'s stream from now on (its own stream is released).  For ONE instance volume next to
+ * the engine that holds the full frame on a GPU of their own — the one-volume-per-GPU layout: the view split, the fusion and
+ * the renders of the pair are then ordered by one queue and the frame contains no cross-stream event.  Both engines on one
+ * GPU, driven from one thread, `e` idle, neither with a pipelined view; destroy `e` before or after `owner`, either works. */
+int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner);
 
 /* ---- view ------------------------------------------------------------------- */
 
@@ -354,6 +359,14 @@ int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y
 int dsr_view_extract_silhouette_dev(dsr_engine *main_engine, dsr_engine *instance, const void *mask_dev, int x0, int y0,
                                     int box_w, int box_h);
 int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, int y0, int box_w, int box_h);
+/* (ABI 4) Both steps of ONE instance in one launch: ProcessSilhouette_CPU with the copy mask, then RemoveSilhouette_CPU with
+ * the delete mask (InstanceReconstructor.cpp:238-263 calls them back to back; the reference scales the two masks differently,
+ * Utils/Mask.cpp:21-46).  The cut-out sees the pixel as it is before THIS instance's blanking, exactly as the two calls in
+ * that order; results are identical to them.  `_dev`: masks already in HBM (may be one and the same buffer). */
+int dsr_view_split_silhouette(dsr_engine *main_engine, dsr_engine *instance, const uint8_t *copy_mask, int x0, int y0, int box_w,
+                              int box_h, const uint8_t *delete_mask, int dx0, int dy0, int dbox_w, int dbox_h);
+int dsr_view_split_silhouette_dev(dsr_engine *main_engine, dsr_engine *instance, const void *copy_mask_dev, int x0, int y0,
+                                  int box_w, int box_h, const void *delete_mask_dev, int dx0, int dy0, int dbox_w, int dbox_h);
 
 /* ---- instance compositing (the fused preview) ------------------------------------ */
 

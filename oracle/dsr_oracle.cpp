@@ -1766,6 +1766,17 @@ int orc_view_extract_silhouette_dev(dsr_engine *m, dsr_engine *inst, const void 
 int orc_view_remove_silhouette_dev(dsr_engine *h, const void *mask, int x0, int y0, int box_w, int box_h) {
   return orc_view_remove_silhouette(h, (const uint8_t *)mask, x0, y0, box_w, box_h);
 }
+// dsr_view_split_silhouette: the two host loops in the reference's order (InstanceReconstructor.cpp:238-263)
+int orc_view_split_silhouette(dsr_engine *m, dsr_engine *inst, const uint8_t *copy_mask, int x0, int y0, int box_w, int box_h,
+                              const uint8_t *delete_mask, int dx0, int dy0, int dbox_w, int dbox_h) {
+  int st = orc_view_extract_silhouette(m, inst, copy_mask, x0, y0, box_w, box_h);
+  if (st) return st;
+  return orc_view_remove_silhouette(m, delete_mask, dx0, dy0, dbox_w, dbox_h);
+}
+int orc_view_split_silhouette_dev(dsr_engine *m, dsr_engine *inst, const void *copy_mask, int x0, int y0, int box_w, int box_h,
+                                  const void *delete_mask, int dx0, int dy0, int dbox_w, int dbox_h) {
+  return orc_view_split_silhouette(m, inst, (const uint8_t *)copy_mask, x0, y0, box_w, box_h, (const uint8_t *)delete_mask, dx0, dy0, dbox_w, dbox_h);
+}
 int orc_composite_layer_ptrs_dev(int, void *, void *target_rgba, void *target_depth, const void *const *layer_rgba_ptrs,
                                  const void *const *layer_depth_ptrs, const int32_t *track_ids, int n_layers, int n_pixels,
                                  float tint_strength, int dim_background) {
@@ -1956,6 +1967,7 @@ int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (m
 
 /* stream ordering / bandwidth probe: nothing to order or measure on the CPU */
 int orc_wait_for_stream(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
+int orc_engine_share_stream(dsr_engine *h, dsr_engine *owner) { return (h && owner && h != owner) ? DSR_OK : DSR_E_ARG; }  // no streams here
 int orc_stream_wait_for_engine(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_measure_copy_bandwidth(int, uint64_t, int, double *gbps_out) { if (gbps_out) *gbps_out = 0.0; return DSR_OK; }
 

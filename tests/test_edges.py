@@ -144,6 +144,24 @@ def test_oracle_silhouette_ops(oracle_lib, x0, y0, h, w):
     assert np.array_equal(rem_c[~sel], src_c[~sel]) and np.array_equal(rem_d[~sel], src_d[~sel])
 
 
+def test_oracle_split_silhouette_is_the_two_loops(oracle_lib):
+    """orc_view_split_silhouette (the checker of dsr_view_split_silhouette) = ProcessSilhouette_CPU, then RemoveSilhouette_CPU."""
+    W, H = 160, 48
+    sc, m1, i1 = make_engines(oracle_factory, W, H)
+    _, m2, i2 = make_engines(oracle_factory, W, H)
+    rgba, d, T, _ = sc.frame(0)
+    rng = np.random.default_rng(11)
+    mask = (rng.random((30, 50)) < 0.5).astype(np.uint8)
+    dmask = (rng.random((36, 60)) < 0.7).astype(np.uint8)
+    for m in (m1, m2):
+        m.update_view(rgba, d)
+    m1.split_silhouette(i1, mask, 20, 10, dmask, 15, 7)
+    m2.extract_silhouette(i2, mask, 20, 10)
+    m2.remove_silhouette(dmask, 15, 7)
+    for a, b in ((m1, m2), (i1, i2)):
+        assert np.array_equal(a.get_view()[0], b.get_view()[0]) and np.array_equal(a.get_view()[1], b.get_view()[1])
+
+
 # ------------------------------------------------------------------------- GPU
 
 @pytest.mark.gpu
@@ -195,7 +213,14 @@ def test_gpu_boundary_conversions(hip_api, oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [dict(), dict(DSR_PIPELINED_VIEW="1"), dict(DSR_FORCE_PEER_PATH="1"),
                                  dict(DSR_PIPELINED_VIEW="1", DSR_FORCE_PEER_PATH="1"), dict(DSR_PIPELINED_VIEW="2"),
-                                 dict(DSR_PIPELINED_VIEW="2", DSR_FORCE_PEER_PATH="1")])
+                                 dict(DSR_PIPELINED_VIEW="2", DSR_FORCE_PEER_PATH="1"),
+                                 # the kernels of instance-sized volumes (k_small.h: the mark over the silhouette's box, one
+                                 # workgroup for commit + visible list + range image) on these 20000-block volumes; TEST_SPLIT:
+                                 # cut-out + blanking as ONE call (dsr_view_split_silhouette); TEST_SHARE: the instance on the main
+                                 # engine's stream (dsr_engine_share_stream)
+                                 dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1"),
+                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", TEST_SHARE="1"), dict(TEST_SPLIT="1", DSR_FORCE_PEER_PATH="1"),
+                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", DSR_PIPELINED_VIEW="1"), dict(TEST_SHARE="1")])
 def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
     """Main view -> GPU split into an instance volume + blanked static map, both fused and
     raycast: identical to the oracle running the reference's CPU loops.  Also with the view operations on the engines' view
@@ -203,12 +228,16 @@ def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
     the main engine's GPU, peer-copied to the instance's: DSR_FORCE_PEER_PATH runs that code on one GPU)."""
     from dynslam_amd.engine import OutOfBlocksError
     from tests.common import assert_render_equal, assert_scene_equal
+    env = dict(env)
+    one_call, share = env.pop("TEST_SPLIT", None), env.pop("TEST_SHARE", None)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     W, H = 320, 96
     sc = StreetScene(W, H, n_instances=2)
     sc, gm, gi = make_engines(hip_factory, W, H)
     sc, om, oi = make_engines(oracle_factory, W, H)
+    if share:
+        gi.share_stream(gm)
     sc = StreetScene(W, H, n_instances=2)
     for i in range(4):
         rgba, d, T, inst_id = sc.frame(i)
@@ -218,8 +247,11 @@ def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
             if len(ys):
                 y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
                 mask = (inst_id[y0:y1, x0:x1] == 0).astype(np.uint8)
-                main.extract_silhouette(inst, mask, x0, y0)
-                main.remove_silhouette(mask, x0, y0)
+                if one_call and main is gm:
+                    main.split_silhouette(inst, mask, x0, y0)
+                else:
+                    main.extract_silhouette(inst, mask, x0, y0)
+                    main.remove_silhouette(mask, x0, y0)
                 # the instance volume lives in the object frame: pose = object^-1 * camera
                 rel = (np.linalg.inv(sc.instance_pose(0, i).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
                 inst.set_pose_inv_m(rel)
@@ -269,6 +301,49 @@ def test_gpu_silhouette_ops_with_masks_in_hbm(hip_api, oracle_lib, x0, y0, h, w)
         assert np.array_equal(vb[0], vc[0]) and np.array_equal(vb[1], vc[1])
     # a null mask is an argument error, not a crash
     assert hip_api.view_remove_silhouette_dev(gm._h, None, x0, y0, w, h) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [dict(), dict(DSR_PIPELINED_VIEW="1"), dict(DSR_FORCE_PEER_PATH="1"), dict(DSR_SMALL_VOLUME="1")])
+@pytest.mark.parametrize("box", [(40, 10, 30, 50, 34, 4, 42, 62), (-7, -5, 40, 60, -12, -9, 50, 70), (300, 80, 40, 60, 296, 76, 48, 68),
+                                 (0, 0, 96, 320, 0, 0, 96, 320)])
+def test_gpu_split_silhouette_equals_the_two_steps(hip_api, oracle_lib, monkeypatch, env, box):
+    """dsr_view_split_silhouette[_dev] (cut-out with the copy mask + blanking with the LARGER delete mask, one launch) == the
+    reference's two host loops in their order (the oracle's restatement), host masks and masks in HBM; then the instance volume
+    fused from the cut-out — its allocation mark only visits the copy mask's box — == the oracle's."""
+    import torch
+    from tests.common import assert_scene_equal
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    x0, y0, h, w, dx0, dy0, dh, dw = box
+    W, H = 320, 96
+    rng = np.random.default_rng(abs(x0 * 7 + y0) + 3)
+    mask = (rng.random((h, w)) < 0.6).astype(np.uint8)
+    mask[rng.random((h, w)) < 0.05] = 2  # only the value 1 copies (InstanceReconstructor.cpp:113)
+    dmask = (rng.random((dh, dw)) < 0.7).astype(np.uint8)
+    sc, gm, gi = make_engines(hip_factory, W, H)
+    _, gm2, gi2 = make_engines(hip_factory, W, H)
+    _, om, oi = make_engines(oracle_factory, W, H)
+    mask_t, dmask_t = torch.from_numpy(mask).cuda(), torch.from_numpy(dmask).cuda()
+    for i in (1, 2):
+        rgba, d, T, _ = StreetScene(W, H).frame(i)
+        for m in (gm, gm2, om):
+            m.update_view(rgba, d)
+        gm.split_silhouette(gi, mask, x0, y0, dmask, dx0, dy0)
+        gm2.split_silhouette_dev(gi2, mask_t.data_ptr(), x0, y0, w, h, dmask_t.data_ptr(), dx0, dy0, dw, dh)
+        om.extract_silhouette(oi, mask, x0, y0)
+        om.remove_silhouette(dmask, dx0, dy0)
+        for a, b, c in ((gm, gm2, om), (gi, gi2, oi)):
+            va, vb, vc = a.get_view(), b.get_view(), c.get_view()
+            assert np.array_equal(va[0], vc[0]) and np.array_equal(va[1], vc[1])
+            assert np.array_equal(vb[0], vc[0]) and np.array_equal(vb[1], vc[1])
+        for e in (gi, gi2, oi):
+            e.set_pose_inv_m(T)
+            e.process_frame()
+            e.prepare()
+        assert_scene_equal(gi, oi)
+        assert_scene_equal(gi2, oi)
+    assert hip_api.view_split_silhouette_dev(gm._h, gi._h, C.c_void_p(mask_t.data_ptr()), x0, y0, w, h, None, dx0, dy0, dw, dh) != 0
 
 
 @pytest.mark.gpu

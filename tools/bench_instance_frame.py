@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--host-masks", action="store_true", help="upload the mask per call (the reference host's way: synchronises)")
     ap.add_argument("--two-renders", action="store_true", help="colour and depth as two get_image calls (round 2's preview)")
+    ap.add_argument("--two-step-split", action="store_true", help="extract + remove as two calls (round 4's view split)")
+    ap.add_argument("--share-stream", action="store_true", help="the instance queues its work on the view engine's stream (dsr_engine_share_stream)")
     args = ap.parse_args()
     import bench
     W, H = 1242, 375
@@ -42,6 +44,8 @@ def main():
     kinds = bench.volume_settings("5mm")
     view = EngineCore(default_settings(**kinds["view"], device=0, sync_status=0), calib)
     inst = EngineCore(default_settings(**kinds["instance"], device=0, sync_status=0), calib)
+    if args.share_stream:
+        inst.share_stream(view)
     rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
     dep = [torch.from_numpy(f[1]).to(dev) for f in frames]
     masks = []
@@ -64,7 +68,12 @@ def main():
         j = i % n_unique
         x0, y0, mk, mk_dev, rel, pose_m = masks[j]
         call("update_view_dev", view.update_view_dev, rgb[j].data_ptr(), dep[j].data_ptr())
-        if args.host_masks:
+        if not args.two_step_split and hasattr(view, "split_silhouette_dev"):
+            if args.host_masks:
+                call("split_silhouette", view.split_silhouette, inst, mk, x0, y0)
+            else:
+                call("split_silhouette", view.split_silhouette_dev, inst, mk_dev.data_ptr(), x0, y0, mk.shape[1], mk.shape[0])
+        elif args.host_masks:
             call("extract_silhouette", view.extract_silhouette, inst, mk, x0, y0)
             call("remove_silhouette", view.remove_silhouette, mk, x0, y0)
         else:
@@ -86,7 +95,8 @@ def main():
     for i in range(n_unique):  # warm-up: one pass over the sequence
         frame(i)
     drain()
-    res = {"frames": args.frames, "host_masks": args.host_masks, "two_renders": args.two_renders}
+    res = {"frames": args.frames, "host_masks": args.host_masks, "two_renders": args.two_renders, "two_step_split": args.two_step_split,
+           "share_stream": args.share_stream, "lib": os.environ.get("DSR_HIP_LIB", "default")}
     # (a) free-running: host enqueues ahead, one drain at the end
     host.clear()
     t0 = time.perf_counter()
