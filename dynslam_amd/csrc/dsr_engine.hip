@@ -7,27 +7,9 @@
 // free-list heads stay in device memory and kernels use fixed grids that read them there.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see __graft_entry__.build()).
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types only: librccl is loaded on first use (exchange_* below), the library does not link it
-
-#include <dlfcn.h>
 #include <sched.h>
-#include <unistd.h>
 
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <new>
-#include <string>
-#include <unordered_map>
-#include <vector>
-
-#include "dsr_device.h"
+#include "dsr_internal.h"
 #include "k_alloc.h"
 #include "k_composite.h"
 #include "k_decay.h"
@@ -38,40 +20,16 @@
 #include "k_mesh.h"
 #include "k_small.h"
 
-using namespace dsr;
-
 namespace {
 
-thread_local std::string g_err;
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
 std::atomic<int> g_enginesOnDevice[64];         // live engines per device (range-image overlap policy, allocate_scene)
-int fail(int code, const std::string &msg) { g_err = msg; return code; }
-std::mutex g_pinMutex;
-std::map<uintptr_t, size_t> g_pinned;           // host ranges the caller page-locked through dsr_pin_host_buffer
-bool host_range_pinned(const void *p, size_t bytes) {
-  std::lock_guard<std::mutex> lock(g_pinMutex);
-  if (g_pinned.empty()) return false;
-  auto it = g_pinned.upper_bound((uintptr_t)p);
-  if (it == g_pinned.begin()) return false;
-  --it;
-  return (uintptr_t)p + bytes <= it->first + it->second;
-}
 std::mutex g_ioMutex;
 hipStream_t g_ioStream[64] = {};                // per GPU: uploads, previews and view read-backs of every engine on it
 // DSR_PIPELINED_VIEW=2: per GPU ONE view stream for all engines and ONE fusion stream for all instance-sized volumes (a host drives
 // its instance volumes one after the other anyway): a map + N instances are then 4-5 streams instead of 2N + 4, and the map's
 // fusion stream need not share a hardware queue with anybody
 hipStream_t g_sharedViewStream[64] = {}, g_sharedSmallStream[64] = {};
-
-#define HIP_TRY(expr)                                                                              \
-  do {                                                                                             \
-    hipError_t _e = (expr);                                                                        \
-    if (_e != hipSuccess) {                                                                        \
-      char _b[512];                                                                                \
-      snprintf(_b, sizeof _b, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-      return fail(DSR_E_DEVICE, _b);                                                               \
-    }                                                                                              \
-  } while (0)
 
 // ----------------------------------------------------------------- host matrices
 // ORUtils::Matrix4f helpers, float, same operation order as the oracle (host code is
@@ -124,191 +82,8 @@ bool m4_inv(const Mat4 &in, Mat4 &out) {
   return true;
 }
 
-struct RenderStateDev {  // ITMRenderState_VH
-  int32_t *visibleIDs = nullptr;
-  int32_t *visibleIDsAlt = nullptr;  // ping-pong target of the post-decay compaction (live only)
-  int4 *visBlocks = nullptr;         // the visible-block stream: one 16-byte record per list entry (dsr_device.h)
-  int4 *visBlocksAlt = nullptr;
-  uint8_t *visType = nullptr;
-  float2 *minmax = nullptr;
-  float4 *raycastResult = nullptr;
-  uchar4 *raycastImage = nullptr;
-  int ctrIdx = CTR_NO_VISIBLE_LIVE;
-};
-
-struct ProfRec { std::string name; double ms = 0; long long launches = 0; };
-
 }  // namespace
 
-struct dsr_engine {
-  dsr_settings s;
-  dsr_calib calib;
-  int device = 0;
-  hipStream_t stream = nullptr;
-  // The range image of the live view (K6) needs the visible list and the pose — not a single voxel — so it is computed on
-  // a SIDE stream while k_integrate runs (the host's Integrate(); PrepareNextStep(); pair, InfiniTamDriver.h:137-158):
-  // its LDS / atomic / latency phases hide under the VALU-bound integration.  dsr_prepare takes the result when list and
-  // camera are still the ones it was computed for, else it recomputes on the main stream.  env DSR_OVERLAP_EXPECTED=0: off.
-  // Measured (profiles/r03j_range_image_overlap_ab.json): 1.176 vs 1.192 ms per frame.  K6's 1024-thread, 58 KB-LDS
-  // workgroups only find room as integration workgroups retire, so under a profiler its SPAN is the integration's (~510 us
-  // for ~40 us of work): a span, not a cost.  Tried on top: raised wave priority (s_setprio 3: no change — the waves are not
-  // resident, not slow) and the global-atomics kernel, whose 256-thread workgroups do co-reside (182 us) but whose atomics
-  // slow the integration to 692 us (profiles/r03m_*).
-  hipStream_t sideStream = nullptr;
-  hipEvent_t evList = nullptr, evExpected = nullptr;
-  bool overlapExpected = true;
-  unsigned long long listVersion = 0;  // bumped by every call that rewrites the live visible list
-  struct { bool valid = false; bool onSide = false; unsigned long long version = 0; Mat4 M; float proj[4] = {0, 0, 0, 0}; } liveExp;
-  int W = 0, H = 0, Wr = 0, Hr = 0, P = 0;
-  int noBuckets = 0, noExcess = 0, E = 0, noBlocks = 0;
-  int numTilesE = 0, numTilesB = 0, numTilesMax = 0;
-  uint32_t maxSteps = 0;
-  int gridPersistent = 2048;
-  int gridDecay = 2048;
-  // k_integrate grid: more, finer strided shares balance the tail (5 mm bench: 1280 workgroups
-  // (= resident) 918 us, 4096 872 us, 8192 840 us, 16384 835 us, whole-block variant); scaled down
-  // for small volumes.
-  // env DSR_GRID_INTEGRATE overrides.
-  int gridIntegrate = 8192;
-  // a volume of instance size (7142 blocks in the reference, InstanceReconstructor.cpp:379): its frames are bound by the number
-  // of launches, not by bandwidth, so the paths with fewer, simpler launches are taken (expected depths in one workgroup,
-  // free-view visible list by one sweep instead of through the cached list of allocated entries); results are identical
-  bool smallVolume = false;
-  // ... and, when the table is no larger than upstream's (1 179 648 entries) and nothing is swapped: the one-workgroup kernels of
-  // k_small.h — commit + visible list + range image as ONE launch, the free-view list + range image as one (21 -> 9 launches
-  // per instance frame); results identical, both paths under test
-  bool smallPath = false;
-  // the box (pixels, end exclusive) outside which the current view's depth is known to be 0: set by the silhouette cut-out
-  // that produced an instance's view, the whole image after any other writer.  The allocation's per-pixel mark runs over it.
-  int viewBox[4] = {0, 0, 0, 0};
-  int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
-  Mat4 calibInv, M_d, invM_d;
-
-  SceneP scene{};
-  RenderStateDev live, freeview;
-  int2 *tileSums = nullptr;
-  uint2 *integrateStats = nullptr;  // per wave of k_integrate: {lanes that stored depth planes, colour voxels}
-  int4 *allocWork = nullptr;  // ordered work list of the frame's allocations
-  // free-view cache: DynSLAM renders several image types from ONE pose per redraw (GetImage colour +
-  // GetFloatImage depth, InfiniTamDriver.cpp:165-209); while neither the scene nor the camera has
-  // changed, FindVisibleBlocks + CreateExpectedDepths + the raycast are reused and only the
-  // shading runs again
-  unsigned long long sceneVersion = 0;
-  int32_t *allocList = nullptr;              // ascending list of the allocated entries, valid for allocListVersion
-  unsigned long long allocListVersion = ~0ull;
-  bool fvValid = false;
-  unsigned long long fvVersion = 0;
-  Mat4 fvM;
-  float fvProj[4] = {0, 0, 0, 0};
-  dsr_triangle *meshTris = nullptr;  // current mesh (dsr_mesh_scene), device
-  uint64_t meshCount = 0;
-
-  // view
-  bool hasView = false;
-  uchar4 *rgb = nullptr;
-  float *depth = nullptr, *depthTmp = nullptr;
-  short *rawDepth = nullptr;
-  // tracking state point cloud
-  float4 *pointsMap = nullptr, *normalsMap = nullptr;
-  // scratch
-  float *freeDepth = nullptr;
-  dsr_voxel *aosScratch = nullptr;
-  int aosScratchBlocks = 0;
-
-  int depthWeighting = 0;
-  bool shortDivMuExact = false;  // div_short(x, mu) == x / mu for every x (checked at creation)
-  long long framesProcessed = 0;
-
-  // voxel GC FIFO of visible lists
-  uint32_t *fifoPlanes = nullptr;    // ring storage (device): fifoCap planes of fifoPlaneWords words, a bit per entry (k_decay.h)
-  size_t fifoPlaneWords = 0;
-  int fifoCap = 0, fifoHead = 0, fifoLen = 0;
-  int32_t *decayCand = nullptr;      // forceAll candidate list
-  // host swapping (use_swapping): ITMGlobalCache = host store of plane-wise 4 KiB blocks
-  uint8_t *swapStagingDev = nullptr;             // 16 MiB: fetched host copies of a swap-in batch
-  int32_t *swapIdsDev = nullptr;
-  uint8_t *swapFlagsDev = nullptr;
-  // host store (ITMGlobalCache): pinned slabs the GPU reads and writes directly (k_swap.h)
-  std::vector<uint8_t *> hostSlabs;              // e->scene.slabBlocks blocks each; also listed in scene.hostSlabs
-  static constexpr int kMaxHostSlabs = 4096;     // 256 GiB of host store
-  long long hostUsedUpper = 0;                   // upper bound of CTR_HOST_USED after the enqueued frames
-  int32_t *hostUsedSeen = nullptr;               // pinned: asynchronous read-back of CTR_HOST_USED
-  hipEvent_t hostUsedEvent = nullptr;
-  bool hostUsedPending = false;
-  long long hostUsedCallsSince = 0;              // swap-out batches enqueued since that read-back was issued
-  // silhouette masks handed over as HOST buffers (instance view split): a ring of pinned, device-mapped staging slots.
-  // The host copies the mask into a slot and the silhouette kernel reads it from there over the host link (10-20 KB,
-  // once): no copy command, no synchronisation — the caller's buffer is free when the call returns and a slot is reused
-  // only once the kernel that read it has run.  (A hipMemcpyAsync from the pinned slot into a device twin was measured
-  // first: the copy engine's hand-over to the compute queue costs ~40 us per mask, configs[2] 623 -> 505 frames/s.)
-  static constexpr int kMaskSlots = 32;  // two masks per instance and frame: a scene of up to 16 instances never waits on a slot
-  uint8_t *maskHost = nullptr, *maskHostDev = nullptr;  // the ring and its device-side address
-  size_t maskSlotBytes = 0;
-  hipEvent_t maskEvent[kMaskSlots] = {};
-  bool maskEventUsed[kMaskSlots] = {};
-  int maskNext = 0;
-  // noVisibleBlocks of the live view as the host last saw it (read together with the status word: dsr_process_frame with
-  // sync_status, dsr_get_stats); valid until the next call that changes the list
-  int32_t noVisibleSeen = 0;
-  bool noVisibleValid = false;
-  // ---- host buffers in and out WITHOUT draining the engine's stream (DESIGN.md "through the host").  DynSLAM's host hands
-  // every frame over as pageable host buffers and wants two previews and a status word back per frame and per driver
-  // (InfiniTamDriver.cpp:211-224, InfiniTamDriver.h:137-158); waiting for the engine's stream at each of these calls exposes the
-  // integration and the raycast to the host serially.  Instead: frames are copied into a pinned slot (two, alternating) and
-  // uploaded on the GPU's I/O stream (one per device, shared by the engines of the process) into a landing buffer the ingest
-  // kernel reads; the status words are PUBLISHED by k_visible_write into a pinned, device-mapped word the host polls; previews
-  // and view read-backs run on the I/O stream after the last kernel that wrote the view (evView) — none of them waits for
-  // k_integrate or k_raycast.
-  // PIPELINED VIEW (opt-in: env DSR_PIPELINED_VIEW=1, see dsr_engine_create for the measurements): everything that writes or
-  // modifies the view — ingest, SetView, the silhouette kernels — runs on the engine's VIEW stream, and the view is double
-  // buffered: a frame's view is built in the buffer fusion is not reading, so the next frame's view split (and with it the
-  // instance volumes' whole frames) proceeds while this volume's integration and raycast are still running.  Without it the
-  // view kernels of frame i + 1 queue behind the raycast of frame i on the one stream, and a host that waits for an instance's
-  // allocation status waits for the map's whole previous frame (configs[2] through the reference's call pattern).
-  bool pipelinedView = false;
-  bool ownsStream = true, ownsViewStream = true;  // false: the per-GPU shared streams (DSR_PIPELINED_VIEW=2)
-  bool borrowedStream = false;                    // dsr_engine_share_stream: the stream is another engine's (which may be gone by now)
-  hipStream_t viewStream = nullptr;
-  uchar4 *rgbAlt = nullptr;
-  float *depthAlt = nullptr;
-  hipEvent_t evAltFree = nullptr;      // recorded on the fusion stream when the buffers were swapped: readers of the old view are behind it
-  bool altFreeValid = false;
-  hipEvent_t evFusionRead = nullptr;   // the last fusion work that read the view ...
-  const float *fusionReadDepth = nullptr;  // ... and which buffer it read
-  uint8_t *upPin[2] = {nullptr, nullptr};
-  size_t upBytes = 0, upDepthOff = 0;
-  hipEvent_t upSlotFree[2] = {nullptr, nullptr};
-  bool upSlotUsed[2] = {false, false};
-  int upNext = 0;
-  uint8_t *upDev = nullptr;                    // landing buffer of the upload: colour, then depth
-  hipEvent_t evUploaded = nullptr, evIngested = nullptr;
-  bool ingestPending = false;
-  hipEvent_t evView = nullptr;                 // recorded after the last kernel that wrote this engine's view
-  bool viewEventValid = false;
-  hipEvent_t evViewRead = nullptr;             // the I/O stream's last read of the view (previews, dsr_get_view)
-  bool viewReadEver = false;
-  uint8_t *pvPin = nullptr, *pvDev = nullptr;  // previews: packed BGR (3 B / pixel), then int16 millimetres
-  size_t pvMmOff = 0;
-  int32_t *statusHost = nullptr, *statusDev = nullptr;  // {noVisibleBlocks, status, sequence number}, pinned + mapped
-  int statusSeq = 0;
-  // cross-GPU view split (main engine on one GPU, the instance volume on another): the cut-out is produced here, then peer-copied
-  uchar4 *xferRgb = nullptr;
-  float *xferDepth = nullptr;
-  bool sidePending = false;          // evExpected has been recorded and not been waited for by the main stream since
-  hipEvent_t xEvent = nullptr;       // as instance: orders the main stream after this engine's queued work
-  hipEvent_t xEvent2 = nullptr;      // as main engine: orders the instance stream after a view split
-  bool xEvent2System = false;        // ... created with a system-scope release (an instance on another GPU has waited for it)
-  hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
-  uint8_t *decayFlags = nullptr;
-
-  // profiling
-  int profiling = 0;  // 0 off, 1 every kernel, 2 the two dominant kernels only
-  std::vector<ProfRec> profRecs;
-  std::map<std::string, int> profIndex;
-  struct Pending { int rec; hipEvent_t a, b; };
-  std::vector<Pending> profPending;
-  std::vector<hipEvent_t> eventPool;
-};
 
 namespace {
 
@@ -473,32 +248,6 @@ void free_all(dsr_engine *e) {
   if (e->evExpected) (void)hipEventDestroy(e->evExpected);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream && e->ownsStream) (void)hipStreamDestroy(e->stream);
-}
-
-// div_short(a, b, RN(1/b)) against a / b for every numerator mantissa (a in [1, 2): division is
-// scale invariant while nothing under- or overflows, and symmetric in the signs)
-__global__ __launch_bounds__(256) void k_check_short_division(float b, unsigned long long *mismatches) {
-  const float y = 1.0f / b;
-  unsigned long long bad = 0;
-  for (uint32_t m = blockIdx.x * blockDim.x + threadIdx.x; m < (1u << 23); m += gridDim.x * blockDim.x) {
-    const float a = __uint_as_float(0x3f800000u | m);
-    if (__float_as_uint(div_short(a, b, y)) != __float_as_uint(a / b)) bad++;
-  }
-  if (bad) atomicAdd(mismatches, bad);
-}
-
-// true when the one-correction division is exact for this divisor (k_integrate.h div_short)
-int short_division_exact(hipStream_t stream, float b, bool *exact) {
-  unsigned long long *d = nullptr, h = 1;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8));
-  (void)hipMemsetAsync(d, 0, 8, stream);
-  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, stream, b, d);
-  hipError_t err = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream);
-  if (err == hipSuccess) err = hipStreamSynchronize(stream);
-  (void)hipFree(d);
-  if (err != hipSuccess) return fail(DSR_E_DEVICE, "short-division check failed to run");
-  *exact = (h == 0);
-  return DSR_OK;
 }
 
 template <class T>
@@ -974,141 +723,7 @@ int swap_out(dsr_engine *e) {
   return DSR_OK;
 }
 
-// ---- RCCL, loaded on first use: the library itself does not link librccl (a host without multi-GPU needs never pays for it,
-// and a process that already holds a copy — PyTorch ships its own — keeps using that one)
-struct RcclApi {
-  void *lib = nullptr;
-  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-  ncclResult_t (*GroupStart)() = nullptr;
-  ncclResult_t (*GroupEnd)() = nullptr;
-  const char *(*GetErrorString)(ncclResult_t) = nullptr;
-  std::string error;
-};
-RcclApi *rccl_api() {
-  static RcclApi api;
-  static std::once_flag once;
-  std::call_once(once, [] {
-    const char *names[] = {"librccl.so", "librccl.so.1"};
-    for (const char *n : names)  // a copy the process has loaded already (torch's) wins
-      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-    for (const char *n : paths)
-      if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!api.lib) {
-      const char *why = dlerror();  // (dlerror() clears the message: one call)
-      api.error = std::string("librccl not found: ") + (why ? why : "");
-      return;
-    }
-#define RCCL_SYM(field, name)                                                           \
-    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, name));            \
-    if (!api.field && api.error.empty()) api.error = std::string("librccl lacks ") + name;
-    RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommInitAll, "ncclCommInitAll")
-    RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(AllGather, "ncclAllGather") RCCL_SYM(GroupStart, "ncclGroupStart")
-    RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(GetErrorString, "ncclGetErrorString")
-#undef RCCL_SYM
-  });
-  return &api;
-}
-// RCCL prints a version banner on STDOUT when a process's first communicator comes up; a host that reports on stdout (a bench
-// line, DynSLAM's own logs piped to a tool) must not find it there: fd 1 points at stderr while the communicator is created.
-std::mutex g_stdoutSwapMutex;  // the descriptor swap is process-wide: one communicator creation at a time
-struct StdoutToStderr {
-  std::lock_guard<std::mutex> lock{g_stdoutSwapMutex};
-  int saved = -1;
-  StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
-  ~StdoutToStderr() { if (saved >= 0) { fflush(stdout); dup2(saved, 1); close(saved); } }
-};
-#define RCCL_TRY(api, expr)                                                                              \
-  do {                                                                                                   \
-    ncclResult_t _r = (expr);                                                                            \
-    if (_r != ncclSuccess) return fail(DSR_E_DEVICE, std::string(#expr) + ": " + (api)->GetErrorString(_r)); \
-  } while (0)
-
 }  // namespace
-
-// One exchange = the layer buffers of the fused preview on every GPU this process drives, the communicator(s) between them and
-// one stream per GPU (include/dsr.h "multi-GPU").  GROUP = one GPU's worth of ranks: the unit the collective sees.  The gathered
-// buffer holds groups x perGroup x slots layers of 8 bytes per pixel (float depth plane, then RGBA plane); a rank's own slots
-// lie INSIDE the gathered buffer of its GPU (in-place all-gather), so ranks that share a GPU exchange nothing at all.
-struct dsr_exchange {
-  int nRanks = 0, slots = 0, P = 0;
-  size_t layerBytes = 0, chunkBytes = 0;  // chunk = one group's share of the gathered buffer
-  int groups = 0, perGroup = 0;
-  std::vector<int> groupOfRank, indexInGroup;
-  bool rankMode = false;
-  struct Dev {
-    int device = 0, group = 0;
-    hipStream_t stream = nullptr;
-    uint8_t *all = nullptr;                 // gathered layers
-    uchar4 *targetRgba = nullptr;           // the exchange's own composite target (lazily)
-    float *targetDepth = nullptr;
-    ncclComm_t comm = nullptr;
-  };
-  std::vector<Dev> devs;                    // local GPUs
-  std::vector<int> devOfRank;               // index into devs, -1: a rank of another process
-  bool useRccl = false;
-};
-
-namespace {
-
-size_t layer_index(const dsr_exchange *x, int rank, int slot) {
-  return ((size_t)x->groupOfRank[rank] * x->perGroup + x->indexInGroup[rank]) * x->slots + slot;
-}
-dsr_exchange::Dev *local_dev(dsr_exchange *x, int rank) {
-  if (!x || rank < 0 || rank >= x->nRanks || x->devOfRank[rank] < 0) return nullptr;
-  return &x->devs[x->devOfRank[rank]];
-}
-void exchange_free(dsr_exchange *x) {
-  if (!x) return;
-  RcclApi *api = x->useRccl ? rccl_api() : nullptr;
-  for (auto &d : x->devs) {
-    (void)hipSetDevice(d.device);
-    if (d.stream) (void)hipStreamSynchronize(d.stream);
-    if (d.comm && api && api->CommDestroy) (void)api->CommDestroy(d.comm);
-    if (d.all) (void)hipFree(d.all);
-    if (d.targetRgba) (void)hipFree(d.targetRgba);
-    if (d.targetDepth) (void)hipFree(d.targetDepth);
-    if (d.stream) (void)hipStreamDestroy(d.stream);
-  }
-  delete x;
-}
-int exchange_alloc(dsr_exchange *x) {
-  x->layerBytes = (size_t)x->P * 8;
-  x->chunkBytes = x->layerBytes * x->perGroup * x->slots;
-  for (auto &d : x->devs) {
-    HIP_TRY(hipSetDevice(d.device));
-    HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d.all), x->chunkBytes * x->groups));
-    HIP_TRY(hipMemsetAsync(d.all, 0, x->chunkBytes * x->groups, d.stream));  // empty layers: depth 0 never wins a pixel
-    HIP_TRY(hipStreamSynchronize(d.stream));
-  }
-  return DSR_OK;
-}
-int exchange_target(dsr_exchange *x, dsr_exchange::Dev *d) {
-  if (d->targetRgba) return DSR_OK;
-  HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d->targetRgba), (size_t)x->P * 4));
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d->targetDepth), (size_t)x->P * 4));
-  HIP_TRY(hipMemsetAsync(d->targetRgba, 0, (size_t)x->P * 4, d->stream));
-  HIP_TRY(hipMemsetAsync(d->targetDepth, 0, (size_t)x->P * 4, d->stream));
-  return DSR_OK;
-}
-
-}  // namespace
-
-// ---- HBM ceiling probe kernel (dsr_measure_copy_bandwidth)
-typedef float copy_v4f __attribute__((ext_vector_type(4)));
-template <bool NT>
-__global__ __launch_bounds__(256) void k_copy16(const copy_v4f *__restrict__ in, copy_v4f *__restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);  // streaming: no reuse to keep in L2
-    else out[i] = in[i];
-  }
-}
 
 // per-pixel conversion kernels of the boundary (k_edges.h): device-resident and host-buffer drivers
 template <class K, class TI, class TO>
@@ -1160,9 +775,12 @@ int convert_host(K kernel, const void *in, size_t inBytes, void *out, size_t out
   return DSR_OK;
 }
 
-#define CHECK_E(e)                                          \
-  if (!(e)) return fail(DSR_E_ARG, "null engine");          \
-  { int _st = set_device(e); if (_st) return _st; }
+std::string &dsr_internal::last_error() {
+  thread_local std::string message;
+  return message;
+}
+int dsr_internal::engine_set_device(dsr_engine *e) { return set_device(e); }
+void dsr_internal::engine_prof_resolve(dsr_engine *e) { prof_resolve(e); }
 
 extern "C" {
 
@@ -1179,7 +797,7 @@ void dsr_default_settings(dsr_settings *s) {
   s->use_swapping = 0; s->use_bilateral_filter = 0; s->device = -1; s->sync_status = 1;
 }
 
-const char *dsr_last_error(void) { return g_err.c_str(); }
+const char *dsr_last_error(void) { return dsr_internal::last_error().c_str(); }
 
 int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_engine **out) {
   if (!settings || !calib || !out) return fail(DSR_E_ARG, "null argument");
@@ -1277,8 +895,9 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->live.visBlocksAlt, (size_t)e->noBlocks));
   e->live.ctrIdx = CTR_NO_VISIBLE_LIVE; e->freeview.ctrIdx = CTR_NO_VISIBLE_FREE;
   ALLOC(dmalloc(&e->tileSums, (size_t)e->numTilesMax + 1));
-  ALLOC(dmalloc(&e->integrateStats, (size_t)e->gridIntegrate * kIntegrateWaves));
-  (void)hipMemsetAsync(e->integrateStats, 0, (size_t)e->gridIntegrate * kIntegrateWaves * sizeof(uint2), e->stream);
+  e->integrateStatsCount = (size_t)e->gridIntegrate * kIntegrateWaves;
+  ALLOC(dmalloc(&e->integrateStats, e->integrateStatsCount));
+  (void)hipMemsetAsync(e->integrateStats, 0, e->integrateStatsCount * sizeof(uint2), e->stream);
   ALLOC(dmalloc(&e->rgb, (size_t)e->Wr * e->Hr));
   ALLOC(dmalloc(&e->depth, (size_t)e->P));
   ALLOC(dmalloc(&e->depthTmp, (size_t)e->P));
@@ -1497,26 +1116,6 @@ int dsr_set_view_float_dev(dsr_engine *e, const void *rgba_dev, const void *dept
 
 // view->rgb / view->depth ->UpdateHostFromDevice(): on the I/O stream, after the last kernel that wrote the view — not after
 // the fusion and the raycast that may be queued behind it on the engine's stream
-int dsr_pin_host_buffer(void *ptr, size_t bytes) {
-  if (!ptr || !bytes) return fail(DSR_E_ARG, "null buffer");
-  if (host_range_pinned(ptr, bytes)) return DSR_OK;
-  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-  std::lock_guard<std::mutex> lock(g_pinMutex);
-  g_pinned[(uintptr_t)ptr] = bytes;
-  return DSR_OK;
-}
-int dsr_unpin_host_buffer(void *ptr) {
-  if (!ptr) return fail(DSR_E_ARG, "null buffer");
-  {
-    std::lock_guard<std::mutex> lock(g_pinMutex);
-    auto it = g_pinned.find((uintptr_t)ptr);
-    if (it == g_pinned.end()) return fail(DSR_E_ARG, "not a buffer pinned through dsr_pin_host_buffer");
-    g_pinned.erase(it);
-  }
-  HIP_TRY(hipHostUnregister(ptr));
-  return DSR_OK;
-}
-
 int dsr_get_view(dsr_engine *e, uint8_t *rgba_out, float *depth_m_out) {
   CHECK_E(e);
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
@@ -1832,6 +1431,13 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
   return DSR_OK;
 }
 
+}  // extern "C"
+int dsr_internal::engine_render(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out,
+                                void *depth_out, bool outIsDevice) {
+  return render_common(e, type, pose_m, intrinsics, rgba_out, depth_out, outIsDevice);
+}
+extern "C" {
+
 int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], uint8_t *rgba_out,
                   float *depth_out) {
   CHECK_E(e);
@@ -1927,119 +1533,6 @@ int dsr_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m) {
   if (st) return st;
   if (err != hipSuccess) return fail(DSR_E_DEVICE, "clip copy failed");
   return DSR_OK;
-}
-
-// the text between <tag ...> and </tag> of the first such element at or after `from` (FileStorage XML is
-// flat enough for this: the node "depth-frame" holds <rows>, <cols>, <dt>, <data>)
-static bool xml_element(const std::string &doc, const char *tag, size_t from, size_t *begin, size_t *end) {
-  const std::string open = std::string("<") + tag;
-  size_t p0 = doc.find(open, from);
-  while (p0 != std::string::npos) {
-    const char c = p0 + open.size() < doc.size() ? doc[p0 + open.size()] : 0;
-    if (c == '>' || c == ' ' || c == '\t' || c == '\n' || c == '\r') break;
-    p0 = doc.find(open, p0 + 1);
-  }
-  if (p0 == std::string::npos) return false;
-  const size_t gt = doc.find('>', p0);
-  if (gt == std::string::npos) return false;
-  const size_t close = doc.find(std::string("</") + tag + ">", gt);
-  if (close == std::string::npos) return false;
-  *begin = gt + 1; *end = close;
-  return true;
-}
-static bool read_whole_file(const char *path, std::string *out) {
-  FILE *f = fopen(path, "rb");
-  if (!f) return false;
-  char buf[1 << 16];
-  size_t n;
-  while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
-  fclose(f);
-  return true;
-}
-
-static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
-  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
-  std::string doc;
-  if (!read_whole_file(path, &doc)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
-  size_t nb, ne, b, e2;
-  if (!xml_element(doc, "depth-frame", 0, &nb, &ne)) return fail(DSR_E_IO, "Could not read precomputed depth map.");
-  const std::string node = doc.substr(nb, ne - nb);
-  int rows = 0, cols = 0;
-  if (!xml_element(node, "rows", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <rows>");
-  rows = atoi(node.substr(b, e2 - b).c_str());
-  if (!xml_element(node, "cols", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <cols>");
-  cols = atoi(node.substr(b, e2 - b).c_str());
-  if (!xml_element(node, "dt", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <dt>");
-  std::string dt = node.substr(b, e2 - b);
-  dt.erase(std::remove_if(dt.begin(), dt.end(), [](char c) { return c == ' ' || c == '\n' || c == '\r' || c == '\t'; }), dt.end());
-  if (dt != "s") return fail(DSR_E_IO, "Precomputed depth map had the wrong format.");  // :42-44: CV_16SC1 only
-  // a size no camera produces is a malformed file, not something to allocate for (the size query hands it to the caller)
-  if ((long long)rows * cols > (1ll << 28) || rows > (1 << 20) || cols > (1 << 20)) return fail(DSR_E_IO, "depth-frame: implausible rows x cols");
-  *width = cols; *height = rows;
-  if (rows <= 0 || cols <= 0) return fail(DSR_E_IO, "Could not read precomputed depth map: empty matrix");
-  if (!depth_mm_out || (long long)rows * cols > capacity) return fail(DSR_E_ARG, "depth map larger than the buffer");
-  if (!xml_element(node, "data", 0, &b, &e2)) return fail(DSR_E_IO, "depth-frame without <data>");
-  const char *p = node.c_str() + b, *end = node.c_str() + e2;
-  const long long n = (long long)rows * cols;
-  long long i = 0;
-  while (i < n) {
-    while (p < end && (*p == ' ' || *p == '\n' || *p == '\r' || *p == '\t')) ++p;
-    if (p >= end) break;
-    char *next = nullptr;
-    const long v = strtol(p, &next, 10);
-    if (next == p) return fail(DSR_E_IO, "malformed <data> in depth-frame");
-    depth_mm_out[i++] = (int16_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));  // cv::saturate_cast<short>
-    p = next;
-  }
-  if (i != n) return fail(DSR_E_IO, "depth-frame <data> holds fewer values than rows x cols");
-  return DSR_OK;
-}
-
-static int read_pfm_impl(const char *path, float *out, int capacity, int *width, int *height) {
-  if (!path || !width || !height) return fail(DSR_E_ARG, "bad arguments");
-  FILE *f = fopen(path, "rb");
-  if (!f) return fail(DSR_E_IO, "Could not read precomputed depth map.");
-  char magic[3] = {0, 0, 0};
-  int w = 0, h = 0;
-  float scale = 0.0f;
-  // "Pf" <ws> width <ws> height <ws> scale <single whitespace byte> raster
-  if (fscanf(f, "%2s", magic) != 1 || strcmp(magic, "Pf") != 0 || fscanf(f, "%d %d %f", &w, &h, &scale) != 3) {
-    fclose(f);
-    return fail(DSR_E_IO, "not a single-channel PFM (\"Pf\") file");
-  }
-  (void)fgetc(f);
-  if ((long long)w * h > (1ll << 28) || w > (1 << 20) || h > (1 << 20)) { fclose(f); return fail(DSR_E_IO, "PFM: implausible width x height"); }
-  *width = w; *height = h;
-  if (w <= 0 || h <= 0) { fclose(f); return fail(DSR_E_IO, "Could not read precomputed depth map: empty image"); }
-  if (!out || (long long)w * h > capacity) { fclose(f); return fail(DSR_E_ARG, "PFM image larger than the buffer"); }
-  const bool fileLittle = scale < 0.0f;
-  const uint16_t probe = 1;
-  const bool hostLittle = *reinterpret_cast<const uint8_t *>(&probe) == 1;
-  for (int r = h - 1; r >= 0; --r) {  // the file's first row is the image's bottom row
-    float *row = out + (size_t)r * w;
-    if (fread(row, 4, (size_t)w, f) != (size_t)w) { fclose(f); return fail(DSR_E_IO, "PFM raster shorter than width x height"); }
-    if (fileLittle != hostLittle)
-      for (int c = 0; c < w; ++c) {
-        uint32_t v; memcpy(&v, row + c, 4);
-        v = (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
-        memcpy(row + c, &v, 4);
-      }
-  }
-  fclose(f);
-  return DSR_OK;
-}
-
-// The size is reported whenever the header could be read (DSR_OK, and DSR_E_ARG for a buffer that is too small: the
-// size query of a caller that allocates afterwards); after DSR_E_IO it is 0 x 0, never a half-parsed value.
-int dsr_read_depth_xml(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {
-  const int st = read_depth_xml_impl(path, depth_mm_out, capacity, width, height);
-  if (st == DSR_E_IO && width && height) *width = *height = 0;
-  return st;
-}
-int dsr_read_pfm(const char *path, float *out, int capacity, int *width, int *height) {
-  const int st = read_pfm_impl(path, out, capacity, width, height);
-  if (st == DSR_E_IO && width && height) *width = *height = 0;
-  return st;
 }
 
 // -> device-side address of the staged mask (see the ring's description in dsr_engine); `mask_slot_used` must be called
@@ -2277,319 +1770,6 @@ int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, 
   return remove_silhouette(e, nullptr, (const uint8_t *)mask_dev, x0, y0, box_w, box_h);
 }
 
-// ---- instance compositing
-
-int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
-                                const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
-                                int n_layers, int n_pixels, float tint_strength, int dim_background) {
-  if (!target_depth_dev || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
-  if (n_layers > 0 && (!layers_depth_dev || !track_ids || (target_rgba_dev && !layers_rgba_dev)))
-    return fail(DSR_E_ARG, "null layer buffers");
-  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
-  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
-  CompositeLayers none;
-  memset(&none, 0, sizeof none);
-  hipLaunchKernelGGL(k_composite<false>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
-                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
-                     (const float *)layers_depth_dev, none);
-  HIP_TRY(hipGetLastError());
-  return DSR_OK;
-}
-
-int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
-                                 const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
-                                 const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
-                                 int dim_background) {
-  if (!target_depth_dev || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
-  if (n_layers > 0 && (!layer_depth_ptrs || !track_ids || (target_rgba_dev && !layer_rgba_ptrs)))
-    return fail(DSR_E_ARG, "null layer buffers");
-  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
-  CompositeLayers lp;
-  memset(&lp, 0, sizeof lp);
-  for (int l = 0; l < n_layers; ++l) {
-    lp.depth[l] = (const float *)layer_depth_ptrs[l];
-    lp.rgba[l] = target_rgba_dev ? (const uchar4 *)layer_rgba_ptrs[l] : nullptr;
-    if (!lp.depth[l] || (target_rgba_dev && !lp.rgba[l])) return fail(DSR_E_ARG, "null layer buffers");
-  }
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
-  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
-  hipLaunchKernelGGL(k_composite<true>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
-                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
-  HIP_TRY(hipGetLastError());
-  return DSR_OK;
-}
-
-int dsr_composite_instances(uint8_t *target_rgba, float *target_depth, const uint8_t *layers_rgba,
-                            const float *layers_depth, const int32_t *track_ids, int n_layers, int n_pixels,
-                            float tint_strength, int dim_background) {
-  if (!target_depth || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
-  const size_t P = (size_t)n_pixels, L = (size_t)n_layers;
-  uchar4 *tR = nullptr, *lR = nullptr;
-  float *tD = nullptr, *lD = nullptr;
-  int st = DSR_OK;
-  auto cleanup = [&]() { if (tR) (void)hipFree(tR); if (lR) (void)hipFree(lR); if (tD) (void)hipFree(tD); if (lD) (void)hipFree(lD); };
-  if ((st = dmalloc(&tD, P))) { cleanup(); return st; }
-  if (L && (st = dmalloc(&lD, P * L))) { cleanup(); return st; }
-  if (target_rgba && (st = dmalloc(&tR, P))) { cleanup(); return st; }
-  if (target_rgba && L && (st = dmalloc(&lR, P * L))) { cleanup(); return st; }
-#define CP(expr) if ((expr) != hipSuccess) { cleanup(); return fail(DSR_E_DEVICE, "composite copy failed"); }
-  CP(hipMemcpy(tD, target_depth, P * 4, hipMemcpyHostToDevice));
-  if (L) CP(hipMemcpy(lD, layers_depth, P * L * 4, hipMemcpyHostToDevice));
-  if (tR) CP(hipMemcpy(tR, target_rgba, P * 4, hipMemcpyHostToDevice));
-  if (lR) CP(hipMemcpy(lR, layers_rgba, P * L * 4, hipMemcpyHostToDevice));
-  st = dsr_composite_instances_dev(-1, nullptr, tR, tD, lR, lD, track_ids, n_layers, n_pixels, tint_strength, dim_background);
-  if (st) { cleanup(); return st; }
-  CP(hipDeviceSynchronize());
-  CP(hipMemcpy(target_depth, tD, P * 4, hipMemcpyDeviceToHost));
-  if (tR) CP(hipMemcpy(target_rgba, tR, P * 4, hipMemcpyDeviceToHost));
-#undef CP
-  cleanup();
-  return DSR_OK;
-}
-
-// ---- multi-GPU exchange (include/dsr.h): layers of the fused preview, RCCL all-gather, composite
-
-static int exchange_create_common(dsr_exchange *x, int slots_per_rank, int n_pixels) {
-  if (slots_per_rank <= 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad exchange arguments");
-  x->slots = slots_per_rank; x->P = n_pixels;
-  return exchange_alloc(x);
-}
-
-int dsr_exchange_create(const int32_t *devices, int n_ranks, int slots_per_rank, int n_pixels, dsr_exchange **out) {
-  if (!devices || n_ranks <= 0 || !out) return fail(DSR_E_ARG, "bad exchange arguments");
-  int nDev = 0;
-  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail(DSR_E_DEVICE, "no HIP device: the exchange has no CPU fallback");
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  dsr_exchange *x = new (std::nothrow) dsr_exchange();
-  if (!x) return fail(DSR_E_NOMEM, "oom");
-  x->nRanks = n_ranks;
-  x->groupOfRank.assign(n_ranks, 0); x->indexInGroup.assign(n_ranks, 0); x->devOfRank.assign(n_ranks, -1);
-  std::vector<int> count;
-  for (int r = 0; r < n_ranks; ++r) {
-    const int dv = devices[r] < 0 ? prev : devices[r];
-    if (dv >= nDev) { delete x; return fail(DSR_E_ARG, "device ordinal out of range"); }
-    int g = -1;
-    for (size_t k = 0; k < x->devs.size(); ++k) if (x->devs[k].device == dv) g = (int)k;
-    if (g < 0) { dsr_exchange::Dev d; d.device = dv; d.group = (int)x->devs.size(); x->devs.push_back(d); count.push_back(0); g = d.group; }
-    x->groupOfRank[r] = g; x->indexInGroup[r] = count[g]++; x->devOfRank[r] = g;
-  }
-  x->groups = (int)x->devs.size();
-  x->perGroup = *std::max_element(count.begin(), count.end());
-  int st = exchange_create_common(x, slots_per_rank, n_pixels);
-  // one communicator rank per GPU; a single GPU has nothing to exchange (DSR_EXCHANGE_FORCE_RCCL: a 1-rank communicator anyway,
-  // so that the RCCL path runs on a one-GPU box)
-  if (st == DSR_OK && (x->groups > 1 || getenv("DSR_EXCHANGE_FORCE_RCCL"))) {
-    RcclApi *api = rccl_api();
-    if (!api->error.empty()) st = fail(DSR_E_DEVICE, api->error);
-    else {
-      std::vector<int> devlist; std::vector<ncclComm_t> comms(x->devs.size());
-      for (auto &d : x->devs) devlist.push_back(d.device);
-      ncclResult_t r;
-      { StdoutToStderr quiet; r = api->CommInitAll(comms.data(), (int)devlist.size(), devlist.data()); }
-      if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitAll: ") + api->GetErrorString(r));
-      else { for (size_t k = 0; k < comms.size(); ++k) x->devs[k].comm = comms[k]; x->useRccl = true; }
-    }
-  }
-  (void)hipSetDevice(prev);
-  if (st) { exchange_free(x); return st; }
-  *out = x;
-  return DSR_OK;
-}
-
-int dsr_exchange_unique_id(uint8_t id_out[128]) {
-  if (!id_out) return fail(DSR_E_ARG, "null");
-  static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
-  RcclApi *api = rccl_api();
-  if (!api->error.empty()) return fail(DSR_E_DEVICE, api->error);
-  ncclUniqueId id;
-  RCCL_TRY(api, api->GetUniqueId(&id));
-  memcpy(id_out, &id, sizeof id);
-  return DSR_OK;
-}
-
-int dsr_exchange_create_rank(const uint8_t unique_id[128], int world_size, int rank, int device, int slots_per_rank, int n_pixels,
-                             dsr_exchange **out) {
-  if (!unique_id || world_size <= 0 || rank < 0 || rank >= world_size || !out) return fail(DSR_E_ARG, "bad exchange arguments");
-  int nDev = 0;
-  if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail(DSR_E_DEVICE, "no HIP device: the exchange has no CPU fallback");
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  if (device < 0) device = prev;
-  if (device >= nDev) return fail(DSR_E_ARG, "device ordinal out of range");
-  RcclApi *api = rccl_api();
-  if (!api->error.empty()) return fail(DSR_E_DEVICE, api->error);
-  dsr_exchange *x = new (std::nothrow) dsr_exchange();
-  if (!x) return fail(DSR_E_NOMEM, "oom");
-  x->rankMode = true; x->nRanks = world_size; x->groups = world_size; x->perGroup = 1;
-  x->groupOfRank.resize(world_size); x->indexInGroup.assign(world_size, 0); x->devOfRank.assign(world_size, -1);
-  for (int r = 0; r < world_size; ++r) x->groupOfRank[r] = r;
-  dsr_exchange::Dev d; d.device = device; d.group = rank;
-  x->devs.push_back(d);
-  x->devOfRank[rank] = 0;
-  int st = exchange_create_common(x, slots_per_rank, n_pixels);
-  if (st == DSR_OK) {
-    ncclUniqueId id;
-    memcpy(&id, unique_id, sizeof id);
-    ncclResult_t r;
-    { StdoutToStderr quiet; r = (hipSetDevice(device) == hipSuccess) ? api->CommInitRank(&x->devs[0].comm, world_size, id, rank) : ncclUnhandledCudaError; }
-    if (r != ncclSuccess) st = fail(DSR_E_DEVICE, std::string("ncclCommInitRank: ") + api->GetErrorString(r));
-    else x->useRccl = true;
-  }
-  (void)hipSetDevice(prev);
-  if (st) { exchange_free(x); return st; }
-  *out = x;
-  return DSR_OK;
-}
-
-void dsr_exchange_destroy(dsr_exchange *x) {
-  int prev = 0;
-  const bool havePrev = hipGetDevice(&prev) == hipSuccess;
-  exchange_free(x);
-  if (havePrev) (void)hipSetDevice(prev);
-}
-
-void *dsr_exchange_stream(dsr_exchange *x, int rank) {
-  dsr_exchange::Dev *d = local_dev(x, rank);
-  return d ? (void *)d->stream : nullptr;
-}
-
-int dsr_exchange_layer_ptrs(dsr_exchange *x, int on_rank, int rank, int slot, void **rgba_dev, void **depth_dev) {
-  dsr_exchange::Dev *d = local_dev(x, on_rank);
-  if (!d || rank < 0 || rank >= x->nRanks || slot < 0 || slot >= x->slots) return fail(DSR_E_ARG, "bad exchange layer");
-  uint8_t *base = d->all + layer_index(x, rank, slot) * x->layerBytes;
-  if (depth_dev) *depth_dev = base;                       // float depth plane first,
-  if (rgba_dev) *rgba_dev = base + (size_t)x->P * 4;      // then the RGBA plane
-  return DSR_OK;
-}
-
-int dsr_exchange_slot_ptrs(dsr_exchange *x, int rank, int slot, void **rgba_dev, void **depth_dev) {
-  return dsr_exchange_layer_ptrs(x, rank, rank, slot, rgba_dev, depth_dev);
-}
-
-int dsr_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e, int type, const float pose_m[16],
-                             const float intrinsics[4]) {
-  dsr_exchange::Dev *d = local_dev(x, rank);
-  void *rgba = nullptr, *depth = nullptr;
-  if (!d || dsr_exchange_slot_ptrs(x, rank, slot, &rgba, &depth)) return fail(DSR_E_ARG, "bad exchange slot");
-  if (!e) {  // not visible in this frame: an empty layer
-    HIP_TRY(hipSetDevice(d->device));
-    HIP_TRY(hipMemsetAsync(depth, 0, (size_t)x->P * 4, d->stream));
-    return DSR_OK;
-  }
-  if (e->device != d->device) return fail(DSR_E_ARG, "the engine does not live on the rank's GPU");
-  if (e->P != x->P) return fail(DSR_E_ARG, "image size differs from the exchange's");
-  int st = dsr_wait_for_stream(e, d->stream);  // the previous gather / composite is done with this slot
-  if (st) return st;
-  if ((st = render_common(e, type, pose_m, intrinsics, rgba, depth, true))) return st;
-  return dsr_stream_wait_for_engine(e, d->stream);
-}
-
-int dsr_exchange_gather(dsr_exchange *x) {
-  if (!x) return fail(DSR_E_ARG, "null exchange");
-  if (!x->useRccl) return DSR_OK;  // one GPU: every layer is where the composite reads it
-  RcclApi *api = rccl_api();
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  RCCL_TRY(api, api->GroupStart());
-  ncclResult_t r = ncclSuccess;
-  for (auto &d : x->devs) {
-    if (hipSetDevice(d.device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
-    r = api->AllGather(d.all + (size_t)d.group * x->chunkBytes, d.all, x->chunkBytes, ncclUint8, d.comm, d.stream);  // in place
-    if (r != ncclSuccess) break;
-  }
-  const ncclResult_t r2 = api->GroupEnd();
-  (void)hipSetDevice(prev);
-  if (r != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclAllGather: ") + api->GetErrorString(r));
-  if (r2 != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclGroupEnd: ") + api->GetErrorString(r2));
-  return DSR_OK;
-}
-
-int dsr_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba_dev, void **depth_dev) {
-  dsr_exchange::Dev *d = local_dev(x, rank);
-  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
-  int st = exchange_target(x, d);
-  if (st) return st;
-  if (rgba_dev) *rgba_dev = d->targetRgba;
-  if (depth_dev) *depth_dev = d->targetDepth;
-  return DSR_OK;
-}
-
-int dsr_exchange_clear_target(dsr_exchange *x, int rank) {
-  dsr_exchange::Dev *d = local_dev(x, rank);
-  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
-  int st = exchange_target(x, d);
-  if (st) return st;
-  HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipMemsetAsync(d->targetRgba, 0, (size_t)x->P * 4, d->stream));
-  HIP_TRY(hipMemsetAsync(d->targetDepth, 0, (size_t)x->P * 4, d->stream));
-  return DSR_OK;
-}
-
-int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev, void *target_depth_dev,
-                           const int32_t *ranks, const int32_t *slots, const int32_t *track_ids, int n_layers, float tint_strength,
-                           int dim_background) {
-  dsr_exchange::Dev *d = local_dev(x, root_rank);
-  if (!d || n_layers < 0 || (n_layers > 0 && (!ranks || !slots || !track_ids))) return fail(DSR_E_ARG, "bad composite arguments");
-  if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
-  int st = DSR_OK;
-  if (!target_depth_dev) {
-    if ((st = exchange_target(x, d))) return st;
-    target_rgba_dev = d->targetRgba; target_depth_dev = d->targetDepth;
-  }
-  if (target_engine) {
-    if (target_engine->device != d->device) return fail(DSR_E_ARG, "the target's engine does not live on the root's GPU");
-    if ((st = dsr_stream_wait_for_engine(target_engine, d->stream))) return st;  // its render of the target
-  }
-  const void *rp[kMaxCompositeLayers], *dp[kMaxCompositeLayers];
-  for (int l = 0; l < n_layers; ++l) {
-    void *r = nullptr, *dd = nullptr;
-    if ((st = dsr_exchange_layer_ptrs(x, root_rank, ranks[l], slots[l], &r, &dd))) return st;
-    rp[l] = r; dp[l] = dd;
-  }
-  if (n_layers > 0 &&
-      (st = dsr_composite_layer_ptrs_dev(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
-                                         track_ids, n_layers, x->P, tint_strength, dim_background)))
-    return st;
-  if (target_engine) return dsr_wait_for_stream(target_engine, d->stream);  // its next render of the target waits for the composite
-  return DSR_OK;
-}
-
-int dsr_exchange_gather_and_composite(dsr_exchange *x, int root_rank, dsr_engine *target_engine, void *target_rgba_dev,
-                                      void *target_depth_dev, const int32_t *ranks, const int32_t *slots, const int32_t *track_ids,
-                                      int n_layers, float tint_strength, int dim_background) {
-  int st = dsr_exchange_gather(x);
-  if (st) return st;
-  if (!local_dev(x, root_rank)) return DSR_OK;  // this process does not hold the consumer of the preview
-  return dsr_exchange_composite(x, root_rank, target_engine, target_rgba_dev, target_depth_dev, ranks, slots, track_ids, n_layers,
-                                tint_strength, dim_background);
-}
-
-int dsr_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float *depth_out) {
-  dsr_exchange::Dev *d = local_dev(x, rank);
-  if (!d) return fail(DSR_E_ARG, "bad exchange rank");
-  int st = exchange_target(x, d);
-  if (st) return st;
-  HIP_TRY(hipSetDevice(d->device));
-  if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, d->targetRgba, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));
-  if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d->targetDepth, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  return DSR_OK;
-}
-
-int dsr_exchange_sync(dsr_exchange *x) {
-  if (!x) return fail(DSR_E_ARG, "null exchange");
-  int prev = 0;
-  (void)hipGetDevice(&prev);
-  for (auto &d : x->devs) {
-    HIP_TRY(hipSetDevice(d.device));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-  }
-  (void)hipSetDevice(prev);
-  return DSR_OK;
-}
-
 int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored) {
   CHECK_E(e);
   if (!e->scene.swapState) return fail(DSR_E_ARG, "swapping is not enabled");
@@ -2734,71 +1914,6 @@ int dsr_save_scene_to_mesh(dsr_engine *e, const char *path) {
   return st;
 }
 
-// ---- self-test
-
-__global__ __launch_bounds__(256) void k_selftest_division(unsigned long long n, unsigned long long seed,
-                                                           unsigned long long *mismatches) {
-  const float y32767 = rcp_refined(32767.0f), y255 = rcp_refined(255.0f);
-  unsigned long long bad = 0;
-  const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  // exhaustive small domains
-  if (tid < 65536) {
-    const float a = (float)(short)(int)(tid - 32768);
-    if (__float_as_uint(div_with_rcp(a, 32767.0f, y32767)) != __float_as_uint(a / 32767.0f)) bad++;
-  }
-  if (tid < 256) {
-    const float a = (float)(int)tid;
-    if (__float_as_uint(div_with_rcp(a, 255.0f, y255)) != __float_as_uint(a / 255.0f)) bad++;
-  }
-  for (unsigned long long i = tid; i < n; i += stride) {
-    // splitmix64
-    unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    // a: sign, exponent in [-40, 40]; b: sign, exponent in [-34, 40] (>= 1e-10: the smallest divisor a
-    // call site lets through is the frustum test's),
-    // random mantissas; every 16th pair uses small integers (weights) as divisor
-    const unsigned ma = (unsigned)(z & 0x7fffffu), mb = (unsigned)((z >> 23) & 0x7fffffu);
-    const int ea = (int)((z >> 46) % 81) - 40, eb = (int)((z >> 53) % 75) - 34;
-    float a = __uint_as_float(((unsigned)(ea + 127) << 23) | ma);
-    float b = __uint_as_float(((unsigned)(eb + 127) << 23) | mb);
-    if (z >> 63) a = -a;
-    if ((z >> 62) & 1) b = -b;
-    if ((i & 15) == 0) b = (float)(1 + (int)((z >> 23) & 0x1ff));
-    if ((i & 255) == 1) a = 0.0f;
-    const float q = a / b;
-    if (!(fabsf(q) == 0.0f || (fabsf(q) >= 1.17549435e-38f && fabsf(q) < 3.0e38f))) continue;  // not tame
-    if (__float_as_uint(fdiv_tame(a, b)) != __float_as_uint(q)) bad++;
-    const float yb = rcp_refined(b);
-    if (__float_as_uint(div_with_rcp(a, b, yb)) != __float_as_uint(q)) bad++;
-  }
-  if (bad) atomicAdd(mismatches, bad);
-}
-
-int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *mismatches) {
-  if (!mismatches) return fail(DSR_E_ARG, "null");
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
-  unsigned long long *d = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 8));
-  HIP_TRY(hipMemset(d, 0, 8));
-  hipLaunchKernelGGL(k_selftest_division, dim3(4096), dim3(256), 0, 0, (unsigned long long)n, (unsigned long long)seed, d);
-  // the divisors the one-correction form is used with: the constants, every integer weight, and
-  // the truncation bands of the presets (an engine checks its own mu at creation)
-  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, 32767.0f, d);
-  hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, 255.0f, d);
-  for (int w = 1; w <= 256; ++w) hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, (float)w, d);
-  for (float mu : {0.02f, 0.016f, 0.2f, 0.14f, 0.1f, 0.3f, 0.05f, 0.04f, 0.08f, 0.5f, 1.0f, 4.0f})
-    hipLaunchKernelGGL(k_check_short_division, dim3(1024), dim3(256), 0, 0, mu, d);
-  unsigned long long h = 0;
-  hipError_t err = hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
-  (void)hipFree(d);
-  if (err != hipSuccess) return fail(DSR_E_DEVICE, "selftest failed to run");
-  *mismatches = h;
-  return DSR_OK;
-}
-
 #ifdef DSR_RAYCAST_STATS
 // measurement builds only (tools/raycast_wave_stats.py): where k_raycast writes its 12 words per wave
 int dsr_debug_raycast_stats(void *dev_buf) {
@@ -2807,51 +1922,6 @@ int dsr_debug_raycast_stats(void *dev_buf) {
   return DSR_OK;
 }
 #endif
-
-// ---- HBM ceiling probe (roofline harness)
-
-int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gbps_out) {
-  if (!gbps_out || bytes < 16 || iters <= 0) return fail(DSR_E_ARG, "bad bandwidth probe arguments");
-  if (device >= 0) HIP_TRY(hipSetDevice(device));
-  float4 *a = nullptr, *b = nullptr;
-  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&a), bytes));
-  if (hipMalloc(reinterpret_cast<void **>(&b), bytes) != hipSuccess) { (void)hipFree(a); return fail(DSR_E_NOMEM, "probe buffers"); }
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  hipError_t err = hipMemset(a, 1, bytes);
-  if (err == hipSuccess) err = hipMemset(b, 2, bytes);
-  if (err == hipSuccess) err = hipEventCreate(&e0);
-  if (err == hipSuccess) err = hipEventCreate(&e1);
-  // The ceiling a copy kernel reaches depends on its launch shape (4.57 TB/s with one fixed shape where the
-  // guide's float4 copy reaches 6.29): three grids x plain / non-temporal accesses, `iters` passes each, the BEST is reported.
-  float ms = 0.0f;
-  if (err == hipSuccess) {
-    const size_t n = bytes / 16;
-    float best = 0.0f;
-    for (int variant = 0; variant < 6 && err == hipSuccess; ++variant) {
-      const int grid = 256 * (variant % 3 == 0 ? 4 : variant % 3 == 1 ? 8 : 16);  // 4 / 8 / 16 workgroups per CU, grid-stride
-      const bool nt = variant >= 3;
-      auto launch = [&]() {
-        if (nt) hipLaunchKernelGGL((k_copy16<true>), dim3(grid), dim3(256), 0, 0, (const copy_v4f *)a, (copy_v4f *)b, n);
-        else hipLaunchKernelGGL((k_copy16<false>), dim3(grid), dim3(256), 0, 0, (const copy_v4f *)a, (copy_v4f *)b, n);
-      };
-      launch();
-      (void)hipEventRecord(e0, 0);
-      for (int i = 0; i < iters; ++i) launch();
-      (void)hipEventRecord(e1, 0);
-      err = hipEventSynchronize(e1);
-      float t = 0.0f;
-      if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
-      if (err == hipSuccess && t > 0.0f && (best == 0.0f || t < best)) best = t;
-    }
-    ms = best;
-  }
-  if (e0) (void)hipEventDestroy(e0);
-  if (e1) (void)hipEventDestroy(e1);
-  (void)hipFree(a); (void)hipFree(b);
-  if (err != hipSuccess || !(ms > 0.0f)) return fail(DSR_E_DEVICE, "bandwidth probe failed");
-  *gbps_out = 2.0 * (double)(bytes / 16 * 16) * iters / ((double)ms * 1e-3) / 1e9;
-  return DSR_OK;
-}
 
 // ---- statistics / dumps
 
@@ -3015,75 +2085,6 @@ int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycas
   if (raycast_image) HIP_TRY(hipMemcpyAsync(raycast_image, rs.raycastImage, P * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return DSR_OK;
-}
-
-// ---- profiling
-
-int dsr_profile_enable(dsr_engine *e, int enable) {
-  CHECK_E(e);
-  if (!enable) prof_resolve(e);
-  e->profiling = enable == 2 ? 2 : (enable != 0);
-  return DSR_OK;
-}
-
-int dsr_profile_reset(dsr_engine *e) {
-  CHECK_E(e);
-  prof_resolve(e);
-  for (auto &r : e->profRecs) { r.ms = 0; r.launches = 0; }
-  // work counters restart as well (decayed-block count is kept)
-  unsigned long long zero = 0;
-  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_INTEGRATED, &zero, 8, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_EXPECTED, &zero, 8, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->scene.work + WORK_V_DECAY, &zero, 8, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemsetAsync(e->integrateStats, 0, (size_t)e->gridIntegrate * kIntegrateWaves * sizeof(uint2), e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  return DSR_OK;
-}
-
-int dsr_profile_get(dsr_engine *e, dsr_kernel_time *out, int cap) {
-  if (!e || !out || cap <= 0) return 0;
-  if (set_device(e)) return 0;
-  prof_resolve(e);
-  unsigned long long work[WORK_COUNT];
-  if (hipMemcpy(work, e->scene.work, sizeof work, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  const double P = (double)e->P, E = (double)e->E, B = (double)kBlockBytes;
-  // k_integrate's own tallies: lanes that stored their 24 B of depth planes, voxels that got colour
-  double storeLanes = 0.0, colourVoxels = 0.0;
-  {
-    std::vector<uint2> ws((size_t)e->gridIntegrate * kIntegrateWaves);
-    if (hipMemcpy(ws.data(), e->integrateStats, ws.size() * sizeof(uint2), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    for (const uint2 &w : ws) { storeLanes += (double)w.x; colourVoxels += (double)w.y; }
-  }
-  int n = 0;
-  for (auto &r : e->profRecs) {
-    if (n >= cap) break;
-    if (r.launches == 0) continue;
-    dsr_kernel_time &k = out[n++];
-    memset(&k, 0, sizeof k);
-    strncpy(k.name, r.name.c_str(), sizeof k.name - 1);
-    k.total_ms = r.ms; k.launches = r.launches;
-    const double L = (double)r.launches;
-    // algorithmic bytes, SURVEY.md 8(d) / DESIGN.md "byte model"
-    if (r.name == "integrate") {
-      const double V = (double)work[WORK_V_INTEGRATED];
-      k.bytes = V * (16.0 + 2.0 * B) + L * 8.0 * P;  // the reference's AoS formulation
-      // what THIS layout has to move (DESIGN.md "byte model"): per visible block its list id (4 B), hash
-      // entry (16 B) and the sdf + w_depth planes (1536 B) read; 24 B written back per lane that updated
-      // a voxel; per colour voxel ONE 4-byte word (r, g, b, w_color) read and written; the depth and RGB frames (8 B per pixel)
-      k.bytes_layout = V * (4.0 + 16.0 + 1536.0) + storeLanes * 24.0 + colourVoxels * 8.0 + L * 8.0 * P;
-      k.units = V;
-      k.store_lanes = storeLanes; k.colour_voxels = colourVoxels;
-    }
-    else if (r.name == "depth_to_float") k.bytes = L * 6.0 * P;
-    else if (r.name == "expected_depth") k.bytes = (double)work[WORK_V_EXPECTED] * 16.0 + L * 8.0 * std::ceil(e->W / 8.0) * std::ceil(e->H / 8.0);
-    else if (r.name == "icp_maps") k.bytes = L * P * (16.0 + 16.0 + 16.0 + 4.0);
-    else if (r.name == "alloc_commit") k.bytes = L * E / 8.0;
-    else if (r.name == "visible_count") k.bytes = L * E * 1.0;
-    else if (r.name == "visible_write") k.bytes = L * E * 1.0;
-    else if (r.name == "decay_blocks") k.bytes = (double)work[WORK_V_DECAY] * (16.0 + 2.0 * B);
-    else k.bytes = 0.0;
-  }
-  return n;
 }
 
 }  // extern "C"

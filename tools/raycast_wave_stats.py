@@ -27,7 +27,7 @@ LIB = os.path.join(ROOT, "dynslam_amd", "csrc", "libdsr_hip_rcstats.so")
 
 def build():
     import __graft_entry__ as g
-    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + g.HIPCC_FLAGS + ["-DDSR_RAYCAST_STATS", "-o", LIB, "dsr_engine.hip"]
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + g.HIPCC_FLAGS + ["-DDSR_RAYCAST_STATS", "-o", LIB] + g.HIP_SOURCES  # (one step, every translation unit)
     subprocess.check_call(cmd, cwd=g.CSRC)
     print(LIB)
 
