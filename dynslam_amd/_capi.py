@@ -98,6 +98,7 @@ SIGNATURES = {
     "wait_for_stream": (C.c_int, [_H, _P]),
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "engine_share_stream": (C.c_int, [_H, _H]),
+    "pin_host_thread": (C.c_int, [C.c_int]),
     "update_view": (C.c_int, [_H, _P, _P]),
     "update_view_dev": (C.c_int, [_H, _P, _P]),
     "update_view_bgr": (C.c_int, [_H, _P, _P]),

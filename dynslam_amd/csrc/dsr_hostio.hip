@@ -1,6 +1,10 @@
 // dsr_hostio.hip — host-side I/O at the boundary: the precomputed depth / disparity maps DynSLAM reads from disk
 // (PrecomputedDepthProvider.cpp:22-75: OpenCV FileStorage XML with int16 millimetres, pfmLib .pfm with float disparities) and the
 // page-locking of the host's persistent frame / preview buffers.  No kernels here: parsing files is not GPU work.
+#include <sched.h>
+
+#include <cctype>
+
 #include "dsr_internal.h"
 
 namespace {
@@ -64,6 +68,35 @@ static bool read_whole_file(const char *path, std::string *out) {
   while ((n = fread(buf, 1, sizeof buf, f)) > 0) out->append(buf, n);
   fclose(f);
   return true;
+}
+
+// The calling thread onto the CPUs next to the GPU (the PCI device's local_cpulist): DynSLAM's host thread copies ~7.5 MB of
+// frames and previews per frame to and from pinned memory and polls status words the GPU writes — on a two-socket box both are
+// cheaper from the GPU's own NUMA node.  Nothing happens (DSR_OK) where the kernel does not publish the list.
+int dsr_pin_host_thread(int device) {
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(DSR_E_DEVICE, "no current HIP device");
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) != hipSuccess) return fail(DSR_E_DEVICE, "hipDeviceGetPCIBusId failed");
+  for (char *c = bus; *c; ++c) *c = (char)tolower(*c);
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+  std::string list;
+  if (!read_whole_file(path.c_str(), &list)) return DSR_OK;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (const char *q = list.c_str(); *q;) {  // "0-63,128-191"
+    char *end = nullptr;
+    const long a = strtol(q, &end, 10);
+    if (end == q) break;
+    long b2 = a;
+    q = end;
+    if (*q == '-') { b2 = strtol(q + 1, &end, 10); q = end; }
+    for (long c = a; c <= b2 && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); ++n; }
+    if (*q == ',') ++q; else break;
+  }
+  if (n > 0 && sched_setaffinity(0, sizeof set, &set) != 0) return fail(DSR_E_DEVICE, "sched_setaffinity failed");
+  return DSR_OK;
 }
 
 static int read_depth_xml_impl(const char *path, int16_t *depth_mm_out, int capacity, int *width, int *height) {

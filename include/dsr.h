@@ -207,6 +207,10 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
  * the renders of the pair are then ordered by one queue and the frame contains no cross-stream event.  Both engines on one
  * GPU, driven from one thread, `e` idle, neither with a pipelined view; destroy `e` before or after `owner`, either works. */
 int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner);
+/* (ABI 4) Restrict the CALLING thread to the CPUs next to `device` (< 0: the current one) — the PCI device's local_cpulist.
+ * DynSLAM's host thread moves ~7.5 MB of frames / previews per frame through pinned memory and polls words the GPU writes; on
+ * a multi-socket host that is cheaper from the GPU's own NUMA node.  DSR_OK and no effect where the list is not published. */
+int dsr_pin_host_thread(int device);
 
 /* ---- view ------------------------------------------------------------------- */
 

@@ -1967,6 +1967,7 @@ int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (m
 
 /* stream ordering / bandwidth probe: nothing to order or measure on the CPU */
 int orc_wait_for_stream(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
+int orc_pin_host_thread(int) { return DSR_OK; }  // no GPU to be near to
 int orc_engine_share_stream(dsr_engine *h, dsr_engine *owner) { return (h && owner && h != owner) ? DSR_OK : DSR_E_ARG; }  // no streams here
 int orc_stream_wait_for_engine(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_measure_copy_bandwidth(int, uint64_t, int, double *gbps_out) { if (gbps_out) *gbps_out = 0.0; return DSR_OK; }

@@ -158,6 +158,10 @@ int main(int argc, char **argv) {
   const int decayMaxW = decay ? atoi(argv[15]) : 0, decayMinAge = decay ? atoi(argv[16]) : 0;
   const size_t P = (size_t)W * H;
 
+  // The host thread next to the GPU's NUMA node BEFORE the frame buffers are allocated and touched (first touch places them): the
+  // same command line read 223-275 or 439-460 frames/s at configs[2] depending on which process started it —
+  // a child inherits its parent's CPU affinity and memory policy.  DSR_HOST_NO_PIN=1: leave the thread where it is (A/B).
+  if (!std::getenv("DSR_HOST_NO_PIN")) (void)dsr_pin_host_thread(devices.empty() ? -1 : devices[0]);
   ITMLibSettings settings;
   settings.sceneParams.voxelSize = (float)atof(argv[10]); settings.sceneParams.mu = (float)atof(argv[11]);
   settings.sceneParams.maxW = 100; settings.sceneParams.viewFrustum_min = 0.2f; settings.sceneParams.viewFrustum_max = 30.0f;
