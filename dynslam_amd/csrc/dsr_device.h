@@ -98,7 +98,8 @@ struct SceneP {
   uint8_t **hostSlabs;    // device-visible table of the pinned host slabs (slabBlocks blocks each)
   int slabBlocks;
   // instance-sized volumes only (k_small.h; null otherwise): one bit per entry, kSmallBitWords words each
-  uint32_t *visBits;      // entries whose visible type the running frame's mark / commit set (cleared by the list kernel)
+  uint8_t *visGrp;        // one BYTE per 8 entries: the running frame's mark touched an entry of the group (plain stores, no atomics)
+  uint32_t *visBits;      // one BIT per entry: visible in the running frame — built and cleared by the list kernel itself
   uint32_t *allocBits;    // entries that own a voxel block (ptr >= 0): set by the commit, cleared by the voxel GC
 };
 

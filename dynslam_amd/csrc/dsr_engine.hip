@@ -197,6 +197,7 @@ int reset_scene(dsr_engine *e) {
   HIP_TRY(hipMemsetAsync(e->scene.allocGrp, 0, (size_t)e->numTilesE * (kTile / 32) * 4, e->stream));
   HIP_TRY(hipMemsetAsync(e->scene.allocTile, 0, ((size_t)e->numTilesE + 1) * 8, e->stream));
   if (e->scene.visBits) {
+    HIP_TRY(hipMemsetAsync(e->scene.visGrp, 0, (size_t)kSmallBitWords * 4, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.visBits, 0, (size_t)kSmallBitWords * 4, e->stream));
     HIP_TRY(hipMemsetAsync(e->scene.allocBits, 0, (size_t)kSmallBitWords * 4, e->stream));
   }
@@ -214,7 +215,7 @@ void free_all(dsr_engine *e) {
   auto F = [](void *p) { if (p) (void)hipFree(p); };
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
   F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
-  F(e->scene.visBits); F(e->scene.allocBits);
+  F(e->scene.visGrp); F(e->scene.visBits); F(e->scene.allocBits);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
   }
@@ -874,9 +875,10 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   ALLOC(dmalloc(&e->scene.allocTile, (size_t)e->numTilesE + 1));
   {
     const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
-    e->smallPath = e->smallVolume && !s.use_swapping && e->E <= kSmallMaxEntries && e->numTilesE <= kSmallMaxTiles &&
+    e->smallPath = e->smallVolume && !s.use_swapping && e->E <= kSmallMaxEntries && e->E % 8 == 0 && e->numTilesE <= kSmallMaxTiles &&
                    small_lds_bytes(cells) <= 64 * 1024;
     if (e->smallPath) {
+      ALLOC(dmalloc(&e->scene.visGrp, (size_t)kSmallBitWords * 4));
       ALLOC(dmalloc(&e->scene.visBits, (size_t)kSmallBitWords));
       ALLOC(dmalloc(&e->scene.allocBits, (size_t)kSmallBitWords));
     }

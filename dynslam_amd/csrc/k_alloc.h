@@ -127,21 +127,14 @@ __host__ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float 
 
 // K1: per-pixel mark.  16x16 pixel tiles (a wave covers 16x4 pixels: neighbouring rays
 // probe the same buckets, which keeps the 16-byte entry gathers in L2).
-// BITS (instance-sized volumes, k_small.h): every entry whose visible type is set here also gets its bit in s.visBits — the
-// one-workgroup list kernel that follows finds the frame's visible entries in 147 KB of bits instead of 1.18 MB of types.
-// The 64 rays of a wave walk through the same few blocks, and a bit per step and lane is ~300 atomics on each of a few hundred
-// words per frame — serialised at L2, 2.9 ms for a kernel of 20 us (profiles/r05a_instance_frame_ab.log).  So the wave first
-// agrees on its DISTINCT entries (a handful) and one lane per entry issues the atomic: call with every lane that runs the loop.
-__device__ __forceinline__ void touch_vis_bits(const SceneP &s, uint32_t entry, bool want) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long pending = __ballot(want);
-  while (pending) {
-    const int leader = __ffsll((long long)pending) - 1;
-    const uint32_t e = (uint32_t)__shfl((int)entry, leader);
-    pending &= ~__ballot(want && entry == e);
-    if (lane == leader) atomicOr(&s.visBits[e >> 5], 1u << (e & 31u));
-  }
-}
+// BITS (instance-sized volumes, k_small.h): the one-workgroup list kernel that follows must find the entries this kernel
+// touched without sweeping 1.18 MB of types.  Atomics are out: the 64 rays of a wave walk through the same few blocks, a bit per
+// step and lane is ~300 atomic ORs on each of a few hundred words — 2.9 ms for a kernel of 20 us, still 122 us with one atomic per
+// distinct entry of a wave (profiles/r05a_, r05c_instance_frame_ab.log).  So only PLAIN byte stores here: the type is written as
+// kTouchedNow (1 with the top bit set: "set by THIS frame's mark", which a type left from an earlier frame never carries) and
+// the byte of the entry's group of 8 in s.visGrp is set; the list kernel reads the few marked groups' types, turns them into
+// bits and puts the plain 1 back (k_small.h phase D0).
+constexpr uint8_t kTouchedNow = 0x81;
 template <bool BITS>
 __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
                                                  uint8_t *__restrict__ visType, int x, int y) {
@@ -173,7 +166,6 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
     // what each of the four steps marks for allocation: entry index (kNoTarget: nothing) and whether it is a chain append
     constexpr uint32_t kNoTarget = 0xffffffffu;
     uint32_t tgt[4] = {kNoTarget, kNoTarget, kNoTarget, kNoTarget};
-    uint32_t seen[4] = {kNoTarget, kNoTarget, kNoTarget, kNoTarget};  // BITS: the entry whose visible type the step set
     bool exc[4] = {false, false, false, false};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -185,8 +177,8 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
       int firstFree = -1;
       dsr_hash_entry he = head[k];
       if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
-        visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
-        if (BITS) seen[k] = hashIdx;
+        if (BITS) { visType[hashIdx] = kTouchedNow; s.visGrp[hashIdx >> 3] = 1; }  // (no swapped-out entries on this path)
+        else visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
         isFound = true;
       }
       if (!isFound) {
@@ -195,8 +187,8 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
           hashIdx = (uint32_t)(p.noBuckets + he.offset - 1);
           he = load_entry(s.table, hashIdx);
           if (he.pos[0] == bx && he.pos[1] == by && he.pos[2] == bz && he.ptr >= -1) {
-            visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
-            if (BITS) seen[k] = hashIdx;
+            if (BITS) { visType[hashIdx] = kTouchedNow; s.visGrp[hashIdx >> 3] = 1; }
+            else visType[hashIdx] = (he.ptr == -1) ? (uint8_t)2 : (uint8_t)1;
             isFound = true;
             break;
           }
@@ -206,8 +198,8 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
           const bool isExcess = firstFree < 0;
           const uint32_t target = isExcess ? hashIdx : (uint32_t)firstFree;
           if (!isExcess) {
-            visType[target] = 1;
-            if (BITS) seen[k] = target;
+            if (BITS) { visType[target] = kTouchedNow; s.visGrp[target >> 3] = 1; }
+            else visType[target] = 1;
           }
           tgt[k] = target; exc[k] = isExcess;
         }
@@ -218,10 +210,6 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
     // wave.  Atomics of one lane on one address are performed in program order, so when two steps of a ray name the same
     // entry the first still sees 0 and counts it, the second does not.  (Sending the idle steps to one spare word instead of
     // predicating them was tried: 16 ms of same-address contention.)
-    if (BITS) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) touch_vis_bits(s, seen[k], seen[k] != kNoTarget);
-    }
     uint32_t old[4] = {1u, 1u, 1u, 1u};
 #pragma unroll
     for (int k = 0; k < 4; ++k)

@@ -107,6 +107,7 @@ __device__ __forceinline__ int small_sweep_bits(uint32_t *plane, int32_t *ids, i
 //   A  tile totals of the marks -> offsets, free-list heads (k_scan_tile_sums SCAN_ALLOC)
 //   B  commit: a thread per sweep tile that holds marks ranks them into the ordered work list (k_alloc_commit)
 //   C  apply: the work list densely (k_alloc_apply)
+//   D0 the mark's touched groups -> bits of visBits, the types' "touched now" flag taken off again
 //   D  the previous frame's visible entries the mark did not touch: frustum test, type 3 / 0 (k_retest_previous_visible)
 //   E  only after a frame whose visible entries did not fit the list: the type sweep over the whole table (K0b's rare branch)
 //   F  ordered compaction of visBits -> visibleEntryIDs, counts, published status (k_visible_count / scan / k_visible_write)
@@ -149,49 +150,86 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p,
     int rank12 = tileOff.x, rank2 = tileOff.y;
     const int tileBase = tid * kTile;
     uint4 *grp4 = reinterpret_cast<uint4 *>(s.allocGrp + (tileBase >> 5));
+#pragma unroll 1
     for (int q = 0; q < kTile / 32 / 16; ++q) {
       uint4 g4[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) g4[r] = grp4[q * 4 + r];
+      uint32_t any = 0u;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if ((g4[r].x | g4[r].y | g4[r].z | g4[r].w) == 0u) continue;
-        grp4[q * 4 + r] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame
-        const uint32_t gw[4] = {g4[r].x, g4[r].y, g4[r].z, g4[r].w};
+      for (int r = 0; r < 4; ++r) any |= g4[r].x | g4[r].y | g4[r].z | g4[r].w;
+      if (any == 0u) continue;
+      // the rare part re-reads its words one by one (from L1): small code instead of sixteen unrolled copies of it
+      const uint32_t *words = s.allocGrp + (tileBase >> 5) + q * 16;
+#pragma unroll 1
+      for (int wq = 0; wq < 16; ++wq) {
+        const uint32_t word = words[wq];
+        if (word == 0u) continue;
+#pragma unroll 1
+        for (int gi = 0; gi < 4; ++gi) {
+          if (((word >> (gi * 8)) & 15u) == 0u) continue;
+          const int base = tileBase + (q * 16 + wq) * 32 + gi * 8;  // this group of 8 entries
+          uint32_t key[kTileItems];
+          int ptrOf[kTileItems];
 #pragma unroll
-        for (int wi = 0; wi < 4; ++wi) {
-          if (gw[wi] == 0u) continue;
-          for (int gi = 0; gi < 4; ++gi) {
-            if (((gw[wi] >> (gi * 8)) & 15u) == 0u) continue;
-            const int base = tileBase + ((q * 4 + r) * 4 + wi) * 32 + gi * 8;  // this group of 8 entries
-            uint32_t key[kTileItems];
-            int ptrOf[kTileItems];
+          for (int j = 0; j < kTileItems; ++j) {
+            const int t = base + j < p.noTotalEntries ? base + j : p.noTotalEntries - 1;
+            key[j] = s.allocKey[t];
+            ptrOf[j] = s.table[t].ptr;
+          }
 #pragma unroll
-            for (int j = 0; j < kTileItems; ++j) {
-              const int t = base + j < p.noTotalEntries ? base + j : p.noTotalEntries - 1;
-              key[j] = s.allocKey[t];
-              ptrOf[j] = s.table[t].ptr;
-            }
+          for (int j = 0; j < kTileItems; ++j)
+            if (base + j >= p.noTotalEntries) key[j] = 0u;
 #pragma unroll
-            for (int j = 0; j < kTileItems; ++j)
-              if (base + j >= p.noTotalEntries) key[j] = 0u;
-#pragma unroll
-            for (int j = 0; j < kTileItems; ++j) {
-              const int t = base + j;
-              const uint32_t k = key[j];
-              if (!k) continue;
-              const bool isExc = ptrOf[j] >= -1;
-              s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
-              const int vbaIdx = oldV - rank12;
-              int exlIdx = 0;
-              if (isExc) { exlIdx = oldE - rank2; rank2++; }
-              // out of voxel blocks: nothing is written past the list end; out of excess entries: a hole
-              if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k, vbaIdx, isExc ? exlIdx : -1);
-              rank12++;
-            }
+          for (int j = 0; j < kTileItems; ++j) {
+            const int t = base + j;
+            const uint32_t k = key[j];
+            if (!k) continue;
+            const bool isExc = ptrOf[j] >= -1;
+            s.allocKey[t] = 0u;  // replaces memset(entriesAllocType, 0) of the next frame
+            const int vbaIdx = oldV - rank12;
+            int exlIdx = 0;
+            if (isExc) { exlIdx = oldE - rank2; rank2++; }
+            // out of voxel blocks: nothing is written past the list end; out of excess entries: a hole
+            if (vbaIdx >= 0) workList[rank12] = make_int4(exlIdx >= 0 ? t : -1, (int)k, vbaIdx, isExc ? exlIdx : -1);
+            rank12++;
           }
         }
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) grp4[q * 4 + r] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame
+    }
+  }
+  // ---- D0: the groups of 8 entries the mark touched (a byte each in visGrp, 147 KB, nine 16-byte loads per lane as in the
+  // bit sweep): the types that carry kTouchedNow become bits of visBits — the group's 8 bits are ONE byte of that plane, nobody
+  // else writes it before the barrier, so a plain byte store does — and go back to the plain type 1
+  {
+    const int wave = tid >> 6;
+    uint4 *rows = reinterpret_cast<uint4 *>(s.visGrp) + wave * (kSmallRows * 64) + lane;
+    uint4 g[kSmallRows];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) g[j] = rows[j * 64];
+#pragma unroll
+    for (int j = 0; j < kSmallRows; ++j) {
+      if ((g[j].x | g[j].y | g[j].z | g[j].w) == 0u) continue;
+      const int firstGroup = (wave * (kSmallRows * 64) + j * 64 + lane) * 16;
+#pragma unroll 1
+      for (int b = 0; b < 16; ++b) {  // (the few lanes that get here read their bytes again one by one: small code)
+        const int grp = firstGroup + b;
+        if (s.visGrp[grp] == 0) continue;
+        uint2 *types = reinterpret_cast<uint2 *>(visType + (size_t)grp * 8);
+        uint2 t8 = *types;
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          uint32_t &w = k < 4 ? t8.x : t8.y;
+          const int sh8 = (k & 3) * 8;
+          if (((w >> sh8) & 0xffu) == (uint32_t)kTouchedNow) { bits |= 1u << k; w = (w & ~(0xffu << sh8)) | (1u << sh8); }
+        }
+        *types = t8;
+        reinterpret_cast<uint8_t *>(s.visBits)[grp] = (uint8_t)bits;
+      }
+      rows[j * 64] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame's mark
     }
   }
   __syncthreads();

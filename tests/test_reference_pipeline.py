@@ -30,8 +30,8 @@ N_FRAMES = 8
 W, H = 1242, 375
 
 
-def run_host(exe, root, out_bin, decay=0, evaluate=0):
-    env = dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1)))
+def run_host(exe, root, out_bin, decay=0, evaluate=0, extra_env=None):
+    env = dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1)), **(extra_env or {}))
     r = subprocess.run([exe, root, str(N_FRAMES), out_bin, "0.05", str(decay), str(evaluate)], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     line = r.stdout.strip().splitlines()[-1]
@@ -238,3 +238,12 @@ def test_reference_pipeline_on_the_hip_engine_matches_the_oracle(tmp_path):
         want, _ = run_host(orc, root, str(tmp_path / f"orc{decay}.bin"), decay, evaluate=decay)
         assert got == want, {k: (got.get(k), want[k]) for k in want if got.get(k) != want[k]}
         assert open(tmp_path / f"hip{decay}.bin", "rb").read() == open(tmp_path / f"orc{decay}.bin", "rb").read()
+    # The SAME unmodified host with its volumes placed per GPU by the shim's policy (INTEGRATION.md "multi-GPU without a source
+    # change": DSR_DEVICES lists the GPUs, every track's InfiniTamDriver lands on the next one; here both entries name the one GPU
+    # of the box, instance volumes on all of them) and with the cross-GPU forms forced: every digest of the default run.
+    want, _ = run_host(orc, root, str(tmp_path / "orc_p.bin"))
+    for k, extra in enumerate((dict(DSR_DEVICES="0,0"), dict(DSR_DEVICES="0,0,0", DSR_INSTANCES_ON_ALL_DEVICES="1", DSR_FORCE_PEER_PATH="1"),
+                               dict(DSR_DEVICES="0,0", DSR_PIPELINED_VIEW="2"))):
+        got, _ = run_host(hip, root, str(tmp_path / f"hip_p{k}.bin"), extra_env=extra)
+        assert got == want, (extra, {k2: (got.get(k2), want[k2]) for k2 in want if got.get(k2) != want[k2]})
+        assert open(tmp_path / f"hip_p{k}.bin", "rb").read() == open(tmp_path / "orc_p.bin", "rb").read(), extra
