@@ -566,13 +566,14 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     pose_m = [np.linalg.inv(np.asarray(f[2], np.float64)).astype(np.float32) for f in frames]
     inst_m = [{k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in f[3]} for f in frames]
 
-    def run(scene, nranks):
+    def run(scene, nranks, preview=True):
         def step(i):
             if on_gpu:
                 scene.step(rgb_in[i].data_ptr(), dep_in[i].data_ptr(), frames[i][2], masks_in[i])
             else:
                 scene.step(frames[i][0], frames[i][1], frames[i][2], masks_in[i])
-            scene.preview(pose_m[i], inst_m[i], track_ids)
+            if preview:
+                scene.preview(pose_m[i], inst_m[i], track_ids)
 
         def barrier():
             scene.sync()
@@ -608,18 +609,46 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
             probe.sync()
             probe.profile_reset()
         scene.after_warmup = _reset
+    native = bool(getattr(scene, "native", False))
+    if native:  # HIP events around the collective and the composite on the exchange's stream (dsr_exchange_timing)
+        prev_after = getattr(scene, "after_warmup", None)
+
+        def _after():
+            if prev_after:
+                prev_after()
+            scene.exchange.x.timing(True)
+        scene.after_warmup = _after
     elapsed, t_enq = run(scene, world)
+    xt = scene.exchange.x.timing(False) if native else None
     if profiled:
         prof = probe.profile_get()
         probe.profile_enable(False)
+    # where a step goes (for the day the N > 1 curve is measured): this rank's fusion chain alone (the same K steps without the
+    # preview: no render, no collective, no composite), and — N > 1 — the same workload with the OTHER collective (gather to the
+    # consumer's GPU instead of the in-place all-gather)
+    scene.after_warmup = None
+    chain_s, _ = run(scene, world, preview=False)
+    alt = None
+    if native and world > 1 and use_dist:
+        scene.exchange.x.set_collective(1, 0)
+        scene.after_warmup = lambda: scene.exchange.x.timing(True)
+        alt_s, _ = run(scene, world)
+        alt_t = scene.exchange.x.timing(False)
+        scene.exchange.x.set_collective(0, 0)
+        alt = (alt_s, alt_t)
     stats = scene.static.get_stats() if scene.owns_static else None
     inst_stats = [e.get_stats() for e in scene.instances.values()]
     hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
     scene.close()
+    gather_us = 1e3 * xt["gather_ms"] / xt["n_gathers"] if xt and xt["n_gathers"] else 0.0
+    composite_us = 1e3 * xt["composite_ms"] / xt["n_composites"] if xt and xt["n_composites"] else 0.0
+    alt_elapsed = alt[0] if alt else 0.0
+    alt_gather_us = 1e3 * alt[1]["gather_ms"] / alt[1]["n_gathers"] if alt and alt[1]["n_gathers"] else 0.0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([elapsed, chain_s, gather_us, composite_us, alt_elapsed, alt_gather_us], dtype=torch.float64,
+                         device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, chain_s, gather_us, composite_us, alt_elapsed, alt_gather_us = [float(v) for v in t.tolist()]
 
     sliced = None
     if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
@@ -666,6 +695,13 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
                    "volumes": V, "volumes_per_rank": per_rank, "has_static_map": bool(has_static),
                    "composited_frames_per_s": round(K / elapsed, 3),
                    "host_enqueue_ms_per_step_rank0": round(1e3 * t_enq / K, 4),
+                   # max over ranks: a rank's fusion chain alone (no preview), the collective and the composite on the exchange's
+                   # stream (HIP events), and how many GPUs the library's RCCL communicator spans (0: no collective ran)
+                   "chain_us_max_rank": round(1e6 * chain_s / K, 1), "gather_us": round(gather_us, 1),
+                   "composite_us": round(composite_us, 1), "rccl_ranks": world if (native and use_dist) else 0,
+                   "collective": "all-gather (in place)",
+                   "gather_to_root": ({"value": round(V * K / alt_elapsed, 3), "ms_per_step": round(1e3 * alt_elapsed / K, 4),
+                                       "gather_us": round(alt_gather_us, 1)} if alt_elapsed > 0 else None),
                    "preview_hit_fraction": round(hit, 4),
                    "static_visible_blocks_last_frame": stats.no_visible_blocks if stats else None,
                    "instance_visible_blocks_last_frame_rank0": [s_.no_visible_blocks for s_ in inst_stats],

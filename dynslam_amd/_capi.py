@@ -150,6 +150,8 @@ SIGNATURES = {
     "exchange_layer_ptrs": (C.c_int, [_X, C.c_int, C.c_int, C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     "exchange_render_slot": (C.c_int, [_X, C.c_int, C.c_int, _H, C.c_int, _P, _P]),
     "exchange_gather": (C.c_int, [_X]),
+    "exchange_set_collective": (C.c_int, [_X, C.c_int, C.c_int]),
+    "exchange_timing": (C.c_int, [_X, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "exchange_composite": (C.c_int, [_X, C.c_int, _H, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int]),
     "exchange_gather_and_composite": (C.c_int, [_X, C.c_int, _H, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_int]),
     "exchange_target_ptrs": (C.c_int, [_X, C.c_int, C.POINTER(_P), C.POINTER(_P)]),

@@ -20,6 +20,8 @@ struct RcclApi {
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -46,6 +48,7 @@ RcclApi *rccl_api() {
     RCCL_SYM(GetUniqueId, "ncclGetUniqueId") RCCL_SYM(CommInitRank, "ncclCommInitRank") RCCL_SYM(CommInitAll, "ncclCommInitAll")
     RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(AllGather, "ncclAllGather") RCCL_SYM(GroupStart, "ncclGroupStart")
     RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+    RCCL_SYM(Send, "ncclSend") RCCL_SYM(Recv, "ncclRecv")
 #undef RCCL_SYM
   });
   return &api;
@@ -88,6 +91,16 @@ struct dsr_exchange {
   std::vector<Dev> devs;                    // local GPUs
   std::vector<int> devOfRank;               // index into devs, -1: a rank of another process
   bool useRccl = false;
+  // which collective dsr_exchange_gather runs (dsr_exchange_set_collective): every GPU gets every layer (in-place all-gather),
+  // or only the GPU of rootGroup does (the composite has one consumer: 1/N of the bytes on every link but the root's)
+  bool gatherToRoot = false;
+  int rootGroup = 0;
+  // measurement (dsr_exchange_timing): HIP events around the collective and around the composite, resolved when asked for
+  bool timing = false;
+  struct Timed { hipEvent_t a, b; int kind; int dev; };
+  std::vector<Timed> pending;
+  double gatherMs = 0.0, compositeMs = 0.0;
+  int gatherN = 0, compositeN = 0;
 };
 
 namespace {
@@ -101,6 +114,7 @@ dsr_exchange::Dev *local_dev(dsr_exchange *x, int rank) {
 }
 void exchange_free(dsr_exchange *x) {
   if (!x) return;
+  for (auto &t : x->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   RcclApi *api = x->useRccl ? rccl_api() : nullptr;
   for (auto &d : x->devs) {
     (void)hipSetDevice(d.device);
@@ -348,23 +362,75 @@ int dsr_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e,
   return dsr_stream_wait_for_engine(e, d->stream);
 }
 
+static void timed_begin(dsr_exchange *x, dsr_exchange::Dev &d, int kind, size_t devIndex) {
+  if (!x->timing) return;
+  dsr_exchange::Timed t{nullptr, nullptr, kind, (int)devIndex};
+  if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return;
+  (void)hipEventRecord(t.a, d.stream);
+  x->pending.push_back(t);
+}
+static void timed_end(dsr_exchange *x, dsr_exchange::Dev &d, int kind, size_t devIndex) {
+  if (!x->timing) return;
+  for (auto it = x->pending.rbegin(); it != x->pending.rend(); ++it)
+    if (it->kind == kind && it->dev == (int)devIndex) { (void)hipEventRecord(it->b, d.stream); return; }
+}
+
+int dsr_exchange_set_collective(dsr_exchange *x, int gather_to_root, int root_rank) {
+  if (!x || root_rank < 0 || root_rank >= x->nRanks) return fail(DSR_E_ARG, "bad exchange arguments");
+  x->gatherToRoot = gather_to_root != 0;
+  x->rootGroup = x->groupOfRank[root_rank];
+  return DSR_OK;
+}
+
 int dsr_exchange_gather(dsr_exchange *x) {
   if (!x) return fail(DSR_E_ARG, "null exchange");
   if (!x->useRccl) return DSR_OK;  // one GPU: every layer is where the composite reads it
   RcclApi *api = rccl_api();
   int prev = 0;
   (void)hipGetDevice(&prev);
+  for (size_t k = 0; k < x->devs.size(); ++k) { (void)hipSetDevice(x->devs[k].device); timed_begin(x, x->devs[k], 0, k); }
   RCCL_TRY(api, api->GroupStart());
   ncclResult_t r = ncclSuccess;
   for (auto &d : x->devs) {
     if (hipSetDevice(d.device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
-    r = api->AllGather(d.all + (size_t)d.group * x->chunkBytes, d.all, x->chunkBytes, ncclUint8, d.comm, d.stream);  // in place
+    if (!x->gatherToRoot) {
+      r = api->AllGather(d.all + (size_t)d.group * x->chunkBytes, d.all, x->chunkBytes, ncclUint8, d.comm, d.stream);  // in place
+    } else if (d.group == x->rootGroup) {  // (communicator rank == group, both for ncclCommInitAll and for rank mode)
+      for (int g = 0; g < x->groups && r == ncclSuccess; ++g)
+        if (g != d.group) r = api->Recv(d.all + (size_t)g * x->chunkBytes, x->chunkBytes, ncclUint8, g, d.comm, d.stream);
+    } else {
+      r = api->Send(d.all + (size_t)d.group * x->chunkBytes, x->chunkBytes, ncclUint8, x->rootGroup, d.comm, d.stream);
+    }
     if (r != ncclSuccess) break;
   }
   const ncclResult_t r2 = api->GroupEnd();
+  for (size_t k = 0; k < x->devs.size(); ++k) { (void)hipSetDevice(x->devs[k].device); timed_end(x, x->devs[k], 0, k); }
   (void)hipSetDevice(prev);
-  if (r != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclAllGather: ") + api->GetErrorString(r));
+  if (r != ncclSuccess) return fail(DSR_E_DEVICE, std::string("exchange collective: ") + api->GetErrorString(r));
   if (r2 != ncclSuccess) return fail(DSR_E_DEVICE, std::string("ncclGroupEnd: ") + api->GetErrorString(r2));
+  return DSR_OK;
+}
+
+int dsr_exchange_timing(dsr_exchange *x, int enable, double *gather_ms, double *composite_ms, int32_t *n_gathers, int32_t *n_composites) {
+  if (!x) return fail(DSR_E_ARG, "null exchange");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (auto &t : x->pending) {  // resolve what has been recorded so far
+    float ms = 0.0f;
+    (void)hipSetDevice(x->devs[t.dev].device);
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+      if (t.kind == 0) { x->gatherMs += ms; x->gatherN++; } else { x->compositeMs += ms; x->compositeN++; }
+    }
+    (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+  }
+  x->pending.clear();
+  (void)hipSetDevice(prev);
+  if (gather_ms) *gather_ms = x->gatherMs;
+  if (composite_ms) *composite_ms = x->compositeMs;
+  if (n_gathers) *n_gathers = x->gatherN;
+  if (n_composites) *n_composites = x->compositeN;
+  x->gatherMs = x->compositeMs = 0.0; x->gatherN = x->compositeN = 0;
+  x->timing = enable != 0;
   return DSR_OK;
 }
 
@@ -410,10 +476,15 @@ int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_en
     if ((st = dsr_exchange_layer_ptrs(x, root_rank, ranks[l], slots[l], &r, &dd))) return st;
     rp[l] = r; dp[l] = dd;
   }
-  if (n_layers > 0 &&
-      (st = dsr_composite_layer_ptrs_dev(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
-                                         track_ids, n_layers, x->P, tint_strength, dim_background)))
-    return st;
+  const size_t devIndex = (size_t)(d - x->devs.data());
+  if (n_layers > 0) {
+    HIP_TRY(hipSetDevice(d->device));
+    timed_begin(x, *d, 1, devIndex);
+    if ((st = dsr_composite_layer_ptrs_dev(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
+                                           track_ids, n_layers, x->P, tint_strength, dim_background)))
+      return st;
+    timed_end(x, *d, 1, devIndex);
+  }
   if (target_engine) return dsr_wait_for_stream(target_engine, d->stream);  // its next render of the target waits for the composite
   return DSR_OK;
 }

@@ -168,6 +168,16 @@ class Exchange:
     def gather(self):
         self._check(self.api.exchange_gather(self._h))
 
+    def set_collective(self, gather_to_root, root_rank=0):
+        """0: in-place all-gather; 1: gather to `root_rank`'s GPU only (dsr_exchange_set_collective)."""
+        self._check(self.api.exchange_set_collective(self._h, int(bool(gather_to_root)), int(root_rank)))
+
+    def timing(self, enable=True):
+        """-> {gather_ms, composite_ms, n_gathers, n_composites} since the last call; `enable` switches the event timing on / off."""
+        g, c, ng, nc = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+        self._check(self.api.exchange_timing(self._h, int(bool(enable)), C.byref(g), C.byref(c), C.byref(ng), C.byref(nc)))
+        return {"gather_ms": g.value, "composite_ms": c.value, "n_gathers": ng.value, "n_composites": nc.value}
+
     def clear_target(self, rank):
         self._check(self.api.exchange_clear_target(self._h, int(rank)))
 

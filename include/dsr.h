@@ -442,6 +442,13 @@ int dsr_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e,
                              const float intrinsics[4]);
 /* The all-gather of every rank's layers (one collective; nothing for a single device).  Collective in rank mode. */
 int dsr_exchange_gather(dsr_exchange *x);
+/* (ABI 4) Which collective dsr_exchange_gather runs between the GPUs: 0 = the in-place all-gather (every GPU ends up with every
+ * layer), 1 = a gather to the GPU of `root_rank` only (ncclSend / ncclRecv in one group: the composite has ONE consumer, so every
+ * link but the root's carries 1/N of the bytes).  The composite must then run on that rank.  No effect on a one-GPU exchange. */
+int dsr_exchange_set_collective(dsr_exchange *x, int gather_to_root, int root_rank);
+/* (ABI 4) Measurement: returns (and resets) the HIP-event time the collectives and the composites of this process took on their
+ * exchange streams since the last call, and switches the timing on / off for what follows (`enable`).  Waits for that work. */
+int dsr_exchange_timing(dsr_exchange *x, int enable, double *gather_ms, double *composite_ms, int32_t *n_gathers, int32_t *n_composites);
 /* CompositeInstances on the GPU of local rank `root_rank`: layers (ranks[i], slots[i]) with track_ids[i], in the
  * given order (the host's ascending track ids), over the target — arithmetic of dsr_composite_layer_ptrs_dev.
  * target_*_dev == NULL: the exchange's own target pair on that GPU (dsr_exchange_target_ptrs: render the static map

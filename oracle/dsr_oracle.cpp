@@ -1843,6 +1843,15 @@ int orc_exchange_render_slot(dsr_exchange *x, int rank, int slot, dsr_engine *e,
   return orc_get_image_dev(e, type, pose_m, intrinsics, rgba, depth);
 }
 int orc_exchange_gather(dsr_exchange *x) { return x ? DSR_OK : fail(DSR_E_ARG, "null exchange"); }
+int orc_exchange_set_collective(dsr_exchange *x, int, int) { return x ? DSR_OK : fail(DSR_E_ARG, "null exchange"); }  // one address space: nothing to move
+int orc_exchange_timing(dsr_exchange *x, int, double *gather_ms, double *composite_ms, int32_t *n_gathers, int32_t *n_composites) {
+  if (!x) return fail(DSR_E_ARG, "null exchange");
+  if (gather_ms) *gather_ms = 0.0;
+  if (composite_ms) *composite_ms = 0.0;
+  if (n_gathers) *n_gathers = 0;
+  if (n_composites) *n_composites = 0;
+  return DSR_OK;
+}
 int orc_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba, void **depth) {
   if (!x || rank < 0 || rank >= x->nRanks) return fail(DSR_E_ARG, "bad exchange rank");
   if (rgba) *rgba = x->targetRgba.data();
