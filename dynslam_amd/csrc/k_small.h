@@ -159,12 +159,17 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p,
 #pragma unroll
       for (int r = 0; r < 4; ++r) any |= g4[r].x | g4[r].y | g4[r].z | g4[r].w;
       if (any == 0u) continue;
-      // the rare part re-reads its words one by one (from L1): small code instead of sixteen unrolled copies of it
+      // which of the 16 words hold marks (from the registers), then only those are read again, one by one: the loop runs as
+      // often as the busiest lane of the wave has words, and the code stays small (no sixteen unrolled copies of the body)
+      uint32_t nz = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        nz |= ((g4[r].x ? 1u : 0u) | (g4[r].y ? 2u : 0u) | (g4[r].z ? 4u : 0u) | (g4[r].w ? 8u : 0u)) << (r * 4);
       const uint32_t *words = s.allocGrp + (tileBase >> 5) + q * 16;
-#pragma unroll 1
-      for (int wq = 0; wq < 16; ++wq) {
+      while (nz) {
+        const int wq = __ffs((int)nz) - 1;
+        nz &= nz - 1u;
         const uint32_t word = words[wq];
-        if (word == 0u) continue;
 #pragma unroll 1
         for (int gi = 0; gi < 4; ++gi) {
           if (((word >> (gi * 8)) & 15u) == 0u) continue;
@@ -213,10 +218,14 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p,
     for (int j = 0; j < kSmallRows; ++j) {
       if ((g[j].x | g[j].y | g[j].z | g[j].w) == 0u) continue;
       const int firstGroup = (wave * (kSmallRows * 64) + j * 64 + lane) * 16;
-#pragma unroll 1
-      for (int b = 0; b < 16; ++b) {  // (the few lanes that get here read their bytes again one by one: small code)
-        const int grp = firstGroup + b;
-        if (s.visGrp[grp] == 0) continue;
+      // which of the 16 groups are marked (from the registers); the loop runs as often as the busiest lane of the wave has groups
+      const uint32_t gw[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
+      uint32_t nz = 0u;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) nz |= ((gw[b >> 2] >> ((b & 3) * 8)) & 0xffu) ? (1u << b) : 0u;
+      while (nz) {
+        const int grp = firstGroup + __ffs((int)nz) - 1;
+        nz &= nz - 1u;
         uint2 *types = reinterpret_cast<uint2 *>(visType + (size_t)grp * 8);
         uint2 t8 = *types;
         uint32_t bits = 0u;

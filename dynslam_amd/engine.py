@@ -88,6 +88,25 @@ def _colmajor(m):
     return a
 
 
+class PoseArg:
+    """A 4x4 pose converted ONCE to the float[16] column-major buffer the C ABI takes.  Every entry point that takes a pose accepts
+    one in place of the matrix: a host that calls per frame and per volume (bench.py's loop, ShardedScene) then pays a pointer
+    hand-over instead of a numpy transpose + a ctypes view per call (~10 us each in CPython, 16 of them per step of 8 volumes)."""
+    __slots__ = ("buf", "ptr")
+
+    def __init__(self, m):
+        self.buf = (C.c_float * 16)(*_colmajor(m).tolist())
+        self.ptr = C.cast(self.buf, C.c_void_p)
+
+
+def _pose_arg(m):
+    """-> (object to keep alive during the call, c_void_p)"""
+    if isinstance(m, PoseArg):
+        return m, m.ptr
+    a = _colmajor(m)
+    return a, _ptr(a)
+
+
 def _from_colmajor(buf):
     return np.asarray(buf, dtype=np.float32).reshape(4, 4).T.copy()
 
@@ -160,10 +179,10 @@ class Exchange:
         return r.value, d.value
 
     def render_slot(self, rank, slot, engine, image_type=_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=None, intrinsics=None):
-        pm = _colmajor(pose_m) if pose_m is not None else None
+        keep, pm_ptr = _pose_arg(pose_m) if pose_m is not None else (None, None)
         intr = np.ascontiguousarray(intrinsics, dtype=np.float32) if intrinsics is not None else None
         self._check(self.api.exchange_render_slot(self._h, int(rank), int(slot), engine._h if engine is not None else None, int(image_type),
-                                                  _ptr(pm) if pm is not None else None, _ptr(intr) if intr is not None else None))
+                                                  pm_ptr, _ptr(intr) if intr is not None else None))
 
     def gather(self):
         self._check(self.api.exchange_gather(self._h))
@@ -185,9 +204,12 @@ class Exchange:
                              dim_background=True, gather=True):
         """layers: [(rank, slot, track id)] in compositing order (ascending track id)."""
         n = len(layers)
-        ranks = (C.c_int32 * max(1, n))(*[int(l[0]) for l in layers])
-        slots = (C.c_int32 * max(1, n))(*[int(l[1]) for l in layers])
-        tids = (C.c_int32 * max(1, n))(*[int(l[2]) for l in layers])
+        key = tuple(layers)
+        hit = getattr(self, "_layer_cache", None)
+        if hit is None or hit[0] != key:  # (the same layer set frame after frame: the three ctypes arrays are built once)
+            hit = self._layer_cache = (key, (C.c_int32 * max(1, n))(*[int(l[0]) for l in layers]),
+                                       (C.c_int32 * max(1, n))(*[int(l[1]) for l in layers]), (C.c_int32 * max(1, n))(*[int(l[2]) for l in layers]))
+        _, ranks, slots, tids = hit
         fn = self.api.exchange_gather_and_composite if gather else self.api.exchange_composite
         self._check(fn(self._h, int(root_rank), target_engine._h if target_engine is not None else None,
                        C.c_void_p(target_rgba_ptr) if target_rgba_ptr else None, C.c_void_p(target_depth_ptr) if target_depth_ptr else None,
@@ -329,8 +351,8 @@ class EngineCore:
 
     # -- pose ---------------------------------------------------------------
     def set_pose_inv_m(self, inv_m):
-        a = _colmajor(inv_m)
-        self._check(self.api.set_pose_inv_m(self._h, _ptr(a)))
+        keep, ptr = _pose_arg(inv_m)
+        self._check(self.api.set_pose_inv_m(self._h, ptr))
 
     def set_pose_m(self, m):
         a = _colmajor(m)
@@ -374,10 +396,10 @@ class EngineCore:
         return rgba, depth
 
     def get_image_dev(self, image_type, pose_m, intrinsics, rgba_dev_ptr, depth_dev_ptr):
-        pm = _colmajor(pose_m) if pose_m is not None else None
+        keep, pm_ptr = _pose_arg(pose_m) if pose_m is not None else (None, None)
         intr = np.ascontiguousarray(intrinsics, dtype=np.float32) if intrinsics is not None else None
         self._check(self.api.get_image_dev(
-            self._h, int(image_type), _ptr(pm) if pm is not None else None,
+            self._h, int(image_type), pm_ptr,
             _ptr(intr) if intr is not None else None,
             C.c_void_p(rgba_dev_ptr) if rgba_dev_ptr else None,
             C.c_void_p(depth_dev_ptr) if depth_dev_ptr else None))

@@ -209,8 +209,12 @@ class NativeLayers:
         return self.x.stream(self.rank)
 
     def ordered_layers(self, track_id_of_instance):
-        items = sorted((track_id_of_instance[k], rs) for k, rs in self.slot_of_instance.items() if k in track_id_of_instance)
-        return [(r, s, t) for t, (r, s) in items]
+        key = tuple(track_id_of_instance.items())
+        hit = getattr(self, "_ordered", None)
+        if hit is None or hit[0] != key:
+            items = sorted((track_id_of_instance[k], rs) for k, rs in self.slot_of_instance.items() if k in track_id_of_instance)
+            hit = self._ordered = (key, [(r, s, t) for t, (r, s) in items])
+        return hit[1]
 
     @property
     def all_depth(self):
