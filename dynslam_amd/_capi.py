@@ -78,7 +78,18 @@ class KernelTime(C.Structure):
                 ("store_lanes", C.c_double), ("colour_voxels", C.c_double)]
 
 
-assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8
+class BatchItem(C.Structure):  # dsr_batch_item
+    _fields_ = [("volume", C.c_int32), ("x0", C.c_int32), ("y0", C.c_int32), ("box_w", C.c_int32), ("box_h", C.c_int32),
+                ("dx0", C.c_int32), ("dy0", C.c_int32), ("dbox_w", C.c_int32), ("dbox_h", C.c_int32), ("reserved", C.c_int32),
+                ("copy_mask_dev", C.c_void_p), ("delete_mask_dev", C.c_void_p), ("inv_m", C.c_float * 16)]
+
+
+class BatchRenderItem(C.Structure):  # dsr_batch_render_item
+    _fields_ = [("volume", C.c_int32), ("reserved", C.c_int32), ("rgba_out_dev", C.c_void_p), ("depth_out_dev", C.c_void_p),
+                ("pose_m", C.c_float * 16)]
+
+
+assert C.sizeof(HashEntry) == 16 and C.sizeof(Voxel) == 8 and C.sizeof(BatchItem) == 120 and C.sizeof(BatchRenderItem) == 88
 
 _P = C.c_void_p
 _H = C.c_void_p  # dsr_engine*
@@ -99,6 +110,10 @@ SIGNATURES = {
     "stream_wait_for_engine": (C.c_int, [_H, _P]),
     "engine_share_stream": (C.c_int, [_H, _H]),
     "pin_host_thread": (C.c_int, [C.c_int]),
+    "batch_create": (C.c_int, [_H, C.POINTER(_H), C.c_int, C.POINTER(C.c_void_p)]),
+    "batch_destroy": (None, [C.c_void_p]),
+    "batch_fuse": (C.c_int, [C.c_void_p, C.POINTER(BatchItem), C.c_int, C.POINTER(C.c_int32)]),
+    "batch_render": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(BatchRenderItem), C.c_int]),
     "update_view": (C.c_int, [_H, _P, _P]),
     "update_view_dev": (C.c_int, [_H, _P, _P]),
     "update_view_bgr": (C.c_int, [_H, _P, _P]),

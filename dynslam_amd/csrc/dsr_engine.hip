@@ -19,6 +19,7 @@
 #include "k_swap.h"
 #include "k_mesh.h"
 #include "k_small.h"
+#include "k_batch.h"
 
 namespace {
 
@@ -1770,6 +1771,252 @@ int dsr_view_remove_silhouette(dsr_engine *e, const uint8_t *mask, int x0, int y
 int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, int y0, int box_w, int box_h) {
   if (!mask_dev) return fail(DSR_E_ARG, "bad silhouette arguments");
   return remove_silhouette(e, nullptr, (const uint8_t *)mask_dev, x0, y0, box_w, box_h);
+}
+
+// ---- the instance volumes of one GPU as a batch (include/dsr.h "volume batch", k_batch.h) ----------------------------------
+
+struct dsr_batch {
+  dsr_engine *source = nullptr;
+  std::vector<dsr_engine *> vols;
+  std::vector<BatchVolP> volsHost;
+  BatchVolP *volsDev = nullptr;
+  BatchFrameP *framesDev = nullptr;
+};
+
+static BatchVolP batch_vol_record(dsr_engine *e) {
+  BatchVolP v;
+  memset(&v, 0, sizeof v);
+  v.s = e->scene; v.depth = e->depth; v.rgb = e->rgb; v.visType = e->live.visType; v.workList = e->allocWork;
+  v.visibleIDs = e->live.visibleIDs; v.visBlocks = e->live.visBlocks; v.minmax = reinterpret_cast<int2 *>(e->live.minmax);
+  v.raycastResult = e->live.raycastResult; v.raycastImage = e->live.raycastImage; v.pointsMap = e->pointsMap; v.normalsMap = e->normalsMap;
+  v.integrateStats = e->integrateStats;
+  v.fvVisibleIDs = e->freeview.visibleIDs; v.fvVisBlocks = e->freeview.visBlocks; v.fvMinmax = reinterpret_cast<int2 *>(e->freeview.minmax);
+  v.fvRaycastResult = e->freeview.raycastResult; v.fvRaycastImage = e->freeview.raycastImage; v.allocList = e->allocList;
+  v.statusDev = e->statusDev;
+  v.numTiles = e->numTilesE; v.noBlocks = e->noBlocks; v.gridIntegrate = e->gridIntegrate;
+  return v;
+}
+// the voxel GC swaps a volume's list buffers (dsr_decay): bring the device records up to date before they are used
+static int batch_refresh(dsr_batch *b) {
+  for (size_t k = 0; k < b->vols.size(); ++k) {
+    const BatchVolP v = batch_vol_record(b->vols[k]);
+    if (memcmp(&v, &b->volsHost[k], sizeof v) == 0) continue;
+    b->volsHost[k] = v;
+    HIP_TRY(hipMemcpyAsync(b->volsDev + k, &b->volsHost[k], sizeof v, hipMemcpyHostToDevice, b->source->stream));
+    HIP_TRY(hipStreamSynchronize(b->source->stream));  // (rare; the source of the copy is pageable)
+  }
+  return DSR_OK;
+}
+// this call's per-volume records -> the device table, as kernel arguments of k_batch_set
+static int batch_set_frames(dsr_batch *b, const std::vector<BatchFrameP> &f) {
+  dsr_engine *e = b->source;
+  for (int first = 0; first < (int)f.size(); first += kBatchSetChunk) {
+    BatchSet in;
+    memset(&in, 0, sizeof in);
+    const int count = std::min(kBatchSetChunk, (int)f.size() - first);
+    for (int k = 0; k < count; ++k) in.f[k] = f[first + k];
+    LAUNCH(e, "batch_set", k_batch_set, dim3(1), dim3(256), in, b->framesDev, first, count);
+  }
+  return DSR_OK;
+}
+
+int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volumes, dsr_batch **out) {
+  CHECK_E(source);
+  if (!volumes || n_volumes <= 0 || n_volumes > kBatchMax || !out) return fail(DSR_E_ARG, "a batch holds 1..8 volumes");
+  if (source->pipelinedView) return fail(DSR_E_ARG, "not with pipelined views");
+  for (int k = 0; k < n_volumes; ++k) {
+    dsr_engine *e = volumes[k];
+    if (!e || e == source) return fail(DSR_E_ARG, "bad volume");
+    for (int j = 0; j < k; ++j) if (volumes[j] == e) return fail(DSR_E_ARG, "a volume is listed twice");
+    if (!e->smallPath) return fail(DSR_E_ARG, "a batch takes instance-sized volumes (k_small.h path) only");
+    if (e->device != source->device || e->pipelinedView) return fail(DSR_E_ARG, "the volumes of a batch live on the source engine's GPU, without pipelined views");
+    if (e->W != source->W || e->H != source->H || e->Wr != source->Wr || e->Hr != source->Hr || e->W != e->Wr || e->H != e->Hr)
+      return fail(DSR_E_ARG, "main and instance engines must share the image size");
+    if (e->s.stop_integrating_at_max_w != volumes[0]->s.stop_integrating_at_max_w || e->shortDivMuExact != volumes[0]->shortDivMuExact)
+      return fail(DSR_E_ARG, "the volumes of a batch must share their fusion parameters");
+  }
+  dsr_batch *b = new (std::nothrow) dsr_batch();
+  if (!b) return fail(DSR_E_NOMEM, "oom");
+  b->source = source;
+  for (int k = 0; k < n_volumes; ++k) {
+    dsr_engine *e = volumes[k];
+    if (e->stream != source->stream) {  // one queue for the whole batch
+      int st = dsr_engine_share_stream(e, source);
+      if (st) { delete b; return st; }
+    }
+    b->vols.push_back(e);
+    b->volsHost.push_back(batch_vol_record(e));
+  }
+  if (hipMalloc(reinterpret_cast<void **>(&b->volsDev), sizeof(BatchVolP) * kBatchMax) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&b->framesDev), sizeof(BatchFrameP) * kBatchMax) != hipSuccess ||
+      hipMemcpy(b->volsDev, b->volsHost.data(), sizeof(BatchVolP) * b->vols.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(b->framesDev, 0, sizeof(BatchFrameP) * kBatchMax) != hipSuccess) {
+    if (b->volsDev) (void)hipFree(b->volsDev);
+    if (b->framesDev) (void)hipFree(b->framesDev);
+    delete b;
+    return fail(DSR_E_NOMEM, "batch tables");
+  }
+  *out = b;
+  return DSR_OK;
+}
+
+void dsr_batch_destroy(dsr_batch *b) {
+  if (!b) return;
+  (void)hipSetDevice(b->source->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(b->volsDev);
+  (void)hipFree(b->framesDev);
+  delete b;
+}
+
+// InstanceReconstructor::ProcessFrame for the instances of this GPU (InstanceReconstructor.cpp:238-263,569-700): per item, in the
+// host's order, ProcessSilhouette + RemoveSilhouette, SetPose, Integrate, PrepareNextStep — as 2 + 6 launches for ALL of them.
+int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32_t *status_out) {
+  if (!b || !items || n_items <= 0) return fail(DSR_E_ARG, "bad batch arguments");
+  dsr_engine *src = b->source;
+  CHECK_E(src);
+  if (!src->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+  const int nv = (int)b->vols.size();
+  std::vector<int> itemOf(nv, -1);
+  bool anyBlank = false;
+  for (int i = 0; i < n_items; ++i) {
+    const dsr_batch_item &it = items[i];
+    if (it.volume >= nv || it.volume < -1) return fail(DSR_E_ARG, "bad batch volume index");
+    if (it.volume >= 0) {
+      if (itemOf[it.volume] >= 0) return fail(DSR_E_ARG, "a volume appears twice in one frame");
+      if (!it.copy_mask_dev || it.box_w <= 0 || it.box_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments");
+      itemOf[it.volume] = i;
+    }
+    if (it.delete_mask_dev) { if (it.dbox_w <= 0 || it.dbox_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments"); anyBlank = true; }
+  }
+  int st = batch_refresh(b);
+  if (st) return st;
+  hipStream_t S = src->stream;
+  // ---- the view split: every cut-out and every blanking in ceil(n / 8) passes over the frame
+  if (anyBlank && (st = begin_view_modify(src))) return st;
+  for (int v = 0; v < nv; ++v)
+    if (itemOf[v] >= 0 && (st = before_view_write(b->vols[v], S))) return st;
+  for (int first = 0; first < n_items; first += kBatchMax) {
+    BatchSplit sp;
+    memset(&sp, 0, sizeof sp);
+    const int n = std::min(kBatchMax, n_items - first);
+    for (int k = 0; k < n; ++k) {
+      const dsr_batch_item &it = items[first + k];
+      BatchSplitItem &o = sp.it[k];
+      o.rmask = (const uint8_t *)it.delete_mask_dev; o.rx0 = it.dx0; o.ry0 = it.dy0; o.rbw = it.dbox_w; o.rbh = it.dbox_h;
+      if (it.volume >= 0) {
+        dsr_engine *e = b->vols[it.volume];
+        o.mask = (const uint8_t *)it.copy_mask_dev; o.x0 = it.x0; o.y0 = it.y0; o.bw = it.box_w; o.bh = it.box_h;
+        o.dstRgb = e->rgb; o.dstDepth = e->depth;
+      }
+    }
+    LAUNCH(src, "batch_split", k_batch_split, dim3(div_up(src->W, 16), div_up(src->H, 16)), dim3(256), src->rgb, src->depth, src->W, src->H, sp, n);
+  }
+  HIP_TRY(hipGetLastError());
+  if (anyBlank && (st = view_written(src, S))) return st;
+  // ---- per volume: pose, this frame's parameters, the bookkeeping of allocate_scene / integrate_scene / dsr_prepare
+  std::vector<BatchFrameP> fr(nv);
+  int maxTilesX = 0, maxTilesY = 0, maxGrid = 0, rgbSame = -1, plain = -1;
+  for (int v = 0; v < nv; ++v) {
+    memset(&fr[v], 0, sizeof fr[v]);
+    if (itemOf[v] < 0) continue;
+    dsr_engine *e = b->vols[v];
+    const dsr_batch_item &it = items[itemOf[v]];
+    if ((st = view_written(e, S))) return st;
+    e->viewBox[0] = std::max(0, it.x0); e->viewBox[1] = std::max(0, it.y0);
+    e->viewBox[2] = std::min(e->W, it.x0 + it.box_w); e->viewBox[3] = std::min(e->H, it.y0 + it.box_h);
+    if ((st = dsr_set_pose_inv_m(e, it.inv_m))) return st;
+    float proj[4]; depth_proj(e, proj);
+    BatchFrameP &f = fr[v];
+    f.p = make_frame_params(e, e->M_d, e->invM_d, proj);
+    f.active = 1;
+    f.tileX0 = e->viewBox[0] / 16; f.tileY0 = e->viewBox[1] / 16;
+    f.tilesX = std::max(0, div_up(e->viewBox[2], 16) - f.tileX0); f.tilesY = std::max(0, div_up(e->viewBox[3], 16) - f.tileY0);
+    maxTilesX = std::max(maxTilesX, f.tilesX); maxTilesY = std::max(maxTilesY, f.tilesY); maxGrid = std::max(maxGrid, e->gridIntegrate);
+    const int rs = f.p.rgbSame ? 1 : 0, pl = (!f.p.depthWeighting && !f.p.stopAtMaxW && e->shortDivMuExact) ? 1 : 0;
+    if ((rgbSame >= 0 && rgbSame != rs) || (plain >= 0 && plain != pl)) return fail(DSR_E_ARG, "the volumes of a batch must share their fusion parameters");
+    rgbSame = rs; plain = pl;
+    if (e->statusDev) e->statusSeq++;
+    f.publishSeq = e->statusSeq;
+    e->sceneVersion += 2; e->noVisibleValid = false; e->listVersion++; e->framesProcessed++;
+    e->liveExp.valid = true; e->liveExp.onSide = false; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
+    memcpy(e->liveExp.proj, proj, sizeof proj);
+  }
+  if (rgbSame < 0) return DSR_OK;  // only blanking in this frame
+  if ((st = batch_set_frames(b, fr))) return st;
+  const dim3 img(div_up(src->W, 16), div_up(src->H, 16), nv);
+  if (maxTilesX > 0 && maxTilesY > 0)
+    LAUNCH(src, "batch_alloc_mark", k_batch_alloc_mark, dim3(maxTilesX, maxTilesY, nv), dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+  const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
+  {
+    ProfScope _ps(src, "batch_small_alloc_visible");
+    hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), S, (const BatchFrameP *)b->framesDev,
+                       (const BatchVolP *)b->volsDev);
+  }
+#define BATCH_INTEGRATE(A, B) LAUNCH(src, "batch_integrate", (k_batch_integrate<A, B>), dim3(maxGrid, nv), dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev)
+  if (rgbSame) { if (plain) BATCH_INTEGRATE(true, true); else BATCH_INTEGRATE(true, false); }
+  else { if (plain) BATCH_INTEGRATE(false, true); else BATCH_INTEGRATE(false, false); }
+#undef BATCH_INTEGRATE
+  LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+  LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+  HIP_TRY(hipGetLastError());
+  if (status_out) {
+    for (int i = 0; i < n_items; ++i) status_out[i] = DSR_OK;
+    for (int v = 0; v < nv; ++v) {
+      if (itemOf[v] < 0 || !b->vols[v]->s.sync_status) continue;
+      int status = DSR_OK;
+      if ((st = published_status(b->vols[v], &status))) return st;
+      status_out[itemOf[v]] = status;
+      if (status != DSR_OK) {  // the fork throws per failing frame: clear the sticky word after reporting it (dsr_process_frame)
+        (void)hipMemsetAsync(b->vols[v]->scene.ctr + CTR_STATUS, 0, 4, S);
+        if (b->vols[v]->statusHost) b->vols[v]->statusHost[1] = DSR_OK;
+      }
+    }
+  }
+  return DSR_OK;
+}
+
+// GetImage + GetFloatImage of every listed volume from its own free camera (CompositeInstances, InstanceReconstructor.cpp:956-986):
+// two launches for all of them, straight into the caller's HBM buffers (exchange slots)
+int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items, int n_items) {
+  if (!b || !items || n_items <= 0) return fail(DSR_E_ARG, "bad batch arguments");
+  dsr_engine *src = b->source;
+  CHECK_E(src);
+  if (type < DSR_IMAGE_FREECAMERA_SHADED || type > DSR_IMAGE_FREECAMERA_DEPTH) return fail(DSR_E_ARG, "unsupported image type");
+  const int nv = (int)b->vols.size();
+  int st = batch_refresh(b);
+  if (st) return st;
+  std::vector<BatchFrameP> fr(nv);
+  for (int v = 0; v < nv; ++v) memset(&fr[v], 0, sizeof fr[v]);
+  bool any = false;
+  for (int i = 0; i < n_items; ++i) {
+    const dsr_batch_render_item &it = items[i];
+    if (it.volume < 0 || it.volume >= nv || fr[it.volume].active) return fail(DSR_E_ARG, "bad batch volume index");
+    dsr_engine *e = b->vols[it.volume];
+    if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
+    Mat4 M, invM;
+    memcpy(M.m, it.pose_m, sizeof M.m);
+    if (!m4_inv(M, invM)) return fail(DSR_E_ARG, "singular free-camera pose");
+    float proj[4]; depth_proj(e, proj);
+    BatchFrameP &f = fr[it.volume];
+    f.p = make_frame_params(e, M, invM, proj);
+    f.active = 1; f.type = type;
+    f.outRgba = (uchar4 *)it.rgba_out_dev; f.outDepth = (float *)it.depth_out_dev;
+    e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+    any = true;
+  }
+  if (!any) return DSR_OK;
+  if ((st = batch_set_frames(b, fr))) return st;
+  const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
+  {
+    ProfScope _ps(src, "batch_small_freeview");
+    hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, (const BatchFrameP *)b->framesDev,
+                       (const BatchVolP *)b->volsDev);
+  }
+  LAUNCH(src, "batch_raycast_render", k_batch_raycast_render, dim3(div_up(src->W, 16), div_up(src->H, 16), nv), dim3(256),
+         (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
 }
 
 int dsr_dump_swap_state(dsr_engine *e, uint8_t *states, uint8_t *has_stored) {

@@ -122,11 +122,11 @@ __device__ __forceinline__ void store_planes(uint8_t *blk, int vox0, const LaneP
 // instructions per voxel on wave-uniform values — are computed ONCE per task by lanes 0..7, parked in LDS and read back by every
 // lane with one broadcast ds_read_b128 per voxel: the LDS port instead of the vector ALU this kernel is bound by (35 of ~695
 // instructions per task).  The values are the same products of the same operands: bit-identical.
-template <bool RGB_SAME, bool PLAIN, int VOX, int OCC, bool XLDS = false>
-__global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                                         const uchar4 *__restrict__ rgb,
-                                                                         const int4 *__restrict__ visBlocks,
-                                                                         uint2 *__restrict__ waveStats) {
+// (the body, as workgroup `blockId` of `numBlocks`: k_integrate below, and one volume's share of k_batch_integrate, k_batch.h)
+template <bool RGB_SAME, bool PLAIN, int VOX, bool XLDS>
+__device__ __forceinline__ void integrate_body(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
+                                               const uchar4 *__restrict__ rgb, const int4 *__restrict__ visBlocks,
+                                               uint2 *__restrict__ waveStats, const int blockId, const int numBlocks) {
   constexpr int kTasksPerBlock = 8 / VOX;            // 1 (whole block per wave) or 2 (half blocks)
   constexpr int kVoxPerTask = kBlockSize3 / kTasksPerBlock;
   // per wave: the voxels waiting for their colour update, one word each:
@@ -141,17 +141,17 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
 
   const int noVisible = s.ctr[CTR_NO_VISIBLE_LIVE];
   const int noTasks = noVisible * kTasksPerBlock;
-  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_INTEGRATED], (unsigned long long)noVisible);
+  if (blockId == 0 && threadIdx.x == 0) atomicAdd(&s.work[WORK_V_INTEGRATED], (unsigned long long)noVisible);
   const bool stopAtMaxW = PLAIN ? false : (p.stopAtMaxW != 0);
   const bool depthWeighting = PLAIN ? false : (p.depthWeighting != 0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int stride = gridDim.x * kIntegrateWaves;
+  const int stride = numBlocks * kIntegrateWaves;
   const Mat4 &Mr = RGB_SAME ? p.M : p.M_rgb;
   const float4 projr = RGB_SAME ? p.proj : p.proj_rgb;
   const int Wc = RGB_SAME ? p.W : p.Wr, Hc = RGB_SAME ? p.H : p.Hr;
   uint32_t *pend = s_pend[wave];
-  const int t0 = blockIdx.x * kIntegrateWaves + wave;  // this wave's first task; its k-th is t0 + k * stride
+  const int t0 = blockId * kIntegrateWaves + wave;  // this wave's first task; its k-th is t0 + k * stride
   // Two uniforms of the per-voxel code that the register allocator keeps SPILLING (to lanes of a VGPR: a v_readlane — a half-rate
   // VALU instruction — at every use, 8 + 3 per task; ISA of round 4): held in vector registers of their own instead (an opaque
   // copy), where reading them is free.  The kernel has registers to spare since XLDS (57 of 64).
@@ -424,10 +424,18 @@ __global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP 
   }
   if (nPend > 0) colour_pass(0, nPend);
   if (lane == 0 && (statStoreLanes | statColour)) {  // one private 8-byte slot per wave: no atomics
-    uint2 *slot = waveStats + (blockIdx.x * kIntegrateWaves + wave);
+    uint2 *slot = waveStats + (blockId * kIntegrateWaves + wave);
     const uint2 old = *slot;
     *slot = make_uint2(old.x + statStoreLanes, old.y + statColour);
   }
+}
+
+template <bool RGB_SAME, bool PLAIN, int VOX, int OCC, bool XLDS = false>
+__global__ __launch_bounds__(64 * kIntegrateWaves, OCC) void k_integrate(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                                         const uchar4 *__restrict__ rgb,
+                                                                         const int4 *__restrict__ visBlocks,
+                                                                         uint2 *__restrict__ waveStats) {
+  integrate_body<RGB_SAME, PLAIN, VOX, XLDS>(p, s, depth, rgb, visBlocks, waveStats, (int)blockIdx.x, (int)gridDim.x);
 }
 
 }  // namespace dsr

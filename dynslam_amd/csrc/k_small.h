@@ -112,11 +112,11 @@ __device__ __forceinline__ int small_sweep_bits(uint32_t *plane, int32_t *ids, i
 //   E  only after a frame whose visible entries did not fit the list: the type sweep over the whole table (K0b's rare branch)
 //   F  ordered compaction of visBits -> visibleEntryIDs, counts, published status (k_visible_count / scan / k_visible_write)
 //   G  the visible-block stream + the range image (k_visible_write's gather, k_expected_depth_one)
-__global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p, SceneP s, const float *__restrict__ depth,
-                                                                       uint8_t *visType, int numTiles, int4 *workList,
-                                                                       int32_t *visibleIDs, int4 *visBlocks, int capacity,
-                                                                       int32_t *__restrict__ publish, int publishSeq,
-                                                                       int2 *__restrict__ minmax) {
+// (the body, by one workgroup of kSmallThreads: the kernel below, or one volume's workgroup of k_batch_small_alloc_visible)
+__device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
+                                                         uint8_t *visType, int numTiles, int4 *workList, int32_t *visibleIDs,
+                                                         int4 *visBlocks, int capacity, int32_t *__restrict__ publish,
+                                                         int publishSeq, int2 *__restrict__ minmax) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -329,11 +329,18 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p,
   for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
 }
 
+__global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p, SceneP s, const float *__restrict__ depth,
+                                                                       uint8_t *visType, int numTiles, int4 *workList,
+                                                                       int32_t *visibleIDs, int4 *visBlocks, int capacity,
+                                                                       int32_t *__restrict__ publish, int publishSeq,
+                                                                       int2 *__restrict__ minmax) {
+  small_alloc_visible_body(p, s, depth, visType, numTiles, workList, visibleIDs, visBlocks, capacity, publish, publishSeq, minmax);
+}
+
 // FindVisibleBlocks + CreateExpectedDepths of a free camera for an instance-sized volume: the allocated entries come from
 // allocBits (ascending), are tested against the frustum densely, compacted in order; the range image is folded on the way.
-__global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, SceneP s, int32_t *stage, int32_t *__restrict__ visibleIDs,
-                                                                  int4 *__restrict__ visBlocks, int capacity,
-                                                                  int2 *__restrict__ minmax) {
+__device__ __forceinline__ void small_freeview_body(const FrameP &p, const SceneP &s, int32_t *stage, int32_t *__restrict__ visibleIDs,
+                                                    int4 *__restrict__ visBlocks, int capacity, int2 *__restrict__ minmax) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -384,6 +391,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, Scen
   }
   __syncthreads();
   for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
+}
+__global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, SceneP s, int32_t *stage, int32_t *__restrict__ visibleIDs,
+                                                                  int4 *__restrict__ visBlocks, int capacity,
+                                                                  int2 *__restrict__ minmax) {
+  small_freeview_body(p, s, stage, visibleIDs, visBlocks, capacity, minmax);
 }
 
 }  // namespace dsr

@@ -225,6 +225,72 @@ class Exchange:
         self._check(self.api.exchange_sync(self._h))
 
 
+class Batch:
+    """The instance volumes of one GPU driven together (`dsr_batch_*`, include/dsr.h "volume batch"): `fuse` = silhouette split,
+    SetPose, Integrate and PrepareNextStep of every listed instance in 2 + 6 launches, `render` = their preview renders in two.
+    `source`: the engine that holds the full frame; `volumes`: 1..8 instance-sized engines on its GPU."""
+
+    def __init__(self, source, volumes, api=None):
+        self.api = api or source.api
+        self.source, self.volumes = source, list(volumes)
+        arr = (C.c_void_p * len(self.volumes))(*[v._h for v in self.volumes])
+        h = C.c_void_p()
+        self._check(self.api.batch_create(source._h, arr, len(self.volumes), C.byref(h)))
+        self._h = h
+        self._items = (_capi.BatchItem * 16)()
+        self._ritems = (_capi.BatchRenderItem * 8)()
+        self._status = (C.c_int32 * 16)()
+
+    def _check(self, status):
+        if status != DSR_OK:
+            msg = self.api.last_error()
+            raise DsrError(status, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.api.batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fuse(self, items, want_status=False):
+        """items: [(volume index or -1, copy mask (device pointer, w, h) or None, x0, y0, delete mask (device pointer, w, h) or None,
+        dx0, dy0, camera->object pose (matrix or PoseArg) or None)] in the host's order.  -> per-item status list if asked for."""
+        n = len(items)
+        if n > len(self._items):
+            self._items = (_capi.BatchItem * n)()
+            self._status = (C.c_int32 * n)()
+        for it, (vol, cm, x0, y0, dm, dx0, dy0, pose) in zip(self._items, items):
+            it.volume = int(vol)
+            it.copy_mask_dev, it.box_w, it.box_h = (cm[0], int(cm[1]), int(cm[2])) if cm is not None else (None, 0, 0)
+            it.x0, it.y0 = int(x0), int(y0)
+            it.delete_mask_dev, it.dbox_w, it.dbox_h = (dm[0], int(dm[1]), int(dm[2])) if dm is not None else (None, 0, 0)
+            it.dx0, it.dy0 = int(dx0), int(dy0)
+            if pose is not None:
+                if isinstance(pose, PoseArg):
+                    C.memmove(it.inv_m, pose.buf, 64)
+                else:
+                    it.inv_m[:] = _colmajor(pose).tolist()
+        self._check(self.api.batch_fuse(self._h, self._items, n, self._status if want_status else None))
+        return list(self._status[:n]) if want_status else None
+
+    def render(self, items, image_type=_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME):
+        """items: [(volume index, object->camera pose (matrix or PoseArg), rgba device pointer or None, depth device pointer or None)]"""
+        n = len(items)
+        for it, (vol, pose, rp, dp) in zip(self._ritems, items):
+            it.volume = int(vol)
+            it.rgba_out_dev, it.depth_out_dev = rp, dp
+            if isinstance(pose, PoseArg):
+                C.memmove(it.pose_m, pose.buf, 64)
+            else:
+                it.pose_m[:] = _colmajor(pose).tolist()
+        self._check(self.api.batch_render(self._h, int(image_type), self._ritems, n))
+
+
 class EngineCore:
     """One engine handle (an ITMMainEngine: scene + render states + view + pose)."""
 

@@ -247,7 +247,7 @@ class ShardedScene:
     """
 
     def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None, local_only=False,
-                 has_static=True, share_streams=True):
+                 has_static=True, share_streams=True, use_batch=True):
         import torch
         self.torch = torch
         self.W, self.H, self.P = int(width), int(height), int(width) * int(height)
@@ -264,6 +264,14 @@ class ShardedScene:
         # no cross-stream event in the frame (dsr_engine_share_stream)
         if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1:
             next(iter(self.instances.values())).share_stream(self.source)
+        # several instance volumes on this GPU: driven as ONE batch — every kernel of an instance frame launched once for all of
+        # them (dsr_batch_*; results identical to the per-volume calls).  Up to 8 per batch; a rank with more keeps the loop.
+        self.batch, self.batch_index = None, {}
+        if self.on_gpu and use_batch and 2 <= len(self.instances) <= 8 and hasattr(self.source.api, "batch_create"):
+            from .engine import Batch
+            order = sorted(self.instances)
+            self.batch = Batch(self.source, [self.instances[k] for k in order])
+            self.batch_index = {k: i for i, k in enumerate(order)}
         # GPUs: the C ABI's exchange (RCCL called by the library) whenever RCCL can host the ranks — a process group on "nccl", or a
         # single rank; several ranks on ONE GPU (gloo, tests) and CPU tensors (the oracle, tests) go through torch.distributed
         import torch.distributed as dist
@@ -287,6 +295,9 @@ class ShardedScene:
 
     def close(self):
         self.sync()
+        if self.batch is not None:
+            self.batch.close()
+            self.batch = None
         if self.native:
             self.exchange.close()
         for e in self.engines():
@@ -312,6 +323,12 @@ class ShardedScene:
                 self.source.update_view_dev(rgba, depth_mm)
             else:
                 self.source.update_view(rgba, depth_mm)
+        if self.batch is not None and masks and all(isinstance(m[3], tuple) for m in masks):
+            # the whole instance side of the frame as one batch call: every cut-out and blanking in the host's order, then pose,
+            # fusion and tracking render of every owned instance
+            self.batch.fuse([(self.batch_index.get(k, -1), mask if k in self.batch_index else None, x0, y0, mask, x0, y0,
+                              rel if k in self.batch_index else None) for k, x0, y0, mask, rel in masks])
+            masks = ()
         for k, x0, y0, mask, rel in masks:
             ie = self.instances.get(k)
             dev_mask = isinstance(mask, tuple)
@@ -392,9 +409,24 @@ class ShardedScene:
         the library's."""
         from . import _capi
         x = self.exchange.x
-        for slot, k in enumerate(self.exchange.local_instances):
-            x.render_slot(self.rank, slot, self.instances[k] if k in instance_pose_m else None, _capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
-                          instance_pose_m.get(k))
+        if self.batch is not None:
+            if not hasattr(self, "_slot_ptrs"):
+                self._slot_ptrs = [x.slot_ptrs(self.rank, slot) for slot in range(len(self.exchange.local_instances))]
+            ritems = []
+            for slot, k in enumerate(self.exchange.local_instances):
+                if k in instance_pose_m:
+                    ritems.append((self.batch_index[k], instance_pose_m[k], self._slot_ptrs[slot][0], self._slot_ptrs[slot][1]))
+                else:
+                    x.render_slot(self.rank, slot, None)  # not visible in this frame: an empty layer
+            if ritems:
+                xs = x.stream(self.rank)
+                self.source.wait_for_stream(xs)  # the previous gather / composite is done with the slots
+                self.batch.render(ritems, _capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME)
+                self.source.stream_wait_for_engine(xs)
+        else:
+            for slot, k in enumerate(self.exchange.local_instances):
+                x.render_slot(self.rank, slot, self.instances[k] if k in instance_pose_m else None, _capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME,
+                              instance_pose_m.get(k))
         if self.owns_static:
             self.static.wait_for_stream(x.stream(self.rank))  # the previous composite is done with the target
             self.static.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, static_pose_m, None, self.target_rgba.data_ptr(),

@@ -207,6 +207,36 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
  * the renders of the pair are then ordered by one queue and the frame contains no cross-stream event.  Both engines on one
  * GPU, driven from one thread, `e` idle, neither with a pipelined view; destroy `e` before or after `owner`, either works. */
 int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner);
+
+/* ---- volume batch (ABI 4): the instance volumes of ONE GPU driven together.  An instance frame is eight small launches; N
+ * volumes one after the other — the reference's loop, InstanceReconstructor.cpp:315-361 — are N chains of them on a chip each
+ * of them leaves almost idle.  A batch takes the volume as a grid dimension: dsr_batch_fuse does, for every listed instance in
+ * the host's order, ProcessSilhouette + RemoveSilhouette (:238-263), SetPose, Integrate and PrepareNextStep (:569-700) in
+ * 2 + 6 launches for ALL of them; dsr_batch_render their GetImage + GetFloatImage (:956-986) in two.  Results are those of the
+ * per-volume calls, bit for bit.  The volumes (1..8, instance-sized: sdf_local_block_num <= 16384 behind a table no larger than
+ * upstream's) live on `source`'s GPU and from then on share its stream; `source` holds the full frame the silhouettes are cut
+ * from.  Per-volume calls on the same engines (dumps, statistics, decay, a single GetImage) remain valid in between. */
+typedef struct dsr_batch dsr_batch;
+typedef struct dsr_batch_item {
+  int32_t volume;                   /* index into the batch's volumes; -1: the instance's volume lives elsewhere — its silhouette is only blanked here */
+  int32_t x0, y0, box_w, box_h;     /* copy mask: bbox-local uint8 in HBM, placed at (x0, y0) */
+  int32_t dx0, dy0, dbox_w, dbox_h; /* delete mask */
+  int32_t reserved;
+  const void *copy_mask_dev;        /* NULL with volume -1 */
+  const void *delete_mask_dev;      /* NULL: nothing is blanked for this instance */
+  float inv_m[16];                  /* camera -> object pose of the volume for this frame (dsr_set_pose_inv_m) */
+} dsr_batch_item;
+typedef struct dsr_batch_render_item {
+  int32_t volume, reserved;
+  void *rgba_out_dev, *depth_out_dev; /* HBM buffers of the caller (an exchange slot); either may be NULL */
+  float pose_m[16];                   /* object -> camera pose of the free camera (dsr_get_image's pose_m) */
+} dsr_batch_render_item;
+int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volumes, dsr_batch **out);
+void dsr_batch_destroy(dsr_batch *b);
+/* status_out (n_items, or NULL): per item the allocation status of its volume's frame — DSR_E_OUT_OF_BLOCKS where the fork
+ * throws — for volumes created with sync_status; DSR_OK elsewhere.  The call itself fails only on bad arguments / device errors. */
+int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32_t *status_out);
+int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items, int n_items);
 /* (ABI 4) Restrict the CALLING thread to the CPUs next to `device` (< 0: the current one) — the PCI device's local_cpulist.
  * DynSLAM's host thread moves ~7.5 MB of frames / previews per frame through pinned memory and polls words the GPU writes; on
  * a multi-socket host that is cheaper from the GPU's own NUMA node.  DSR_OK and no effect where the list is not published. */

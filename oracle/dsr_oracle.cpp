@@ -1976,6 +1976,46 @@ int orc_selftest_division(int, uint64_t, uint64_t, uint64_t *mismatches) { if (m
 
 /* stream ordering / bandwidth probe: nothing to order or measure on the CPU */
 int orc_wait_for_stream(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
+// dsr_batch_*: the checker's form is the reference's own loop — one instance after the other (InstanceReconstructor.cpp:315-361)
+struct dsr_batch { dsr_engine *source; std::vector<dsr_engine *> vols; };
+int orc_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volumes, dsr_batch **out) {
+  if (!source || !volumes || n_volumes <= 0 || n_volumes > 8 || !out) return fail(DSR_E_ARG, "a batch holds 1..8 volumes");
+  dsr_batch *b = new dsr_batch();
+  b->source = source;
+  for (int k = 0; k < n_volumes; ++k) { if (!volumes[k] || volumes[k] == source) { delete b; return fail(DSR_E_ARG, "bad volume"); } b->vols.push_back(volumes[k]); }
+  *out = b;
+  return DSR_OK;
+}
+void orc_batch_destroy(dsr_batch *b) { delete b; }
+int orc_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32_t *status_out) {
+  if (!b || !items || n_items <= 0) return fail(DSR_E_ARG, "bad batch arguments");
+  for (int i = 0; i < n_items; ++i) {
+    const dsr_batch_item &it = items[i];
+    if (status_out) status_out[i] = DSR_OK;
+    if (it.volume >= (int)b->vols.size() || it.volume < -1) return fail(DSR_E_ARG, "bad batch volume index");
+    dsr_engine *e = it.volume >= 0 ? b->vols[it.volume] : nullptr;
+    int st = DSR_OK;
+    if (e && (st = orc_view_extract_silhouette(b->source, e, (const uint8_t *)it.copy_mask_dev, it.x0, it.y0, it.box_w, it.box_h))) return st;
+    if (it.delete_mask_dev && (st = orc_view_remove_silhouette(b->source, (const uint8_t *)it.delete_mask_dev, it.dx0, it.dy0, it.dbox_w, it.dbox_h))) return st;
+    if (!e) continue;
+    if ((st = orc_set_pose_inv_m(e, it.inv_m))) return st;
+    st = orc_process_frame(e);
+    if (st == DSR_E_OUT_OF_BLOCKS) { if (status_out) status_out[i] = st; }  // the fork's exception, caught by the host (:662-671)
+    else if (st) return st;
+    if ((st = orc_prepare(e))) return st;
+  }
+  return DSR_OK;
+}
+int orc_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items, int n_items) {
+  if (!b || !items || n_items <= 0) return fail(DSR_E_ARG, "bad batch arguments");
+  for (int i = 0; i < n_items; ++i) {
+    const dsr_batch_render_item &it = items[i];
+    if (it.volume < 0 || it.volume >= (int)b->vols.size()) return fail(DSR_E_ARG, "bad batch volume index");
+    int st = orc_get_image_dev(b->vols[it.volume], type, it.pose_m, nullptr, it.rgba_out_dev, it.depth_out_dev);
+    if (st) return st;
+  }
+  return DSR_OK;
+}
 int orc_pin_host_thread(int) { return DSR_OK; }  // no GPU to be near to
 int orc_engine_share_stream(dsr_engine *h, dsr_engine *owner) { return (h && owner && h != owner) ? DSR_OK : DSR_E_ARG; }  // no streams here
 int orc_stream_wait_for_engine(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
