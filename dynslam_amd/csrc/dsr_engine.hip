@@ -846,7 +846,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   int st = set_device(e);
   if (st) { delete e; return st; }
 #define ALLOC(expr) if ((st = (expr)) != DSR_OK) { free_all(e); delete e; return st; }
-  const int pvMode = getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : 0;
+  // The view pipeline (see dsr_engine::pipelinedView).  Engines a HOST waits on (sync_status: DynSLAM's call pattern, the shim) get
+  // form 2 by default since round 5 — the view double buffered, ONE view stream per GPU for all engines and one fusion stream for
+  // all instance-sized volumes: configs[2] through the C++ host 410 -> 457 frames/s (profiles/r04d_*, r05d), the whole GPU suite
+  // green under it (profiles/r05e_gpu_suite_pv2.log).  Engines driven without status waits (the bench, the sharded scene, a volume
+  // batch) keep one stream each and no view stream.  env DSR_PIPELINED_VIEW=0 / 1 / 2 overrides (1: streams per engine).
+  const int pvMode = getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : (s.sync_status ? 2 : 0);
   auto shared_stream = [&](hipStream_t *table) -> hipStream_t {
     if (e->device < 0 || e->device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_ioMutex);
@@ -927,13 +932,9 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     if (const char *sb = getenv("DSR_SLAB_BLOCKS")) e->scene.slabBlocks = std::max(1, atoi(sb));  // tests: force slab growth
     ALLOC(add_host_slab(e));  // the first slab, so that the first frames never wait for one
   }
-  // OFF by default.  Measured through the C++ host at configs[2] (5 mm map + 4 instance volumes, profiles/r04d_through_shim_queues.log):
-  // 453 frames/s with one stream per engine, 388 with the view streams at the runtime's default of 4 hardware queues (twice the
-  // streams share them: a stream's packets wait behind another stream's dependent chain in the same queue), 450 with the small
-  // streams at high priority, 488-498 with GPU_MAX_HW_QUEUES=16 (+ priority) — a gain only with a process-wide runtime setting
-  // the library cannot make.  env DSR_PIPELINED_VIEW=1 enables it; the parity suite runs both forms.
-  e->pipelinedView = false;
-  if (const char *pv = getenv("DSR_PIPELINED_VIEW")) e->pipelinedView = atoi(pv) != 0;
+  // (form 1 — a view stream and a fusion stream PER ENGINE — measured in round 4: 388 frames/s at the runtime's default of 4 hardware
+  //  queues against 453 without a view pipeline, 488-498 only with GPU_MAX_HW_QUEUES=16: twice the streams share the queues)
+  e->pipelinedView = pvMode != 0;
   if (e->pipelinedView && pvMode == 2 && (e->viewStream = shared_stream(g_sharedViewStream))) e->ownsViewStream = false;
   else if (e->pipelinedView && create_stream(&e->viewStream) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");

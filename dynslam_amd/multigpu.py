@@ -262,16 +262,23 @@ class ShardedScene:
         self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
         # one instance volume next to its view engine on a GPU of their own (north_star's layout at 8 GPUs): ONE stream for the pair,
         # no cross-stream event in the frame (dsr_engine_share_stream)
+        from .engine import DsrError
         if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1:
-            next(iter(self.instances.values())).share_stream(self.source)
+            try:
+                next(iter(self.instances.values())).share_stream(self.source)
+            except DsrError:  # engines with a view pipeline of their own (created for a host that waits on them): as they are
+                pass
         # several instance volumes on this GPU: driven as ONE batch — every kernel of an instance frame launched once for all of
         # them (dsr_batch_*; results identical to the per-volume calls).  Up to 8 per batch; a rank with more keeps the loop.
         self.batch, self.batch_index = None, {}
         if self.on_gpu and use_batch and 2 <= len(self.instances) <= 8 and hasattr(self.source.api, "batch_create"):
             from .engine import Batch
             order = sorted(self.instances)
-            self.batch = Batch(self.source, [self.instances[k] for k in order])
-            self.batch_index = {k: i for i, k in enumerate(order)}
+            try:
+                self.batch = Batch(self.source, [self.instances[k] for k in order])
+                self.batch_index = {k: i for i, k in enumerate(order)}
+            except DsrError:  # not batchable (pipelined views, other table sizes): the per-volume loop
+                self.batch = None
         # GPUs: the C ABI's exchange (RCCL called by the library) whenever RCCL can host the ranks — a process group on "nccl", or a
         # single rank; several ranks on ONE GPU (gloo, tests) and CPU tensors (the oracle, tests) go through torch.distributed
         import torch.distributed as dist

@@ -315,8 +315,9 @@ int main(int argc, char **argv) {
       lap(tl, H_UPDATE, timed);
       for (const auto &m : masks[i]) {  // the view split of InstanceReconstructor::ProcessFrame (:238-263), on the GPU
         HostDriver &id = *inst[m.k];
-        ITMLib::Engine::dsr_throw(dsr_view_extract_silhouette(drv.GetDsrEngine(), id.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh));
-        ITMLib::Engine::dsr_throw(dsr_view_remove_silhouette(drv.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh));
+        // cut-out + blanking of this instance in ONE launch (dsr_view_split_silhouette; the two-call form gives the same views)
+        ITMLib::Engine::dsr_throw(dsr_view_split_silhouette(drv.GetDsrEngine(), id.GetDsrEngine(), m.bits.data(), m.x0, m.y0, m.bw, m.bh,
+                                                            m.bits.data(), m.x0, m.y0, m.bw, m.bh));
         Matrix4f rel;
         for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) rel.at(c, r) = m.rel[r * 4 + c];
         id.AdoptDeviceView();

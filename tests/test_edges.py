@@ -219,8 +219,9 @@ def test_gpu_boundary_conversions(hip_api, oracle_lib):
                                  # cut-out + blanking as ONE call (dsr_view_split_silhouette); TEST_SHARE: the instance on the main
                                  # engine's stream (dsr_engine_share_stream)
                                  dict(DSR_SMALL_VOLUME="1"), dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1"),
-                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", TEST_SHARE="1"), dict(TEST_SPLIT="1", DSR_FORCE_PEER_PATH="1"),
-                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", DSR_PIPELINED_VIEW="1"), dict(TEST_SHARE="1")])
+                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", TEST_SHARE="1", DSR_PIPELINED_VIEW="0"),
+                                 dict(TEST_SPLIT="1", DSR_FORCE_PEER_PATH="1"), dict(DSR_PIPELINED_VIEW="0"),
+                                 dict(DSR_SMALL_VOLUME="1", TEST_SPLIT="1", DSR_PIPELINED_VIEW="1"), dict(TEST_SHARE="1", DSR_PIPELINED_VIEW="0")])
 def test_gpu_instance_pipeline(hip_api, oracle_lib, monkeypatch, env):
     """Main view -> GPU split into an instance volume + blanked static map, both fused and
     raycast: identical to the oracle running the reference's CPU loops.  Also with the view operations on the engines' view

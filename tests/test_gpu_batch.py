@@ -32,8 +32,9 @@ def _orc(settings, calib):
 
 
 @pytest.mark.parametrize("size,sync_status", [((320, 96), 1), ((320, 96), 0), ((1242, 375), 0)])
-def test_batch_equals_the_per_volume_calls_and_the_oracle(hip_api, size, sync_status):
+def test_batch_equals_the_per_volume_calls_and_the_oracle(hip_api, monkeypatch, size, sync_status):
     import torch
+    monkeypatch.setenv("DSR_PIPELINED_VIEW", "0")  # (engines a host waits on get a view pipeline by default; a batch has one stream)
     from dynslam_amd.engine import Batch
     from tests.common import assert_render_equal, assert_scene_equal
     W, H = size
@@ -112,8 +113,9 @@ def test_batch_equals_the_per_volume_calls_and_the_oracle(hip_api, size, sync_st
         e.close()
 
 
-def test_batch_argument_errors(hip_api):
+def test_batch_argument_errors(hip_api, monkeypatch):
     from dynslam_amd.engine import Batch, DsrError
+    monkeypatch.setenv("DSR_PIPELINED_VIEW", "0")
     W, H = 320, 96
     sc = StreetScene(W, H)
     calib = make_calib(*sc.intrinsics(), W, H)
