@@ -1934,9 +1934,11 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
     f.tileX0 = e->viewBox[0] / 16; f.tileY0 = e->viewBox[1] / 16;
     f.tilesX = std::max(0, div_up(e->viewBox[2], 16) - f.tileX0); f.tilesY = std::max(0, div_up(e->viewBox[3], 16) - f.tileY0);
     maxTilesX = std::max(maxTilesX, f.tilesX); maxTilesY = std::max(maxTilesY, f.tilesY); maxGrid = std::max(maxGrid, e->gridIntegrate);
+    // k_integrate's specialisations (colour camera == depth camera; no weighting options + exact short division): the batch takes
+    // the one EVERY active volume qualifies for — the general forms compute the same values (a pose with a -0 entry already makes
+    // calib_inv * M differ from M in a sign of zero, and a single volume then runs the general kernel too)
     const int rs = f.p.rgbSame ? 1 : 0, pl = (!f.p.depthWeighting && !f.p.stopAtMaxW && e->shortDivMuExact) ? 1 : 0;
-    if ((rgbSame >= 0 && rgbSame != rs) || (plain >= 0 && plain != pl)) return fail(DSR_E_ARG, "the volumes of a batch must share their fusion parameters");
-    rgbSame = rs; plain = pl;
+    rgbSame = rgbSame < 0 ? rs : (rgbSame & rs); plain = plain < 0 ? pl : (plain & pl);
     if (e->statusDev) e->statusSeq++;
     f.publishSeq = e->statusSeq;
     e->sceneVersion += 2; e->noVisibleValid = false; e->listVersion++; e->framesProcessed++;

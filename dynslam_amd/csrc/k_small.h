@@ -207,36 +207,50 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   }
   // ---- D0: the groups of 8 entries the mark touched (a byte each in visGrp, 147 KB, nine 16-byte loads per lane as in the
   // bit sweep): the types that carry kTouchedNow become bits of visBits — the group's 8 bits are ONE byte of that plane, nobody
-  // else writes it before the barrier, so a plain byte store does — and go back to the plain type 1
+  // else writes it before the barrier, so a plain byte store does — and go back to the plain type 1.  A lane rarely owns more than
+  // one marked group per row: the FIRST group's types of all nine rows are requested together (one round trip for the wave, not
+  // nine), the rest goes through the loop behind.
   {
     const int wave = tid >> 6;
     uint4 *rows = reinterpret_cast<uint4 *>(s.visGrp) + wave * (kSmallRows * 64) + lane;
     uint4 g[kSmallRows];
 #pragma unroll
     for (int j = 0; j < kSmallRows; ++j) g[j] = rows[j * 64];
+    auto settle = [&](int grp, uint2 t8) {
+      uint32_t bits = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        uint32_t &w = k < 4 ? t8.x : t8.y;
+        const int sh8 = (k & 3) * 8;
+        if (((w >> sh8) & 0xffu) == (uint32_t)kTouchedNow) { bits |= 1u << k; w = (w & ~(0xffu << sh8)) | (1u << sh8); }
+      }
+      *reinterpret_cast<uint2 *>(visType + (size_t)grp * 8) = t8;
+      reinterpret_cast<uint8_t *>(s.visBits)[grp] = (uint8_t)bits;
+    };
+    uint32_t nz[kSmallRows];
+    int first[kSmallRows];
+    uint2 t8[kSmallRows];
 #pragma unroll
     for (int j = 0; j < kSmallRows; ++j) {
-      if ((g[j].x | g[j].y | g[j].z | g[j].w) == 0u) continue;
-      const int firstGroup = (wave * (kSmallRows * 64) + j * 64 + lane) * 16;
-      // which of the 16 groups are marked (from the registers); the loop runs as often as the busiest lane of the wave has groups
       const uint32_t gw[4] = {g[j].x, g[j].y, g[j].z, g[j].w};
-      uint32_t nz = 0u;
+      uint32_t m = 0u;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) nz |= ((gw[b >> 2] >> ((b & 3) * 8)) & 0xffu) ? (1u << b) : 0u;
-      while (nz) {
-        const int grp = firstGroup + __ffs((int)nz) - 1;
-        nz &= nz - 1u;
-        uint2 *types = reinterpret_cast<uint2 *>(visType + (size_t)grp * 8);
-        uint2 t8 = *types;
-        uint32_t bits = 0u;
+      for (int b = 0; b < 16; ++b) m |= ((gw[b >> 2] >> ((b & 3) * 8)) & 0xffu) ? (1u << b) : 0u;
+      nz[j] = m;
+      first[j] = m ? (wave * (kSmallRows * 64) + j * 64 + lane) * 16 + __ffs((int)m) - 1 : -1;
+      t8[j] = make_uint2(0u, 0u);
+      if (m) t8[j] = *reinterpret_cast<const uint2 *>(visType + (size_t)first[j] * 8);
+    }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          uint32_t &w = k < 4 ? t8.x : t8.y;
-          const int sh8 = (k & 3) * 8;
-          if (((w >> sh8) & 0xffu) == (uint32_t)kTouchedNow) { bits |= 1u << k; w = (w & ~(0xffu << sh8)) | (1u << sh8); }
-        }
-        *types = t8;
-        reinterpret_cast<uint8_t *>(s.visBits)[grp] = (uint8_t)bits;
+    for (int j = 0; j < kSmallRows; ++j) {
+      if (nz[j] == 0u) continue;
+      settle(first[j], t8[j]);
+      uint32_t m = nz[j] & (nz[j] - 1u);
+      const int firstGroup = (wave * (kSmallRows * 64) + j * 64 + lane) * 16;
+      while (m) {
+        const int grp = firstGroup + __ffs((int)m) - 1;
+        m &= m - 1u;
+        settle(grp, *reinterpret_cast<const uint2 *>(visType + (size_t)grp * 8));
       }
       rows[j * 64] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame's mark
     }
