@@ -630,6 +630,10 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     if profiled:
         prof = probe.profile_get()
         probe.profile_enable(False)
+    # (the state the line reports is the one the timed region left: read before the diagnostic legs below fuse the frames again)
+    stats = scene.static.get_stats() if scene.owns_static else None
+    inst_stats = [e.get_stats() for e in scene.instances.values()]
+    hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
     # where a step goes (for the day the N > 1 curve is measured): this rank's fusion chain alone (the same K steps without the
     # preview: no render, no collective, no composite), and — N > 1 — the same workload with the OTHER collective (gather to the
     # consumer's GPU instead of the in-place all-gather)
@@ -643,9 +647,6 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
         alt_t = scene.exchange.x.timing(False)
         scene.exchange.x.set_collective(0, 0)
         alt = (alt_s, alt_t)
-    stats = scene.static.get_stats() if scene.owns_static else None
-    inst_stats = [e.get_stats() for e in scene.instances.values()]
-    hit = float((scene.target_depth > 0).float().mean().item()) if rank == 0 else 0.0
     scene.close()
     gather_us = 1e3 * xt["gather_ms"] / xt["n_gathers"] if xt and xt["n_gathers"] else 0.0
     composite_us = 1e3 * xt["composite_ms"] / xt["n_composites"] if xt and xt["n_composites"] else 0.0

@@ -18,7 +18,16 @@
  *     metres with <=0 meaning "invalid" (InstanceReconstructor.cpp:97,165).
  *   - every call returns a dsr_status (0 == DSR_OK) unless stated otherwise.
  *   - calls on one engine handle must come from one thread at a time; distinct
- *     handles are independent (each owns its HIP stream).
+ *     handles are independent (each owns its HIP stream) and may be driven from
+ *     distinct threads — with two things shared per GPU and process: the I/O stream
+ *     (frame uploads, previews, view read-backs of ALL engines of that GPU queue on
+ *     it in call order) and, for engines a host waits on (sync_status), the view
+ *     stream and the instance-sized volumes' fusion stream (DSR_PIPELINED_VIEW=2,
+ *     the default for them).  DynSLAM drives all its drivers from one thread
+ *     (SURVEY 8b); a host that drives a map and its instance drivers from several
+ *     threads gets correct results and head-of-line waits on those streams.
+ *     Engines that share a stream explicitly (dsr_engine_share_stream, a
+ *     dsr_batch) must be driven from ONE thread.
  *   - "_dev" variants take pointers to device (HBM) memory on the engine's GPU.
  *
  * The same signatures, with the prefix `orc_` instead of `dsr_`, are exported by
@@ -37,7 +46,8 @@ extern "C" {
 /* bumped whenever a public struct layout or the meaning of a field changes, so that a library and a caller built on
  * different sides of the change refuse each other at load (2: dsr_kernel_time grew bytes_layout/units, dsr_stats was
  * extended, DSR_E_IO; 3: the multi-GPU exchange (dsr_exchange_*), dsr_update_view_bgr, host-buffer calls no longer
- * synchronise with the engine's stream) */
+ * synchronise with the engine's stream; 4: dsr_view_split_silhouette, dsr_engine_share_stream, dsr_pin_host_thread, the volume
+ * batch dsr_batch_*, dsr_exchange_set_collective / _timing; the view pipeline is on by default for engines with sync_status) */
 #define DSR_ABI_VERSION 4
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
