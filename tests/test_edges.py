@@ -380,3 +380,55 @@ def test_gpu_view_previews_and_visible_count(hip_api, oracle_lib):
     # either output alone
     bgr = np.zeros((H, W, 3), np.uint8)
     assert hip_api.get_view_previews(g._h, vp(bgr), None) == 0 and np.array_equal(bgr, out["g"][0])
+
+
+def test_oracle_batch_is_the_reference_loop(oracle_lib):
+    """orc_batch_fuse / orc_batch_render (the checkers of dsr_batch_*, reached through the same Batch wrapper the product uses) ==
+    the per-instance calls in the reference's order: views, scenes, preview renders; an instance whose volume lives elsewhere is
+    only blanked; PoseArg hands the same pose over as the matrix."""
+    from dynslam_amd import _capi
+    from dynslam_amd.engine import Batch, PoseArg
+    from oracle.oracle import load_api
+    from tests.common import assert_render_equal, assert_scene_equal
+    W, H = 160, 48
+    sc = StreetScene(W, H, n_instances=3)
+    _, m1, a1 = make_engines(oracle_factory, W, H)
+    _, b1, _ = make_engines(oracle_factory, W, H)
+    _, m2, a2 = make_engines(oracle_factory, W, H)
+    _, b2, _ = make_engines(oracle_factory, W, H)
+    batch = Batch(m1, [a1, b1], api=load_api())
+    out_c, out_d = np.zeros((2, H, W, 4), np.uint8), np.zeros((2, H, W), np.float32)
+    for i in range(3):
+        rgba, d, T, inst_id = sc.frame(i)
+        masks = []
+        for k in range(3):
+            ys, xs = np.nonzero(inst_id == k)
+            if len(ys):
+                y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+                rel = (np.linalg.inv(sc.instance_pose(k, i).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
+                masks.append((k, int(x0), int(y0), np.ascontiguousarray((inst_id[y0:y1, x0:x1] == k).astype(np.uint8)), rel))
+        assert masks
+        m1.update_view(rgba, d); m2.update_view(rgba, d)
+        vol = {0: 0, 1: 1}  # instance 2 is somebody else's
+        items = []
+        for k, x0, y0, m, rel in masks:
+            mk = (m.ctypes.data, m.shape[1], m.shape[0])
+            items.append((vol.get(k, -1), mk if k in vol else None, x0, y0, mk, x0, y0, PoseArg(rel) if k in vol else None))
+        assert batch.fuse(items, want_status=True) == [0] * len(items)
+        for k, x0, y0, m, rel in masks:
+            if k in vol:
+                m2.extract_silhouette((a2, b2)[vol[k]], m, x0, y0)
+            m2.remove_silhouette(m, x0, y0)
+            if k in vol:
+                e = (a2, b2)[vol[k]]
+                e.set_pose_inv_m(rel); e.process_frame(); e.prepare()
+        assert np.array_equal(m1.get_view()[0], m2.get_view()[0]) and np.array_equal(m1.get_view()[1], m2.get_view()[1])
+        for g, o in ((a1, a2), (b1, b2)):
+            assert np.array_equal(g.get_view()[1], o.get_view()[1])
+            assert_scene_equal(g, o); assert_render_equal(g, o)
+        vis = [(vol[k], np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32)) for k, _, _, _, rel in masks if k in vol]
+        batch.render([(v, M, out_c[v].ctypes.data, out_d[v].ctypes.data) for v, M in vis])
+        for v, M in vis:
+            c, dd = (a2, b2)[v].get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+            assert np.array_equal(out_c[v], c) and np.array_equal(out_d[v], dd)
+    batch.close()
