@@ -2230,29 +2230,26 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
   hipStream_t io = nullptr;
   int st = io_stream(e, &io);
   if (st) return st;
-  if (!e->pvDev) {
+  if (!e->pvPin) {
     e->pvMmOff = ((size_t)e->P * 3 + 255) / 256 * 256;
     const size_t bytes = e->pvMmOff + (size_t)e->P * 2;
-    if ((st = dmalloc(&e->pvDev, bytes))) return st;
     if (hipHostMalloc(reinterpret_cast<void **>(&e->pvPin), bytes, hipHostMallocDefault) != hipSuccess)
       return fail(DSR_E_NOMEM, "pinned preview staging allocation failed");
   }
   if ((st = io_reads_view(e, io))) return st;
-  // buffers the caller page-locked (dsr_pin_host_buffer) take the copy directly: no staging copy on the host
-  const bool bgrPinned = bgr_out && host_range_pinned(bgr_out, (size_t)e->P * 3);
-  const bool mmPinned = depth_mm_out && host_range_pinned(depth_mm_out, (size_t)e->P * 2);
+  // ONE conversion kernel stores both previews straight into page-locked host memory (k_edges.h k_previews): buffers the caller
+  // page-locked (dsr_pin_host_buffer: the reference keeps its previews in cv::Mat members) take the stores directly, others go
+  // through the engine's own pinned pair and one memcpy on the host.  No copy command: the conversion + two D2H copies of round 4
+  // were four commands with a hand-over between the compute queue and the copy engine each.
+  const bool bgrPinned = bgr_out && host_range_pinned(bgr_out, (size_t)e->P * 3) && ((uintptr_t)bgr_out & 3) == 0;
+  const bool mmPinned = depth_mm_out && host_range_pinned(depth_mm_out, (size_t)e->P * 2) && ((uintptr_t)depth_mm_out & 7) == 0;
+  void *bgrDev = nullptr, *mmDev = nullptr;
+  if (bgr_out) HIP_TRY(hipHostGetDevicePointer(&bgrDev, bgrPinned ? (void *)bgr_out : (void *)e->pvPin, 0));
+  if (depth_mm_out) HIP_TRY(hipHostGetDevicePointer(&mmDev, mmPinned ? (void *)depth_mm_out : (void *)(e->pvPin + e->pvMmOff), 0));
   {
     StreamSwap sw(e, io);
-    if (bgr_out) {
-      LAUNCH(e, "preview_convert", k_rgba_to_bgr, dim3(div_up(e->P, 256)), dim3(256), (const uchar4 *)e->rgb, e->pvDev, e->P);
-      HIP_TRY(hipMemcpyAsync(bgrPinned ? bgr_out : e->pvPin, e->pvDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, io));
-    }
-    if (depth_mm_out) {
-      LAUNCH(e, "preview_convert", k_depth_m_to_mm, dim3(div_up(e->P, 256)), dim3(256), (const float *)e->depth,
-             reinterpret_cast<short *>(e->pvDev + e->pvMmOff), e->P);
-      HIP_TRY(hipMemcpyAsync(mmPinned ? (uint8_t *)depth_mm_out : e->pvPin + e->pvMmOff, e->pvDev + e->pvMmOff, (size_t)e->P * 2,
-                             hipMemcpyDeviceToHost, io));
-    }
+    LAUNCH(e, "preview_convert", k_previews, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const uchar4 *)e->rgb, (const float *)e->depth,
+           (uint32_t *)bgrDev, (short *)mmDev, e->P);
   }
   HIP_TRY(hipGetLastError());
   if ((st = io_read_done(e, io))) return st;

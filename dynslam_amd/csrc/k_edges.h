@@ -58,6 +58,39 @@ __global__ __launch_bounds__(256) void k_depth_m_to_mm(const float *__restrict__
   depth_m_to_mm_px(i, m, mm);
 }
 
+// PrepareNextStep's two previews (ItmToCv + ItmDepthToCv, InfiniTamDriver.h:154-156) in ONE kernel that may store straight into
+// page-locked HOST memory: four pixels per thread — 12 bytes of packed BGR as three dwords, four int16 millimetres as one 8-byte
+// store — so that a wave writes 768 + 512 consecutive bytes over the host link instead of byte-sized stores, and no copy command
+// (with its hand-over between the compute queue and the copy engine) follows.  Same per-pixel functions as the two kernels above.
+__global__ __launch_bounds__(256) void k_previews(const uchar4 *__restrict__ rgba, const float *__restrict__ depth,
+                                                  uint32_t *__restrict__ bgrOut, short *__restrict__ mmOut, int n) {
+  const int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    if (bgrOut) {
+      const uint4 c = *reinterpret_cast<const uint4 *>(rgba + i4);  // four RGBA pixels (r = low byte)
+      auto B = [](uint32_t px) { return (px >> 16) & 0xffu; };
+      auto G = [](uint32_t px) { return (px >> 8) & 0xffu; };
+      auto R = [](uint32_t px) { return px & 0xffu; };
+      uint32_t *o = bgrOut + (i4 >> 2) * 3;  // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+      o[0] = B(c.x) | (G(c.x) << 8) | (R(c.x) << 16) | (B(c.y) << 24);
+      o[1] = G(c.y) | (R(c.y) << 8) | (B(c.z) << 16) | (G(c.z) << 24);
+      o[2] = R(c.z) | (B(c.w) << 8) | (G(c.w) << 16) | (R(c.w) << 24);
+    }
+    if (mmOut) {
+      const float4 d = *reinterpret_cast<const float4 *>(depth + i4);
+      short4 m;
+      m.x = (short)DeviceOps::f2i(d.x * (float)1000); m.y = (short)DeviceOps::f2i(d.y * (float)1000);
+      m.z = (short)DeviceOps::f2i(d.z * (float)1000); m.w = (short)DeviceOps::f2i(d.w * (float)1000);
+      *reinterpret_cast<short4 *>(mmOut + i4) = m;
+    }
+  } else {
+    for (int i = i4; i < n; ++i) {
+      if (bgrOut) rgba_to_bgr_px(i, rgba, reinterpret_cast<uint8_t *>(bgrOut));
+      if (mmOut) depth_m_to_mm_px(i, depth, mmOut);
+    }
+  }
+}
+
 // dest (instance view) := default everywhere, source pixel where the bbox-local mask is 1
 __host__ __device__ __forceinline__ void extract_silhouette_px(int x, int y, const uchar4 *__restrict__ srcRgb, const float *__restrict__ srcDepth,
                                                                uchar4 *__restrict__ dstRgb, float *__restrict__ dstDepth, int W,
