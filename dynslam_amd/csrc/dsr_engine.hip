@@ -2237,19 +2237,37 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
       return fail(DSR_E_NOMEM, "pinned preview staging allocation failed");
   }
   if ((st = io_reads_view(e, io))) return st;
-  // ONE conversion kernel stores both previews straight into page-locked host memory (k_edges.h k_previews): buffers the caller
-  // page-locked (dsr_pin_host_buffer: the reference keeps its previews in cv::Mat members) take the stores directly, others go
-  // through the engine's own pinned pair and one memcpy on the host.  No copy command: the conversion + two D2H copies of round 4
-  // were four commands with a hand-over between the compute queue and the copy engine each.
+  // ONE conversion kernel for both previews (k_edges.h k_previews).  Buffers the caller page-locked (dsr_pin_host_buffer: the
+  // reference keeps its previews in cv::Mat members) receive them directly, others through the engine's own pinned pair and one
+  // memcpy on the host.  How the bytes cross the host link depends on what else the GPU is doing (profiles/r05h_through_shim.log):
+  //  * an instance-sized or mid-sized volume: the kernel STORES STRAIGHT INTO the page-locked host memory — no scratch, no copy
+  //    command (round 4's two kernels + two D2H copies were four commands, each handed over between the compute queue and the
+  //    copy engine): configs[2] through the C++ host 477-499 -> 664-667 frames/s;
+  //  * a volume whose integration fills the chip for half a millisecond (>= 2^20 blocks): waves that sit on host-link stores take
+  //    slots and memory queues from it (configs[1] through the host 851-858 -> 824-827 frames/s with direct stores), so the kernel
+  //    converts into HBM and the copy engine moves the bytes, as before.
+  const bool direct = e->noBlocks < (1 << 20);
   const bool bgrPinned = bgr_out && host_range_pinned(bgr_out, (size_t)e->P * 3) && ((uintptr_t)bgr_out & 3) == 0;
   const bool mmPinned = depth_mm_out && host_range_pinned(depth_mm_out, (size_t)e->P * 2) && ((uintptr_t)depth_mm_out & 7) == 0;
-  void *bgrDev = nullptr, *mmDev = nullptr;
-  if (bgr_out) HIP_TRY(hipHostGetDevicePointer(&bgrDev, bgrPinned ? (void *)bgr_out : (void *)e->pvPin, 0));
-  if (depth_mm_out) HIP_TRY(hipHostGetDevicePointer(&mmDev, mmPinned ? (void *)depth_mm_out : (void *)(e->pvPin + e->pvMmOff), 0));
+  uint8_t *bgrHost = bgr_out ? (bgrPinned ? bgr_out : e->pvPin) : nullptr;
+  uint8_t *mmHost = depth_mm_out ? (mmPinned ? (uint8_t *)depth_mm_out : e->pvPin + e->pvMmOff) : nullptr;
+  void *bgrDst = nullptr, *mmDst = nullptr;
+  if (direct) {
+    if (bgrHost) HIP_TRY(hipHostGetDevicePointer(&bgrDst, bgrHost, 0));
+    if (mmHost) HIP_TRY(hipHostGetDevicePointer(&mmDst, mmHost, 0));
+  } else {
+    if (!e->pvDev && (st = dmalloc(&e->pvDev, e->pvMmOff + (size_t)e->P * 2))) return st;
+    bgrDst = bgrHost ? e->pvDev : nullptr;
+    mmDst = mmHost ? e->pvDev + e->pvMmOff : nullptr;
+  }
   {
     StreamSwap sw(e, io);
     LAUNCH(e, "preview_convert", k_previews, dim3(div_up(div_up(e->P, 4), 256)), dim3(256), (const uchar4 *)e->rgb, (const float *)e->depth,
-           (uint32_t *)bgrDev, (short *)mmDev, e->P);
+           (uint32_t *)bgrDst, (short *)mmDst, e->P);
+    if (!direct) {
+      if (bgrHost) HIP_TRY(hipMemcpyAsync(bgrHost, e->pvDev, (size_t)e->P * 3, hipMemcpyDeviceToHost, io));
+      if (mmHost) HIP_TRY(hipMemcpyAsync(mmHost, e->pvDev + e->pvMmOff, (size_t)e->P * 2, hipMemcpyDeviceToHost, io));
+    }
   }
   HIP_TRY(hipGetLastError());
   if ((st = io_read_done(e, io))) return st;

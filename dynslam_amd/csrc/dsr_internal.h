@@ -202,7 +202,7 @@ struct dsr_engine {
   bool viewEventValid = false;
   hipEvent_t evViewRead = nullptr;             // the I/O stream's last read of the view (previews, dsr_get_view)
   bool viewReadEver = false;
-  uint8_t *pvPin = nullptr, *pvDev = nullptr;  // previews: packed BGR (3 B / pixel), then int16 millimetres — pinned; the conversion kernel stores into it (pvDev: unused since round 5)
+  uint8_t *pvPin = nullptr, *pvDev = nullptr;  // previews: packed BGR (3 B / pixel), then int16 millimetres — pinned pair (the conversion kernel of a small volume stores into it directly) and the HBM scratch of a map-sized volume
   size_t pvMmOff = 0;
   int32_t *statusHost = nullptr, *statusDev = nullptr;  // {noVisibleBlocks, status, sequence number}, pinned + mapped
   int statusSeq = 0;
