@@ -2243,10 +2243,11 @@ int dsr_get_view_previews(dsr_engine *e, uint8_t *bgr_out, int16_t *depth_mm_out
   //  * an instance-sized or mid-sized volume: the kernel STORES STRAIGHT INTO the page-locked host memory — no scratch, no copy
   //    command (round 4's two kernels + two D2H copies were four commands, each handed over between the compute queue and the
   //    copy engine): configs[2] through the C++ host 477-499 -> 664-667 frames/s;
-  //  * a volume whose integration fills the chip for half a millisecond (>= 2^20 blocks): waves that sit on host-link stores take
-  //    slots and memory queues from it (configs[1] through the host 851-858 -> 824-827 frames/s with direct stores), so the kernel
-  //    converts into HBM and the copy engine moves the bytes, as before.
-  const bool direct = e->noBlocks < (1 << 20);
+  //  * a map-sized volume (>= 2^20 blocks) that has the GPU to ITSELF: waves that sit on host-link stores take slots and memory
+  //    queues from its half-millisecond integration (configs[1] through the host 851-858 -> 824-827 frames/s with direct stores),
+  //    so the kernel converts into HBM and the copy engine moves the bytes, as before (852-856).  Next to instance drivers the map
+  //    stores directly as well: its copies queue behind theirs on the I/O stream otherwise (configs[2] 535-543 instead of 664).
+  const bool direct = !(e->noBlocks >= (1 << 20) && (e->device >= 64 || g_enginesOnDevice[e->device].load(std::memory_order_relaxed) <= 1));
   const bool bgrPinned = bgr_out && host_range_pinned(bgr_out, (size_t)e->P * 3) && ((uintptr_t)bgr_out & 3) == 0;
   const bool mmPinned = depth_mm_out && host_range_pinned(depth_mm_out, (size_t)e->P * 2) && ((uintptr_t)depth_mm_out & 7) == 0;
   uint8_t *bgrHost = bgr_out ? (bgrPinned ? bgr_out : e->pvPin) : nullptr;
