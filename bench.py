@@ -226,12 +226,13 @@ def through_shim(args, with_instances):
     """SURVEY 8d "through-shim" rate: the C++ host shim/host_bench (our driver class over shim/ITMLib.h, the
     ITMLib names DynSLAM's InfiniTamDriver uses) fed with the SAME frames as pageable host buffers; per frame
     it pays what DynSLAM's host pays around the engine: BGR->RGBA conversion, the H2D copy of the frame,
-    ProcessFrame, one status / noVisibleBlocks synchronisation, Prepare, the two preview conversions with their
-    D2H copies.  PCIe inclusive — never `value`.
+    ProcessFrame, one status / noVisibleBlocks synchronisation, Prepare, the two previews written into the host's page-locked
+    buffers.  PCIe inclusive — never `value`.
     Each leg is tools/bench_through_shim.py run as a process of its own (it generates the same frames, writes them to /dev/shm and
-    starts the C++ host): started from THIS process the identical host_bench command line on the identical input files read
-    223-275 frames/s for configs[2] where the tool reads 439-460 on the same box (profiles/r04t_cfg2_through_host_where.log;
-    configs[1] reads the same either way) — not understood yet, so the line reports what the tool measures."""
+    starts the C++ host).  Round 4 saw the identical host_bench command read half the rate for configs[2] when THIS process
+    started it (profiles/r04t_*); on round 5's boxes the parent made no difference, with the host thread pinned next to the GPU
+    or not (profiles/r05c_where_does_the_host_run.log) — host_bench pins itself (dsr_pin_host_thread) and the leg stays a process
+    of its own either way."""
     exe = os.path.join(ROOT, "shim", "host_bench")
     if not os.path.exists(exe):
         return None
@@ -255,7 +256,8 @@ def through_shim(args, with_instances):
             r2 = leg(4)
             out["configs2"] = {"frames_per_s": float(r2["frames_per_s"]), "ms_per_frame": float(r2["ms_per_frame"]),
                                "note": "static map + 4 instance volumes (shim/host_bench --masks): GPU view split, per driver and frame one "
-                                       "allocation status and two previews back to the host"}
+                                       "allocation status and two previews back to the host; at --steps 20 the instance volumes are "
+                                       "still growing (45 steps read ~12 % more: profiles/r05zz_through_shim.log)"}
         except Exception as ex:
             out["configs2"] = {"frames_per_s": None, "note": f"failed: {ex}"}
     return out
