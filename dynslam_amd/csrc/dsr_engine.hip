@@ -1778,6 +1778,7 @@ int dsr_view_remove_silhouette_dev(dsr_engine *e, const void *mask_dev, int x0, 
 
 struct dsr_batch {
   dsr_engine *source = nullptr;
+  int device = 0;  // (kept apart from `source`: the engines may be gone by the time the batch is destroyed)
   std::vector<dsr_engine *> vols;
   std::vector<BatchVolP> volsHost;
   BatchVolP *volsDev = nullptr;
@@ -1839,6 +1840,7 @@ int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volum
   dsr_batch *b = new (std::nothrow) dsr_batch();
   if (!b) return fail(DSR_E_NOMEM, "oom");
   b->source = source;
+  b->device = source->device;
   for (int k = 0; k < n_volumes; ++k) {
     dsr_engine *e = volumes[k];
     if (e->stream != source->stream) {  // one queue for the whole batch
@@ -1863,7 +1865,7 @@ int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volum
 
 void dsr_batch_destroy(dsr_batch *b) {
   if (!b) return;
-  (void)hipSetDevice(b->source->device);
+  (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(b->volsDev);
   (void)hipFree(b->framesDev);
