@@ -284,17 +284,22 @@ def roofline_from_profile(prof, args, copy_gbs):
             aos = r["bytes"] / r["launches"]             # the reference's AoS formulation
             achieved = layout / avg_s / 1e9
             traffic, traffic_src = pmc_traffic(args, "k_integrate", v_per_launch)
-            f_meas = round(achieved / copy_gbs, 4) if copy_gbs else None
-            t_meas = round(traffic / avg_s / 1e9 / copy_gbs, 4) if (traffic and copy_gbs) else None
+            # north_star's bar is ">= 60 % of MEASURED HBM roofline".  The denominator is the larger of this box's copy probe
+            # (dsr_measure_copy_bandwidth_spread: 4 GiB per direction, warm clocks, best launch of each of >= 5 rounds; max /
+            # median / min over the rounds reported) and the guide's float4-copy figure: a probe that reads low on a cold or
+            # shared box must not flatter the fraction (five driver runs read 4.6-6.2 TB/s from a 1 GiB probe).
+            probe = copy_gbs if isinstance(copy_gbs, dict) else ({"max": copy_gbs, "median": copy_gbs, "min": copy_gbs} if copy_gbs else None)
+            denom = max(probe["max"], HBM_GUIDE_COPY_GBS) if probe else None
+            f_meas = round(achieved / denom, 4) if denom else None
+            t_meas = round(traffic / avg_s / 1e9 / denom, 4) if (traffic and denom) else None
             roofline = {"bound": "hbm", "kernel": "k_integrate", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        # north_star's bar is ">= 60 % of MEASURED HBM roofline": the same achieved GB/s against this box's own copy
-                        # probe, on the compulsory bytes of the layout and on the bytes the counters saw move
                         "frac_of_measured_copy": f_meas,
-                        "traffic_frac_of_measured_copy": t_meas,
-                        "target_60pct_of_measured": {"on_compulsory_bytes": f_meas, "on_counter_traffic": t_meas,
-                                                     "met_on_compulsory_bytes": (f_meas >= 0.6) if f_meas is not None else None,
-                                                     "met_on_counter_traffic": (t_meas >= 0.6) if t_meas is not None else None},
+                        # the bar is priced on the COMPULSORY bytes of the layout; the counter traffic includes what the kernel
+                        # re-reads or over-fetches (1.3x): a diagnostic of waste, never credited as achievement
+                        "target_60pct_of_measured": {"denominator_GBps": denom, "on_compulsory_bytes": f_meas,
+                                                     "met": (f_meas >= 0.6) if f_meas is not None else None,
+                                                     "traffic_incl_waste": t_meas},
                         "traffic": traffic,
                         # the same launch priced with the bytes it really moved (PMC, profiles/)
                         "traffic_GBps": round(traffic / avg_s / 1e9, 1) if traffic else None,
@@ -304,7 +309,8 @@ def roofline_from_profile(prof, args, copy_gbs):
                         # on THIS box (best of 3 grids x plain / non-temporal, dsr_measure_copy_bandwidth)
                         "guide_copy_GBps": HBM_GUIDE_COPY_GBS, "frac_of_guide_copy": round(achieved / HBM_GUIDE_COPY_GBS, 4),
                         "traffic_frac_of_guide_copy": round(traffic / avg_s / 1e9 / HBM_GUIDE_COPY_GBS, 4) if traffic else None,
-                        "measured_copy_GBps": copy_gbs,
+                        "measured_copy_GBps": probe["max"] if probe else None,
+                        "measured_copy_spread_GBps": probe,
                         "avg_launch_us": round(1e6 * avg_s, 2),
                         "bytes_per_launch": round(layout, 0),
                         "visible_blocks_per_launch": round(v_per_launch, 1),
@@ -333,6 +339,9 @@ def roofline_from_profile(prof, args, copy_gbs):
                                "note": "compulsory = V*(16 + 1024) + 16*P + range image; the kernel is bound by its per-wave chain of "
                                        "dependent gathers (latency), not by bandwidth: DESIGN.md"}
         kernels["raycast"]["GBps"] = roofline["raycast"]["achieved"]
+        denom = roofline["target_60pct_of_measured"]["denominator_GBps"]
+        roofline["raycast"]["frac_of_measured_copy"] = round(roofline["raycast"]["achieved"] / denom, 4) if denom else None
+        roofline["raycast_frac"] = roofline["raycast"]["frac"]  # first-class next to `frac`
     return roofline, kernels
 
 
@@ -721,6 +730,129 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     }
 
 
+CFG4_PERIOD, CFG4_FRAMES, CFG4_MIN_AGE = 50, 320, 200
+
+
+def loop_frames_for(args):
+    """configs[4]'s lap: 50 frames = the 40 m period of the synthetic street (tools/bench_cfg5_sustained.py)."""
+    if "loop" not in _PREGENERATED:
+        _PREGENERATED["loop"] = make_frames(args.width, args.height, CFG4_PERIOD)
+    return _PREGENERATED["loop"]
+
+
+def leg_configs2(args, dev, local_rank, calib):
+    """BASELINE configs[2], engine-only: the 5 mm map + 4 instance volumes on this GPU — view split, fusion and tracking render of
+    every volume per frame (the per-volume calls of the reference's loop, InstanceReconstructor.cpp:315-361), inputs resident in HBM."""
+    import torch
+    from dynslam_amd.engine import EngineCore, default_settings
+    frames = frames_for(args, 4)
+    K, Wm = args.steps, args.warmup
+    kinds = volume_settings(args.preset)
+    eng = EngineCore(default_settings(**kinds["static"], device=local_rank, sync_status=0), calib)
+    inst = [EngineCore(default_settings(**kinds["instance"], device=local_rank, sync_status=0), calib) for _ in range(4)]
+    rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    dep = [torch.from_numpy(f[1]).to(dev) for f in frames]
+
+    def step(i):
+        eng.update_view_dev(rgb[i].data_ptr(), dep[i].data_ptr())
+        for k, x0, y0, mask, rel in frames[i][3]:
+            eng.extract_silhouette(inst[k], mask, x0, y0)
+            eng.remove_silhouette(mask, x0, y0)
+            inst[k].set_pose_inv_m(rel)
+            inst[k].process_frame()
+            inst[k].prepare()
+        eng.set_pose_inv_m(frames[i][2])
+        eng.process_frame()
+        eng.prepare()
+
+    def drain():
+        for e in inst:
+            e.sync()
+        eng.sync()
+        torch.cuda.synchronize()
+    for i in range(Wm):
+        step(i)
+    drain()
+    with _no_gc():
+        t0 = time.perf_counter()
+        for i in range(Wm, Wm + K):
+            step(i)
+        drain()
+        elapsed = time.perf_counter() - t0
+    st = eng.get_stats()
+    ist = [e.get_stats() for e in inst]
+    for e in inst:
+        e.close()
+    eng.close()
+    return {"value": round(K / elapsed, 3), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / K, 4), "steps": K, "warmup": Wm,
+            "config": {"workload": f"configs[2]: static map (preset {args.preset}) + 4 instance volumes (0.035 m, mu 1.0, 7142 blocks) on ONE "
+                                   f"GPU, engine-only (inputs resident in HBM, masks as host buffers through the pinned ring), frames {Wm}..{Wm + K - 1}",
+                       "static_visible_blocks_last_frame": st.no_visible_blocks,
+                       "instance_visible_blocks_last_frame": [s_.no_visible_blocks for s_ in ist],
+                       "engine_status": max([st.sticky_status] + [s_.sticky_status for s_ in ist])}}
+
+
+def leg_configs3_1gpu(args, dev, local_rank, calib):
+    """BASELINE configs[3] on ONE GPU (time-sliced): the 5 mm map + 7 instance volumes + the fused preview per step."""
+    from dynslam_amd.engine import EngineCore, default_settings
+    kinds = volume_settings(args.preset)
+    a = argparse.Namespace(**vars(args))
+    a.volumes, a.no_cpu_baseline, a.no_profile = SCALING_VOLUMES, True, True
+    line = run_volumes(a, frames_for(args, SCALING_VOLUMES - 1),
+                       lambda kind: EngineCore(default_settings(**kinds[kind], device=local_rank, sync_status=0), calib),
+                       dev, 1, 0, False, has_static=True)
+    return {k: line[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config")}
+
+
+def leg_configs4_short(args, dev, local_rank, calib):
+    """A SHORT configs[4] leg: 4 mm voxels, voxel GC (max_weight 1, min_age 200: DynSLAMGUI.cpp:36-42) + host swapping, 320 frames
+    of the 50-frame lap — the GC's FIFO is full and freeing blocks for the last 120 — with the structural invariants of the map
+    checked at the end (dynslam_amd/invariants.py).  The 4541-frame run is tools/bench_cfg5_sustained.py (profiles/)."""
+    import torch
+    from dynslam_amd.engine import EngineCore, default_settings
+    from dynslam_amd.invariants import check_structure
+    frames = loop_frames_for(args)
+    kw = dict(settings_kwargs("4mm"), use_swapping=1)
+    rgb = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    dep = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    eng = EngineCore(default_settings(**kw, device=local_rank, sync_status=0), calib)
+    n_warm = 20
+
+    def step(i):
+        j = i % CFG4_PERIOD
+        eng.update_view_dev(rgb[j].data_ptr(), dep[j].data_ptr())
+        eng.set_pose_inv_m(frames[j][2])
+        eng.process_frame()
+        eng.prepare()
+        eng.decay(1, CFG4_MIN_AGE, False)
+    for i in range(n_warm):
+        step(i)
+    eng.sync()
+    with _no_gc():
+        t0 = time.perf_counter()
+        for i in range(n_warm, CFG4_FRAMES):
+            step(i)
+        eng.sync()
+        elapsed = time.perf_counter() - t0
+    st = eng.get_stats()
+    t1 = time.perf_counter()
+    invariants = "ok"
+    try:
+        check_structure(eng, kw["sdf_local_block_num"], kw["hash_bucket_num"])
+    except AssertionError as ex:
+        invariants = f"VIOLATED: {ex}"
+    t_check = time.perf_counter() - t1
+    eng.close()
+    n = CFG4_FRAMES - n_warm
+    return {"value": round(n / elapsed, 3), "unit": "frames/s", "ms_per_step": round(1e3 * elapsed / n, 4), "steps": n, "warmup": n_warm,
+            "config": {"workload": f"configs[4], short: frames {n_warm}..{CFG4_FRAMES - 1} of laps of a {CFG4_PERIOD}-frame loop, preset 4mm "
+                                   f"(voxel {kw['voxel_size']} m, mu {kw['mu']} m, 2^24 blocks), voxel GC max_weight 1 min_age {CFG4_MIN_AGE} every "
+                                   f"frame + host swapping; step = UpdateView + ProcessFrame (+ swap in / out) + Prepare + Decay",
+                       "allocated_blocks": kw["sdf_local_block_num"] - 1 - st.last_free_block_id, "visible_blocks_last_frame": st.no_visible_blocks,
+                       "decayed_blocks": st.decayed_block_count, "host_store_slots": st.host_store_slots, "engine_status": st.sticky_status,
+                       "structural_invariants": invariants, "invariants_check_s": round(t_check, 2)}}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -730,7 +862,7 @@ def parse_args(argv=None):
     ap.add_argument("--preset", default="5mm", choices=sorted(PRESETS))
     ap.add_argument("--width", type=int, default=1242)
     ap.add_argument("--height", type=int, default=375)
-    ap.add_argument("--cpu-budget-s", type=float, default=12.0, help="per CPU leg (all cores, one thread)")
+    ap.add_argument("--cpu-budget-s", type=float, default=8.0, help="per CPU leg (all cores, one thread)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-through-shim", action="store_true",
                     help="skip the C++-host leg (shim/host_bench: the same frames as pageable host buffers through the ITMLib shim)")
@@ -758,6 +890,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs3", action="store_true", help="--gpus N > 1: only the instance-volumes leg")
     ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
     ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of a multi-volume line")
+    ap.add_argument("--no-nested-legs", action="store_true", help="skip configs[2] / configs[3] on one GPU / the short configs[4] leg of the N = 1 line")
     ap.add_argument("--no-scaling-leg", action="store_true",
                     help="N = 1: do not append north_star's scaling workload (8 instance volumes on this GPU) to the line")
     return ap.parse_args(argv)
@@ -798,6 +931,12 @@ def run_rank(args):
     scaling_leg = (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_scaling_leg and args.preset == "5mm"
                    and not (args.decay or args.swap or args.instances or args.host_views))
     frames8 = frames_for(args, SCALING_VOLUMES) if scaling_leg else None
+    # ... and BASELINE.json's other configurations as nested legs, each with a `status`, so that the driver's line — not only
+    # profiles/ — observes them: configs[2] engine-only, configs[3] time-sliced on this one GPU, and a short
+    # configs[4] leg (4 mm, voxel GC + host swapping, structural invariants checked)
+    nested_legs = scaling_leg and not args.no_nested_legs
+    if nested_legs:
+        frames_for(args, 4); frames_for(args, SCALING_VOLUMES - 1); loop_frames_for(args)
 
 
     import torch
@@ -826,16 +965,16 @@ def run_rank(args):
     poses = [f[2] for f in frames]
     torch.cuda.synchronize()
 
-    # measured device-to-device copy bandwidth of this GPU with the library's float4 grid-stride copy
-    # (MI355X_MICROARCH.md: 6.29 TB/s for that kernel), 1 GiB read + 1 GiB written per pass, reported
-    # next to the nominal 8 TB/s the roofline fraction is quoted against
+    # measured device-to-device copy bandwidth of this GPU with the library's float4 grid-stride copy (MI355X_MICROARCH.md: 6.29 TB/s
+    # for that kernel) — the roofline's "measured" denominator: 4 GiB per direction, clocks warm, best launch of each of 5 rounds
+    # (dsr_measure_copy_bandwidth_spread); max / median / min over the rounds are reported
     copy_gbs = None
     if rank == 0:
         import ctypes as C
         from dynslam_amd.engine import load_hip_api
-        g = C.c_double(0.0)
-        if load_hip_api().measure_copy_bandwidth(local_rank, 1 << 30, 10, C.byref(g)) == 0:
-            copy_gbs = round(g.value, 1)
+        g3 = (C.c_double * 3)()
+        if load_hip_api().measure_copy_bandwidth_spread(local_rank, 4 << 30, 5, g3) == 0:
+            copy_gbs = {"max": round(g3[0], 1), "median": round(g3[1], 1), "min": round(g3[2], 1)}
 
     sc = StreetScene(W, H)
     kw = settings_kwargs(args.preset)
@@ -942,6 +1081,27 @@ def run_rank(args):
                 out["instance_volumes8_1gpu"] = {k: line[k] for k in ("value", "unit", "ms_per_step", "scaling", "config", "cpu_baseline")}
             except Exception as ex:
                 out["instance_volumes8_1gpu"] = {"value": None, "note": f"failed: {ex}"}
+            c = (out.get("instance_volumes8_1gpu") or {}).get("config") or {}
+            if roofline is not None and c.get("composite_us"):
+                # third kernel with a roofline of its own: compulsory bytes of an L-layer composite = 4 B of depth per
+                # layer and pixel + the target's depth and colour read and written (16 B) — the winners' colour reads are a few %
+                L, P = SCALING_VOLUMES, W * H
+                comp = P * (4.0 * L + 16.0)
+                gbs = comp / (c["composite_us"] * 1e-6) / 1e9
+                roofline["composite"] = {"bound": "hbm", "kernel": "k_composite", "layers": L, "bytes_per_launch": comp,
+                                         "avg_launch_us": c["composite_us"], "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                         "note": "HIP events on the exchange's stream around k_composite<true> in the instance_volumes8_1gpu leg"}
+                roofline["composite_frac"] = roofline["composite"]["frac"]
+        if nested_legs:
+            calib = make_calib(*sc.intrinsics(), W, H)
+            for key, fn in (("configs2", lambda: leg_configs2(args, dev, local_rank, calib)),
+                            ("configs3_1gpu", lambda: leg_configs3_1gpu(args, dev, local_rank, calib)),
+                            ("configs4_short", lambda: leg_configs4_short(args, dev, local_rank, calib))):
+                try:
+                    out[key] = dict(fn(), status="ok")
+                except Exception as ex:  # a nested leg must never take the line down; its status says what happened
+                    out[key] = {"value": None, "status": f"failed: {type(ex).__name__}: {ex}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 from types import SimpleNamespace
 
-ABI_VERSION = 4  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
+VIEW_PIPELINE_AUTO, VIEW_PIPELINE_OFF, VIEW_PIPELINE_PER_ENGINE, VIEW_PIPELINE_SHARED = 0, 1, 2, 3  # dsr_settings.view_pipeline
+ABI_VERSION = 5  # == DSR_ABI_VERSION of include/dsr.h (tests/test_capi_symbols.py compares the header too)
 BLOCK_SIZE = 8
 BLOCK_SIZE3 = 512
 
@@ -46,7 +47,7 @@ class Settings(C.Structure):
         ("stop_integrating_at_max_w", C.c_int32), ("sdf_local_block_num", C.c_int32),
         ("hash_bucket_num", C.c_int32), ("excess_list_size", C.c_int32),
         ("use_swapping", C.c_int32), ("use_bilateral_filter", C.c_int32),
-        ("device", C.c_int32), ("sync_status", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("device", C.c_int32), ("sync_status", C.c_int32), ("view_pipeline", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -184,6 +185,7 @@ SIGNATURES = {
     "dump_stored_block": (C.c_int, [_H, C.c_int, _P, C.POINTER(C.c_int)]),
     "selftest_division": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    "measure_copy_bandwidth_spread": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "profile_enable": (C.c_int, [_H, C.c_int]),
     "profile_reset": (C.c_int, [_H]),
     "profile_get": (C.c_int, [_H, C.POINTER(KernelTime), C.c_int]),

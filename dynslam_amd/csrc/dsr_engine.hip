@@ -203,6 +203,9 @@ int reset_scene(dsr_engine *e) {
     HIP_TRY(hipMemsetAsync(e->scene.allocBits, 0, (size_t)kSmallBitWords * 4, e->stream));
   }
   e->fifoHead = 0; e->fifoLen = 0;
+  // (the render buffers keep whatever the previous scene left in them: the next raycast of each render state is a full-frame one)
+  for (RenderStateDev *rs : {&e->live, &e->freeview})
+    if (rs->rayBox) hipLaunchKernelGGL(k_raybox_reset, dim3(1), dim3(RB_WORDS), 0, e->stream, rs->rayBox, (e->W + 7) / 8, (e->H + 7) / 8);
   HIP_TRY(hipGetLastError());
   if (e->statusHost) {
     // the published words describe a scene that no longer exists; the next allocation publishes number statusSeq + 1
@@ -218,7 +221,7 @@ void free_all(dsr_engine *e) {
   F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
   F(e->scene.visGrp); F(e->scene.visBits); F(e->scene.allocBits);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
-    F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage);
+    F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage); F(rs->rayBox);
   }
   F(e->tileSums); F(e->integrateStats); F(e->allocList); F(e->allocWork); F(e->meshTris); F(e->rgb); F(e->depth); F(e->depthTmp); F(e->rawDepth); F(e->pointsMap); F(e->normalsMap);
   F(e->freeDepth); F(e->aosScratch);
@@ -491,7 +494,7 @@ int allocate_scene(dsr_engine *e) {
       ProfScope _ps(e, "small_alloc_visible");
       hipLaunchKernelGGL(k_small_alloc_visible, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene,
                          (const float *)e->depth, rs.visType, e->numTilesE, e->allocWork, rs.visibleIDs, rs.visBlocks, e->noBlocks,
-                         e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax));
+                         e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox);
     }
     HIP_TRY(hipGetLastError());
     { int st = after_fusion(e); if (st) return st; }
@@ -569,7 +572,7 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
     ProfScope _ps(e, "expected_depth");
     hipLaunchKernelGGL(k_expected_depth_one, dim3(1), dim3(1024), (size_t)mw * mh * sizeof(int2), e->stream, p, e->scene,
                        (const int4 *)rs.visBlocks, rs.ctrIdx, reinterpret_cast<int2 *>(rs.minmax),
-                       rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? 1 : 0);
+                       rs.ctrIdx == CTR_NO_VISIBLE_LIVE ? 1 : 0, rs.rayBox);
     return DSR_OK;
   }
   LAUNCH(e, "minmax_init", k_minmax_init, dim3(div_up(mw * mh, 256)), dim3(256), rs.minmax, mw * mh,
@@ -589,7 +592,8 @@ int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p) {
 
 int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderStateDev &rs) {
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
-  LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
+  if (rs.rayBox) LAUNCH(e, name, k_raycast_box, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, rs.rayBox);
+  else LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
   return DSR_OK;
 }
 
@@ -851,7 +855,12 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   // all instance-sized volumes: configs[2] through the C++ host 410 -> 457 frames/s (profiles/r04d_*, r05d), the whole GPU suite
   // green under it (profiles/r05e_gpu_suite_pv2.log).  Engines driven without status waits (the bench, the sharded scene, a volume
   // batch) keep one stream each and no view stream.  env DSR_PIPELINED_VIEW=0 / 1 / 2 overrides (1: streams per engine).
-  const int pvMode = getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : (s.sync_status ? 2 : 0);
+  // dsr_settings.view_pipeline (ABI 5) names a form explicitly — a host that wants its status-reporting volumes in a batch or on a
+  // shared stream asks for _OFF instead of switching the whole process with the environment variable.
+  if (s.view_pipeline < DSR_VIEW_PIPELINE_AUTO || s.view_pipeline > DSR_VIEW_PIPELINE_SHARED) { delete e; return fail(DSR_E_ARG, "bad view_pipeline"); }
+  const int pvMode = s.view_pipeline == DSR_VIEW_PIPELINE_OFF ? 0 : s.view_pipeline == DSR_VIEW_PIPELINE_PER_ENGINE ? 1
+                     : s.view_pipeline == DSR_VIEW_PIPELINE_SHARED ? 2
+                     : getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : (s.sync_status ? 2 : 0);
   auto shared_stream = [&](hipStream_t *table) -> hipStream_t {
     if (e->device < 0 || e->device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_ioMutex);
@@ -898,6 +907,9 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
     ALLOC(dmalloc(&rs->minmax, (size_t)mw * mh));
     ALLOC(dmalloc(&rs->raycastResult, (size_t)e->P));
     ALLOC(dmalloc(&rs->raycastImage, (size_t)e->P));
+    // a range image that ONE workgroup builds (expected_depths below) carries its box (env DSR_RAY_BOX=0: full-frame kernels, A/B)
+    if (e->smallVolume && (size_t)mw * mh * sizeof(int2) <= 64 * 1024 && !(getenv("DSR_RAY_BOX") && atoi(getenv("DSR_RAY_BOX")) == 0))
+      ALLOC(dmalloc(&rs->rayBox, (size_t)RB_WORDS));
   }
   ALLOC(dmalloc(&e->live.visibleIDsAlt, (size_t)e->noBlocks));
   ALLOC(dmalloc(&e->live.visBlocksAlt, (size_t)e->noBlocks));
@@ -1238,8 +1250,10 @@ int dsr_prepare(dsr_engine *e) {
   {
     int st = launch_raycast(e, "raycast", p, rs);
     if (st) return st;
-    LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
-           e->normalsMap, rs.raycastImage);
+    if (rs.rayBox) LAUNCH(e, "icp_maps", k_icp_maps_box, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+                          e->normalsMap, rs.raycastImage, (const int32_t *)rs.rayBox);
+    else LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+                e->normalsMap, rs.raycastImage);
   }
   HIP_TRY(hipGetLastError());
   return DSR_OK;
@@ -1350,17 +1364,17 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         {
           ProfScope _ps(e, "small_freeview");
           hipLaunchKernelGGL(k_small_freeview, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene, e->allocList,
-                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax));
+                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox);
         }
         e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
         if (outIsDevice) {
           LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
+                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out, rs.rayBox);
           HIP_TRY(hipGetLastError());
           break;
         }
         LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr, rs.rayBox);
         HIP_TRY(hipGetLastError());
         if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
         if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
@@ -1380,12 +1394,12 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         // the raycast shades its own pixels (k_raycast_render): one launch less in an instance volume's frame
         if (outIsDevice) {
           LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out);
+                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out, rs.rayBox);
           HIP_TRY(hipGetLastError());
           break;
         }
         LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr);
+               rs.raycastResult, type, rs.raycastImage, depth_out ? e->freeDepth : (float *)nullptr, (uchar4 *)nullptr, rs.rayBox);
         HIP_TRY(hipGetLastError());
         if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, rs.raycastImage, P * 4, kind, e->stream));
         if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, e->freeDepth, P * 4, kind, e->stream));
@@ -1541,20 +1555,26 @@ int dsr_clip_depth_mm(int16_t *depth_mm, int n, float max_depth_m) {
 
 // -> device-side address of the staged mask (see the ring's description in dsr_engine); `mask_slot_used` must be called
 // after the kernel that reads it has been enqueued
+// The ring's slots hold at least `n` bytes.  Growing (rare: a mask larger than any before) drains the stream and REPLACES the
+// ring, so a call that stages several masks for one kernel sizes it for the largest of them BEFORE it stages the first — a
+// mask staged earlier would otherwise point into freed pinned memory.
+static int ensure_mask_ring(dsr_engine *e, size_t n) {
+  if (e->maskSlotBytes >= n) return DSR_OK;
+  HIP_TRY(hipStreamSynchronize(vstream(e)));
+  if (e->maskHost) (void)hipHostFree(e->maskHost);
+  e->maskHost = e->maskHostDev = nullptr; e->maskSlotBytes = 0;
+  const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
+  if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+    return fail(DSR_E_NOMEM, "mask staging allocation failed");
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&e->maskHostDev), e->maskHost, 0) != hipSuccess)
+    return fail(DSR_E_DEVICE, "mask staging is not device-visible");
+  e->maskSlotBytes = slot;
+  for (bool &u : e->maskEventUsed) u = false;
+  return DSR_OK;
+}
 static int upload_mask(dsr_engine *e, const uint8_t *mask, int box_w, int box_h, const uint8_t **devOut, int *slotOut) {
   const size_t n = (size_t)box_w * box_h;
-  if (e->maskSlotBytes < n) {  // grow: rare (a mask larger than any before) — drain, then reallocate the ring
-    HIP_TRY(hipStreamSynchronize(vstream(e)));
-    if (e->maskHost) (void)hipHostFree(e->maskHost);
-    e->maskHost = e->maskHostDev = nullptr; e->maskSlotBytes = 0;
-    const size_t slot = ((n + n / 2 + 4095) / 4096) * 4096;
-    if (hipHostMalloc(reinterpret_cast<void **>(&e->maskHost), slot * dsr_engine::kMaskSlots, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
-      return fail(DSR_E_NOMEM, "mask staging allocation failed");
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&e->maskHostDev), e->maskHost, 0) != hipSuccess)
-      return fail(DSR_E_DEVICE, "mask staging is not device-visible");
-    e->maskSlotBytes = slot;
-    for (bool &u : e->maskEventUsed) u = false;
-  }
+  { int st = ensure_mask_ring(e, n); if (st) return st; }
   const int s = e->maskNext;
   e->maskNext = (s + 1) % dsr_engine::kMaskSlots;
   if (!e->maskEvent[s]) HIP_TRY(hipEventCreateWithFlags(&e->maskEvent[s], hipEventDisableTiming));
@@ -1608,6 +1628,10 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
       instance->Wr != main_engine->Wr || instance->Hr != main_engine->Hr || main_engine->W != main_engine->Wr)
     return fail(DSR_E_ARG, "main and instance engines must share the image size");
   int maskSlot = -1, rmaskSlot = -1;
+  if (!maskDev && blank && !rmaskDev) {  // two host masks for one kernel: the ring must hold the larger one before the first is staged
+    int st = ensure_mask_ring(main_engine, std::max((size_t)box_w * box_h, (size_t)rbw * rbh));
+    if (st) return st;
+  }
   if (!maskDev) {
     int st = upload_mask(main_engine, mask, box_w, box_h, &maskDev, &maskSlot);
     if (st) return st;
@@ -1781,8 +1805,7 @@ struct dsr_batch {
   int device = 0;  // (kept apart from `source`: the engines may be gone by the time the batch is destroyed)
   std::vector<dsr_engine *> vols;
   std::vector<BatchVolP> volsHost;
-  BatchVolP *volsDev = nullptr;
-  BatchFrameP *framesDev = nullptr;
+  BatchVolP *volsDev = nullptr;  // (the per-call records travel as kernel arguments: k_batch.h BatchFrames)
 };
 
 static BatchVolP batch_vol_record(dsr_engine *e) {
@@ -1795,6 +1818,7 @@ static BatchVolP batch_vol_record(dsr_engine *e) {
   v.fvVisibleIDs = e->freeview.visibleIDs; v.fvVisBlocks = e->freeview.visBlocks; v.fvMinmax = reinterpret_cast<int2 *>(e->freeview.minmax);
   v.fvRaycastResult = e->freeview.raycastResult; v.fvRaycastImage = e->freeview.raycastImage; v.allocList = e->allocList;
   v.statusDev = e->statusDev;
+  v.rayBox = e->live.rayBox; v.fvRayBox = e->freeview.rayBox;
   v.numTiles = e->numTilesE; v.noBlocks = e->noBlocks; v.gridIntegrate = e->gridIntegrate;
   return v;
 }
@@ -1809,19 +1833,6 @@ static int batch_refresh(dsr_batch *b) {
   }
   return DSR_OK;
 }
-// this call's per-volume records -> the device table, as kernel arguments of k_batch_set
-static int batch_set_frames(dsr_batch *b, const std::vector<BatchFrameP> &f) {
-  dsr_engine *e = b->source;
-  for (int first = 0; first < (int)f.size(); first += kBatchSetChunk) {
-    BatchSet in;
-    memset(&in, 0, sizeof in);
-    const int count = std::min(kBatchSetChunk, (int)f.size() - first);
-    for (int k = 0; k < count; ++k) in.f[k] = f[first + k];
-    LAUNCH(e, "batch_set", k_batch_set, dim3(1), dim3(256), in, b->framesDev, first, count);
-  }
-  return DSR_OK;
-}
-
 int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volumes, dsr_batch **out) {
   CHECK_E(source);
   if (!volumes || n_volumes <= 0 || n_volumes > kBatchMax || !out) return fail(DSR_E_ARG, "a batch holds 1..8 volumes");
@@ -1851,11 +1862,8 @@ int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volum
     b->volsHost.push_back(batch_vol_record(e));
   }
   if (hipMalloc(reinterpret_cast<void **>(&b->volsDev), sizeof(BatchVolP) * kBatchMax) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&b->framesDev), sizeof(BatchFrameP) * kBatchMax) != hipSuccess ||
-      hipMemcpy(b->volsDev, b->volsHost.data(), sizeof(BatchVolP) * b->vols.size(), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(b->framesDev, 0, sizeof(BatchFrameP) * kBatchMax) != hipSuccess) {
+      hipMemcpy(b->volsDev, b->volsHost.data(), sizeof(BatchVolP) * b->vols.size(), hipMemcpyHostToDevice) != hipSuccess) {
     if (b->volsDev) (void)hipFree(b->volsDev);
-    if (b->framesDev) (void)hipFree(b->framesDev);
     delete b;
     return fail(DSR_E_NOMEM, "batch tables");
   }
@@ -1868,7 +1876,6 @@ void dsr_batch_destroy(dsr_batch *b) {
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
   (void)hipFree(b->volsDev);
-  (void)hipFree(b->framesDev);
   delete b;
 }
 
@@ -1891,6 +1898,11 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
       itemOf[it.volume] = i;
     }
     if (it.delete_mask_dev) { if (it.dbox_w <= 0 || it.dbox_h <= 0) return fail(DSR_E_ARG, "bad silhouette arguments"); anyBlank = true; }
+    if (it.volume >= 0) {  // every pose is checked BEFORE anything is queued or any engine's bookkeeping changes
+      Mat4 invM, M;
+      memcpy(invM.m, it.inv_m, sizeof invM.m);
+      if (!m4_inv(invM, M)) return fail(DSR_E_ARG, "singular pose");
+    }
   }
   int st = batch_refresh(b);
   if (st) return st;
@@ -1918,10 +1930,11 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
   HIP_TRY(hipGetLastError());
   if (anyBlank && (st = view_written(src, S))) return st;
   // ---- per volume: pose, this frame's parameters, the bookkeeping of allocate_scene / integrate_scene / dsr_prepare
-  std::vector<BatchFrameP> fr(nv);
+  BatchFrames frames;
+  memset(&frames, 0, sizeof frames);
+  BatchFrameP *fr = frames.f;
   int maxTilesX = 0, maxTilesY = 0, maxGrid = 0, rgbSame = -1, plain = -1;
   for (int v = 0; v < nv; ++v) {
-    memset(&fr[v], 0, sizeof fr[v]);
     if (itemOf[v] < 0) continue;
     dsr_engine *e = b->vols[v];
     const dsr_batch_item &it = items[itemOf[v]];
@@ -1948,22 +1961,21 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
     memcpy(e->liveExp.proj, proj, sizeof proj);
   }
   if (rgbSame < 0) return DSR_OK;  // only blanking in this frame
-  if ((st = batch_set_frames(b, fr))) return st;
   const dim3 img(div_up(src->W, 16), div_up(src->H, 16), nv);
   if (maxTilesX > 0 && maxTilesY > 0)
-    LAUNCH(src, "batch_alloc_mark", k_batch_alloc_mark, dim3(maxTilesX, maxTilesY, nv), dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+    LAUNCH(src, "batch_alloc_mark", k_batch_alloc_mark, dim3(maxTilesX, maxTilesY, nv), dim3(256), frames, (const BatchVolP *)b->volsDev);
   const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
   {
     ProfScope _ps(src, "batch_small_alloc_visible");
-    hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), S, (const BatchFrameP *)b->framesDev,
+    hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), S, frames,
                        (const BatchVolP *)b->volsDev);
   }
-#define BATCH_INTEGRATE(A, B) LAUNCH(src, "batch_integrate", (k_batch_integrate<A, B>), dim3(maxGrid, nv), dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev)
+#define BATCH_INTEGRATE(A, B) LAUNCH(src, "batch_integrate", (k_batch_integrate<A, B>), dim3(maxGrid, nv), dim3(256), frames, (const BatchVolP *)b->volsDev)
   if (rgbSame) { if (plain) BATCH_INTEGRATE(true, true); else BATCH_INTEGRATE(true, false); }
   else { if (plain) BATCH_INTEGRATE(false, true); else BATCH_INTEGRATE(false, false); }
 #undef BATCH_INTEGRATE
-  LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
-  LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+  LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
+  LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
   HIP_TRY(hipGetLastError());
   if (status_out) {
     for (int i = 0; i < n_items; ++i) status_out[i] = DSR_OK;
@@ -1991,8 +2003,9 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
   const int nv = (int)b->vols.size();
   int st = batch_refresh(b);
   if (st) return st;
-  std::vector<BatchFrameP> fr(nv);
-  for (int v = 0; v < nv; ++v) memset(&fr[v], 0, sizeof fr[v]);
+  BatchFrames frames;
+  memset(&frames, 0, sizeof frames);
+  BatchFrameP *fr = frames.f;
   bool any = false;
   for (int i = 0; i < n_items; ++i) {
     const dsr_batch_render_item &it = items[i];
@@ -2011,15 +2024,14 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
     any = true;
   }
   if (!any) return DSR_OK;
-  if ((st = batch_set_frames(b, fr))) return st;
   const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
   {
     ProfScope _ps(src, "batch_small_freeview");
-    hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, (const BatchFrameP *)b->framesDev,
+    hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, frames,
                        (const BatchVolP *)b->volsDev);
   }
   LAUNCH(src, "batch_raycast_render", k_batch_raycast_render, dim3(div_up(src->W, 16), div_up(src->H, 16), nv), dim3(256),
-         (const BatchFrameP *)b->framesDev, (const BatchVolP *)b->volsDev);
+         frames, (const BatchVolP *)b->volsDev);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -2173,6 +2185,15 @@ int dsr_save_scene_to_mesh(dsr_engine *e, const char *path) {
 int dsr_debug_raycast_stats(void *dev_buf) {
   unsigned int *p = (unsigned int *)dev_buf;
   HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_rcStats), &p, sizeof(p)));
+  return DSR_OK;
+}
+#endif
+
+#ifdef DSR_SMALL_CLOCKS
+// measurement builds only (tools/small_kernel_clocks.py): where the one-workgroup kernels stamp their phase clocks
+int dsr_debug_small_clocks(void *dev_buf) {
+  unsigned long long *p = (unsigned long long *)dev_buf;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_smallClk), &p, sizeof(p)));
   return DSR_OK;
 }
 #endif
@@ -2349,6 +2370,10 @@ int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycas
   const int mw = (e->W + 7) / 8, mh = (e->H + 7) / 8;
   if (!which && e->sidePending) { HIP_TRY(hipStreamWaitEvent(e->stream, e->evExpected, 0)); e->sidePending = false; }  // a range image still in flight on the side stream
   if (minmax) HIP_TRY(hipMemcpyAsync(minmax, rs.minmax, (size_t)mw * mh * 8, hipMemcpyDeviceToHost, e->stream));
+  // the far-plane start points of the misses outside the last raycast's box: never read by the path, completed for the dump
+  if (raycast_result && rs.rayBox)
+    hipLaunchKernelGGL(k_raycast_fill_outside, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), 0, e->stream, e->scene,
+                       (const int32_t *)rs.rayBox, rs.raycastResult);
   if (raycast_result) HIP_TRY(hipMemcpyAsync(raycast_result, rs.raycastResult, P * 16, hipMemcpyDeviceToHost, e->stream));
   if (points) HIP_TRY(hipMemcpyAsync(points, e->pointsMap, P * 16, hipMemcpyDeviceToHost, e->stream));
   if (normals) HIP_TRY(hipMemcpyAsync(normals, e->normalsMap, P * 16, hipMemcpyDeviceToHost, e->stream));

@@ -155,6 +155,12 @@ extern "C" {
 
 // ---- instance compositing
 
+// pixels per lane of k_composite (k_composite.h): 4; env DSR_COMPOSITE_PX=2 for the A/B (tools/bench_composite.py)
+static int composite_px_per_lane() {
+  static const int px = (getenv("DSR_COMPOSITE_PX") && atoi(getenv("DSR_COMPOSITE_PX")) == 2) ? 2 : 4;
+  return px;
+}
+
 int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
                                 const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
                                 int n_layers, int n_pixels, float tint_strength, int dim_background) {
@@ -166,9 +172,14 @@ int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_
   const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
   CompositeLayers none;
   memset(&none, 0, sizeof none);
-  hipLaunchKernelGGL(k_composite<false>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
-                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
-                     (const float *)layers_depth_dev, none);
+  if (composite_px_per_lane() == 2)
+    hipLaunchKernelGGL((k_composite<false, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
+                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
+                       (const float *)layers_depth_dev, none);
+  else
+    hipLaunchKernelGGL((k_composite<false, 4>), dim3((n_pixels + 1023) / 1024), dim3(256), 0, (hipStream_t)hip_stream, c,
+                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
+                       (const float *)layers_depth_dev, none);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -190,8 +201,12 @@ int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba
   }
   if (device >= 0) HIP_TRY(hipSetDevice(device));
   const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
-  hipLaunchKernelGGL(k_composite<true>, dim3((n_pixels + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, c,
-                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
+  if (composite_px_per_lane() == 2)
+    hipLaunchKernelGGL((k_composite<true, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
+                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
+  else
+    hipLaunchKernelGGL((k_composite<true, 4>), dim3((n_pixels + 1023) / 1024), dim3(256), 0, (hipStream_t)hip_stream, c,
+                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -389,7 +404,13 @@ int dsr_exchange_gather(dsr_exchange *x) {
   int prev = 0;
   (void)hipGetDevice(&prev);
   for (size_t k = 0; k < x->devs.size(); ++k) { (void)hipSetDevice(x->devs[k].device); timed_begin(x, x->devs[k], 0, k); }
-  RCCL_TRY(api, api->GroupStart());
+  {
+    const ncclResult_t r0 = api->GroupStart();
+    if (r0 != ncclSuccess) {  // (the caller's device comes back also on this path: ADVICE r5)
+      (void)hipSetDevice(prev);
+      return fail(DSR_E_DEVICE, std::string("ncclGroupStart: ") + api->GetErrorString(r0));
+    }
+  }
   ncclResult_t r = ncclSuccess;
   for (auto &d : x->devs) {
     if (hipSetDevice(d.device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
@@ -461,6 +482,9 @@ int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_en
   dsr_exchange::Dev *d = local_dev(x, root_rank);
   if (!d || n_layers < 0 || (n_layers > 0 && (!ranks || !slots || !track_ids))) return fail(DSR_E_ARG, "bad composite arguments");
   if (n_layers > kMaxCompositeLayers) return fail(DSR_E_ARG, "too many layers (max 64)");
+  // gather-to-root delivers the layers to ONE group's buffer: a composite anywhere else would blend stale layers
+  if (x->useRccl && x->gatherToRoot && x->groupOfRank[root_rank] != x->rootGroup)
+    return fail(DSR_E_ARG, "the exchange gathers to another root (dsr_exchange_set_collective): this rank does not receive the layers");
   int st = DSR_OK;
   if (!target_depth_dev) {
     if ((st = exchange_target(x, d))) return st;

@@ -49,6 +49,9 @@ struct RenderStateDev {  // ITMRenderState_VH
   float2 *minmax = nullptr;
   float4 *raycastResult = nullptr;
   uchar4 *raycastImage = nullptr;
+  // instance-sized volumes: the box record of the range image (k_raycast.h RB_*) — the pixel kernels behind the range image skip
+  // the tiles outside it; null for a map-sized volume (full-frame kernels)
+  int32_t *rayBox = nullptr;
   int ctrIdx = CTR_NO_VISIBLE_LIVE;
 };
 

@@ -5,8 +5,9 @@
 // loop (InstanceReconstructor.cpp:315-361), and round 4's eight streams — pay N chains of dependent launches; kernels of
 // different streams overlap little (round 4: 8 x 21 launches in 1.27 ms, ~7 us per launch whichever queue it sits in).  Here the
 // volume is a grid dimension: blockIdx.z (or .x for the one-workgroup kernels) selects the volume, its parameters come from two
-// small device tables (BatchVolP: pointers, constant; BatchFrameP: this call's camera, written by k_batch_set from kernel
-// arguments), and the kernel BODIES are the per-volume functions of the other headers — alloc_mark_pixel,
+// small tables (BatchVolP: pointers, constant, in HBM; BatchFrameP: this call's cameras — since round 6 the whole table travels
+// as a KERNEL ARGUMENT of every launch, 2.8 KB, instead of through a device copy that two k_batch_set launches per call had to
+// write first), and the kernel BODIES are the per-volume functions of the other headers — alloc_mark_pixel,
 // small_alloc_visible_body, integrate_body, cast_ray, icp_pixel, small_freeview_body, render_pixel — so every volume's
 // arithmetic, and every digest, is what the per-volume launches give (tests/test_gpu_batch.py).
 #pragma once
@@ -16,7 +17,6 @@
 namespace dsr {
 
 constexpr int kBatchMax = 8;       // volumes per launch (a larger scene runs several batches)
-constexpr int kBatchSetChunk = 4;  // BatchFrameP records per k_batch_set launch (kernel arguments: 4 x ~350 B)
 
 struct BatchVolP {  // one volume: what does not change from call to call
   SceneP s;
@@ -38,6 +38,7 @@ struct BatchVolP {  // one volume: what does not change from call to call
   uchar4 *fvRaycastImage;
   int32_t *allocList;  // free-view render state + the staging list of k_small_freeview
   int32_t *statusDev;
+  int32_t *rayBox, *fvRayBox;  // the range images' box records (k_raycast.h RB_*)
   int numTiles, noBlocks, gridIntegrate, pad;
 };
 
@@ -52,14 +53,8 @@ struct BatchFrameP {  // one volume, this call
   float *outDepth;    // render: the caller's HBM buffers (an exchange slot)
 };
 
-struct BatchSet { BatchFrameP f[kBatchSetChunk]; };
-// (the records travel as kernel arguments and are stored by a handful of lanes: no copy command, no pinned staging)
-__global__ __launch_bounds__(256) void k_batch_set(BatchSet in, BatchFrameP *__restrict__ table, int first, int count) {
-  constexpr int kWords = (int)(sizeof(BatchFrameP) / 4);
-  const uint32_t *src = reinterpret_cast<const uint32_t *>(&in);
-  uint32_t *dst = reinterpret_cast<uint32_t *>(table + first);
-  for (int i = threadIdx.x; i < count * kWords; i += blockDim.x) dst[i] = src[i];
-}
+struct BatchFrames { BatchFrameP f[kBatchMax]; };
+static_assert(sizeof(BatchFrames) <= 3584, "the per-call table must fit the kernel argument segment (4 KB) next to the other arguments");
 
 // ---- the view split of up to kBatchMax instances in one pass over the frame: item after item in the host's order, each cut-out
 // sees the blanking of the items before it — exactly what the calls one after the other produce (masks may overlap)
@@ -102,8 +97,8 @@ __global__ __launch_bounds__(256) void k_batch_split(uchar4 *srcRgb, float *srcD
 }
 
 // ---- fusion + tracking render of every active volume
-__global__ __launch_bounds__(256) void k_batch_alloc_mark(const BatchFrameP *__restrict__ frames, const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.z];
+__global__ __launch_bounds__(256) void k_batch_alloc_mark(const BatchFrames frames, const BatchVolP *__restrict__ vols) {
+  const BatchFrameP &f = frames.f[blockIdx.z];
   if (!f.active || (int)blockIdx.x >= f.tilesX || (int)blockIdx.y >= f.tilesY) return;
   const BatchVolP &v = vols[blockIdx.z];
   const int x = ((int)blockIdx.x + f.tileX0) * 16 + (threadIdx.x & 15), y = ((int)blockIdx.y + f.tileY0) * 16 + (threadIdx.x >> 4);
@@ -111,29 +106,33 @@ __global__ __launch_bounds__(256) void k_batch_alloc_mark(const BatchFrameP *__r
   alloc_mark_pixel<true>(f.p, v.s, v.depth, v.visType, x, y);
 }
 
-__global__ __launch_bounds__(kSmallThreads) void k_batch_small_alloc_visible(const BatchFrameP *__restrict__ frames,
+__global__ __launch_bounds__(kSmallThreads) void k_batch_small_alloc_visible(const BatchFrames frames,
                                                                              const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.x];
+  const BatchFrameP &f = frames.f[blockIdx.x];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.x];
   small_alloc_visible_body(f.p, v.s, v.depth, v.visType, v.numTiles, v.workList, v.visibleIDs, v.visBlocks, v.noBlocks, v.statusDev,
-                           f.publishSeq, v.minmax);
+                           f.publishSeq, v.minmax, v.rayBox);
 }
 
 template <bool RGB_SAME, bool PLAIN>
-__global__ __launch_bounds__(64 * kIntegrateWaves, 7) void k_batch_integrate(const BatchFrameP *__restrict__ frames,
+__global__ __launch_bounds__(64 * kIntegrateWaves, 7) void k_batch_integrate(const BatchFrames frames,
                                                                              const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.y];
+  const BatchFrameP &f = frames.f[blockIdx.y];
   const BatchVolP &v = vols[blockIdx.y];
   if (!f.active || (int)blockIdx.x >= v.gridIntegrate) return;
   integrate_body<RGB_SAME, PLAIN, 8, true>(f.p, v.s, v.depth, v.rgb, v.visBlocks, v.integrateStats, (int)blockIdx.x, v.gridIntegrate);
 }
 
-__global__ __launch_bounds__(256, 8) void k_batch_raycast(const BatchFrameP *__restrict__ frames, const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.z];
+__global__ __launch_bounds__(256, 8) void k_batch_raycast(const BatchFrames frames, const BatchVolP *__restrict__ vols) {
+  const BatchFrameP &f = frames.f[blockIdx.z];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.z];
   if (v.s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;  // Prepare() is skipped without visible blocks
+  if (v.rayBox) {  // (null only under DSR_RAY_BOX=0: the A/B against full-frame kernels)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(v.rayBox, f.p);
+    if (!raybox_tile(v.rayBox, RB_DIRTY, blockIdx.x, blockIdx.y)) return;  // the tile keeps its miss (k_raycast.h RB_*)
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
@@ -144,11 +143,11 @@ __global__ __launch_bounds__(256, 8) void k_batch_raycast(const BatchFrameP *__r
   v.raycastResult[x + y * f.p.W] = cast_ray<DeviceOps>(f.p, v.s, x, y, mm RC_STAT(, st));
 }
 
-__global__ __launch_bounds__(256) void k_batch_icp_maps(const BatchFrameP *__restrict__ frames, const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.z];
+__global__ __launch_bounds__(256) void k_batch_icp_maps(const BatchFrames frames, const BatchVolP *__restrict__ vols) {
+  const BatchFrameP &f = frames.f[blockIdx.z];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.z];
-  if (v.s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;
+  if (v.s.ctr[CTR_NO_VISIBLE_LIVE] <= 0 || (v.rayBox && !raybox_tile(v.rayBox, RB_DIRTY, blockIdx.x, blockIdx.y))) return;
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= f.p.W || y >= f.p.H) return;
   float4 point, normal;
@@ -161,22 +160,29 @@ __global__ __launch_bounds__(256) void k_batch_icp_maps(const BatchFrameP *__res
 }
 
 // ---- the preview: free-view list + range image, then the raycast that shades its own pixels, of every active volume
-__global__ __launch_bounds__(kSmallThreads) void k_batch_small_freeview(const BatchFrameP *__restrict__ frames,
+__global__ __launch_bounds__(kSmallThreads) void k_batch_small_freeview(const BatchFrames frames,
                                                                         const BatchVolP *__restrict__ vols) {
-  const BatchFrameP &f = frames[blockIdx.x];
+  const BatchFrameP &f = frames.f[blockIdx.x];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.x];
-  small_freeview_body(f.p, v.s, v.allocList, v.fvVisibleIDs, v.fvVisBlocks, v.noBlocks, v.fvMinmax);
+  small_freeview_body(f.p, v.s, v.allocList, v.fvVisibleIDs, v.fvVisBlocks, v.noBlocks, v.fvMinmax, v.fvRayBox);
 }
 
-__global__ __launch_bounds__(256) void k_batch_raycast_render(const BatchFrameP *__restrict__ frames, const BatchVolP *__restrict__ vols) {
+__global__ __launch_bounds__(256) void k_batch_raycast_render(const BatchFrames frames, const BatchVolP *__restrict__ vols) {
   __shared__ int s_blocks[256][9];
-  const BatchFrameP &f = frames[blockIdx.z];
+  const BatchFrameP &f = frames.f[blockIdx.z];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.z];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (v.fvRayBox && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(v.fvRayBox, f.p);
+  if (v.fvRayBox && !raybox_tile(v.fvRayBox, RB_DIRTY, blockIdx.x, blockIdx.y)) {  // the caller's buffers get the miss, ours keep it
+    if (x >= f.p.W || y >= f.p.H) return;
+    if (f.outRgba) f.outRgba[x + y * f.p.W] = make_uchar4(0, 0, 0, 0);
+    if (f.outDepth) f.outDepth[x + y * f.p.W] = 0.0f;
+    return;
+  }
   if (x >= f.p.W || y >= f.p.H) return;
   const int mw = (f.p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const float2 mm = reinterpret_cast<const float2 *>(v.fvMinmax)[(x >> 3) + (y >> 3) * mw];

@@ -338,6 +338,84 @@ __device__ __forceinline__ void fold_wave_boxes(int2 *cellsLds, int mw, bool val
   }
 }
 
+// ---- the BOX of the range image (instance-sized volumes, round 6) -----------------------------------------------------------
+// An instance volume covers a few per cent of the frame: its range image is empty outside the bounding box of a few hundred
+// projected blocks, and a ray through an empty cell is a miss before its first step.  The full-frame kernels behind the range
+// image — raycast, ICP maps, the free-view raycast + shading — spent their time writing that miss into 465 k pixels per volume
+// (k_batch_icp_maps: 194 MB per launch for eight volumes; profiles/r05z_batch_kernel_stats.json).  The one-workgroup kernel that
+// builds the image (k_small.h, k_expected_depth_one) now also keeps, per render state, a small device record `rb`:
+//   CUR    box of the non-empty cells of the current image (cell units, end exclusive; empty: x0 >= x1)
+//   DIRTY  the cells whose pixels may hold anything but a miss, or must be recomputed: what the next raycast has to cover
+//   RAN    a raycast has consumed DIRTY since it was last extended
+//   LAST   the DIRTY box of the last raycast that ran, EVER: one has run, POSE: its FrameP
+// and the pixel kernels skip every 16x16 tile outside DIRTY.  Invariant: outside DIRTY every pixel of raycastResult has w == 0,
+// the ICP maps hold their miss constants and the images are 0 — which is all their consumers ever look at (icp_pixel,
+// render_pixel, render_depth test w first).  The xyz of a miss (the ray's far-plane start point: pose dependent, never read by
+// the path) goes stale outside DIRTY; dsr_dump_render_state — the parity tests' view of the buffer — completes it with
+// k_raycast_fill_outside from LAST + POSE, so a dump equals the serial engine's buffer bit for bit as before.
+// After creation / a reset DIRTY is the whole image: the first raycast is a full-frame one.
+constexpr int RB_CUR = 0, RB_DIRTY = 4, RB_RAN = 8, RB_LAST = 9, RB_EVER = 13, RB_POSE = 16, RB_WORDS = 128;
+static_assert(RB_POSE * 4 + sizeof(FrameP) <= RB_WORDS * 4, "the pose record must fit");
+static_assert(sizeof(FrameP) % 4 == 0, "FrameP is copied word by word");
+
+__global__ void k_raybox_reset(int32_t *rb, int mw, int mh) {
+  if (threadIdx.x < RB_WORDS) rb[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) { rb[RB_DIRTY + 2] = mw; rb[RB_DIRTY + 3] = mh; }
+}
+
+// All threads of the ONE workgroup that holds the finished range image in LDS: store it, find the box of its non-empty cells,
+// update the record.  boxLds: 4 ints of LDS set to {INT_MAX, INT_MAX, -1, -1} before the barrier that precedes this call.
+__device__ __forceinline__ void store_range_image(const int2 *cells, int2 *__restrict__ minmax, int nCells, int mw,
+                                                  int32_t *__restrict__ rb, int *boxLds) {
+  const int farBits = __float_as_int(kFarAway);
+  int x0 = 0x7fffffff, y0 = 0x7fffffff, x1 = -1, y1 = -1;
+  for (int c = threadIdx.x; c < nCells; c += blockDim.x) {
+    const int2 v = cells[c];
+    minmax[c] = v;
+    if (v.x != farBits) {  // a block was folded into this cell (every z is below FAR_AWAY)
+      const int cy = c / mw, cx = c - cy * mw;
+      x0 = cx < x0 ? cx : x0; y0 = cy < y0 ? cy : y0; x1 = cx > x1 ? cx : x1; y1 = cy > y1 ? cy : y1;
+    }
+  }
+  if (!rb) return;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int a = __shfl_xor(x0, d), b = __shfl_xor(y0, d), c = __shfl_xor(x1, d), e = __shfl_xor(y1, d);
+    x0 = a < x0 ? a : x0; y0 = b < y0 ? b : y0; x1 = c > x1 ? c : x1; y1 = e > y1 ? e : y1;
+  }
+  if ((threadIdx.x & 63) == 0 && x1 >= 0) {
+    atomicMin(&boxLds[0], x0); atomicMin(&boxLds[1], y0); atomicMax(&boxLds[2], x1); atomicMax(&boxLds[3], y1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int n0 = 0, n1 = 0, n2 = 0, n3 = 0;  // the new box; empty: all zero
+    if (boxLds[2] >= 0) { n0 = boxLds[0]; n1 = boxLds[1]; n2 = boxLds[2] + 1; n3 = boxLds[3] + 1; }
+    // what may hold hits: the box of the image the last raycast saw (if one ran since), else everything still pending
+    const int b = rb[RB_RAN] ? RB_CUR : RB_DIRTY;
+    int d0 = rb[b], d1 = rb[b + 1], d2 = rb[b + 2], d3 = rb[b + 3];
+    if (d0 >= d2 || d1 >= d3) { d0 = n0; d1 = n1; d2 = n2; d3 = n3; }
+    else if (n0 < n2 && n1 < n3) { d0 = n0 < d0 ? n0 : d0; d1 = n1 < d1 ? n1 : d1; d2 = n2 > d2 ? n2 : d2; d3 = n3 > d3 ? n3 : d3; }
+    rb[RB_DIRTY] = d0; rb[RB_DIRTY + 1] = d1; rb[RB_DIRTY + 2] = d2; rb[RB_DIRTY + 3] = d3;
+    rb[RB_CUR] = n0; rb[RB_CUR + 1] = n1; rb[RB_CUR + 2] = n2; rb[RB_CUR + 3] = n3;
+    rb[RB_RAN] = 0;
+  }
+}
+
+// does the 16x16 pixel tile (wgx, wgy) — cells [2 wgx, 2 wgx + 2) x [2 wgy, 2 wgy + 2) — touch the box at rb[which]?
+__device__ __forceinline__ bool raybox_tile(const int32_t *__restrict__ rb, int which, int wgx, int wgy) {
+  const int x0 = rb[which], y0 = rb[which + 1], x1 = rb[which + 2], y1 = rb[which + 3];
+  return 2 * wgx < x1 && 2 * wgx + 2 > x0 && 2 * wgy < y1 && 2 * wgy + 2 > y0;
+}
+// the raycast that runs records it (one thread of its first workgroup; nobody reads these words before the next launch)
+__device__ __forceinline__ void raybox_mark_ran(int32_t *__restrict__ rb, const FrameP &p) {
+  rb[RB_RAN] = 1; rb[RB_EVER] = 1;
+  rb[RB_LAST] = rb[RB_DIRTY]; rb[RB_LAST + 1] = rb[RB_DIRTY + 1]; rb[RB_LAST + 2] = rb[RB_DIRTY + 2]; rb[RB_LAST + 3] = rb[RB_DIRTY + 3];
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(FrameP) / 4); ++i) reinterpret_cast<uint32_t *>(rb + RB_POSE)[i] = src[i];
+}
+
 // K6 for SMALL volumes (an instance volume: a few hundred visible blocks): ONE workgroup owns the whole range image —
 // initialise it in LDS, fold every visible block, store every cell.  No global atomics, no separate initialisation
 // launch (k_minmax_init), no 128 workgroups that each clear and flush a 58 KB image for nothing: on an instance volume
@@ -345,11 +423,15 @@ __device__ __forceinline__ void fold_wave_boxes(int2 *cellsLds, int mw, bool val
 // independent: the image is the one the other two kernels give.  `keepIfEmpty`: the live view's Prepare() is skipped
 // without visible blocks (the image keeps its previous contents).
 __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s, const int4 *__restrict__ visBlocks, int ctrIdx,
-                                                             int2 *__restrict__ minmax, int keepIfEmpty) {
+                                                             int2 *__restrict__ minmax, int keepIfEmpty, int32_t *__restrict__ rb) {
   extern __shared__ int2 cellsLds[];
+  __shared__ int boxLds[4];
   const int n = s.ctr[ctrIdx];
   if (n <= 0 && keepIfEmpty) return;
-  if (threadIdx.x == 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+  if (threadIdx.x == 0) {
+    atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
+    boxLds[0] = boxLds[1] = 0x7fffffff; boxLds[2] = boxLds[3] = -1;
+  }
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const int nCells = mw * mh;
   const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
@@ -368,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_expected_depth_one(FrameP p, SceneP s,
     fold_wave_boxes(cellsLds, mw, valid, ul, lr, zr, lane);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < nCells; c += blockDim.x) minmax[c] = cellsLds[c];
+  store_range_image(cellsLds, minmax, nCells, mw, rb, boxLds);
 }
 
 // ----------------------------------------------------------------- K7: raycast
@@ -599,6 +681,35 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
 #endif
 }
 
+// k_raycast for a volume whose range image carries a box (see RB_*): tiles outside DIRTY keep their miss
+__global__ __launch_bounds__(256, 8) void k_raycast_box(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
+                                                        float4 *__restrict__ raycastResult, int32_t *__restrict__ rb) {
+  if (s.ctr[ctrIdx] <= 0 && ctrIdx == CTR_NO_VISIBLE_LIVE) return;  // Prepare() is skipped without visible blocks
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
+  if (!raybox_tile(rb, RB_DIRTY, blockIdx.x, blockIdx.y)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= p.W || y >= p.H) return;
+  const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
+  const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];
+  RC_STAT(RcStats st;)
+  raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm RC_STAT(, st));
+}
+
+// dsr_dump_render_state: the miss pixels outside the last raycast's box get the value that raycast would have written — the
+// start point of a ray through an empty cell, for the pose it ran with (rb's POSE record); pixels inside are left alone
+__global__ __launch_bounds__(256) void k_raycast_fill_outside(SceneP s, const int32_t *__restrict__ rb, float4 *__restrict__ raycastResult) {
+  if (!rb[RB_EVER] || raybox_tile(rb, RB_LAST, blockIdx.x, blockIdx.y)) return;
+  const FrameP &p = *reinterpret_cast<const FrameP *>(rb + RB_POSE);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= p.W || y >= p.H) return;
+  RC_STAT(RcStats st;)
+  raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, make_float2(kFarAway, kVeryClose) RC_STAT(, st));
+}
+
 // ---------------------------------------------------------------- K8: ICP maps
 
 template <class Ops>
@@ -667,6 +778,21 @@ __global__ __launch_bounds__(256) void k_icp_maps(FrameP p, SceneP s, const floa
                                                   float4 *__restrict__ pointsMap, float4 *__restrict__ normalsMap,
                                                   uchar4 *__restrict__ outRendering) {
   if (s.ctr[CTR_NO_VISIBLE_LIVE] <= 0) return;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= p.W || y >= p.H) return;
+  float4 point, normal;
+  uchar4 grey;
+  icp_pixel<DeviceOps>(p, pointsRay, x, y, point, normal, grey);
+  const int locId = x + y * p.W;
+  outRendering[locId] = grey;
+  pointsMap[locId] = point;
+  normalsMap[locId] = normal;
+}
+// ... for a volume whose range image carries a box: outside DIRTY the maps already hold the miss constants
+__global__ __launch_bounds__(256) void k_icp_maps_box(FrameP p, SceneP s, const float4 *__restrict__ pointsRay,
+                                                      float4 *__restrict__ pointsMap, float4 *__restrict__ normalsMap,
+                                                      uchar4 *__restrict__ outRendering, const int32_t *__restrict__ rb) {
+  if (s.ctr[CTR_NO_VISIBLE_LIVE] <= 0 || !raybox_tile(rb, RB_DIRTY, blockIdx.x, blockIdx.y)) return;
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= p.W || y >= p.H) return;
   float4 point, normal;
@@ -886,13 +1012,25 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
 // ray.  The ray is k_raycast's plain path (same functions, same result, still written to raycastResult for later renders of
 // the same pose), the shading is k_render's.  Measured on an instance volume (profiles/r04i_instance_frame_fold_fuse_ab.log):
 // 34.4 + 12.2 us as two launches, 38.1 us as one.
+// rb (may be null): the range image's box record — outside DIRTY the engine's own buffers (raycastResult, outRgba) keep their
+// miss, the CALLER's buffers (outDepth, outRgba2) get it written.
 __global__ __launch_bounds__(256) void k_raycast_render(FrameP p, SceneP s, const float2 *__restrict__ minmax,
                                                         float4 *__restrict__ raycastResult, int type, uchar4 *__restrict__ outRgba,
-                                                        float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2) {
+                                                        float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2,
+                                                        int32_t *__restrict__ rb) {
   __shared__ int s_blocks[256][9];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
   const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (rb) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
+    if (!raybox_tile(rb, RB_DIRTY, blockIdx.x, blockIdx.y)) {
+      if (x >= p.W || y >= p.H) return;
+      if (outRgba2) outRgba2[x + y * p.W] = make_uchar4(0, 0, 0, 0);
+      if (outDepth) outDepth[x + y * p.W] = 0.0f;
+      return;
+    }
+  }
   if (x >= p.W || y >= p.H) return;
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];

@@ -21,6 +21,15 @@
 
 namespace dsr {
 
+// -DDSR_SMALL_CLOCKS (tools/small_kernel_clocks.py, never the product build): thread 0 stamps the 100 MHz clock at the phase
+// boundaries of the two one-workgroup kernels (slots 0..15: alloc_visible, 16..31: freeview; slot 15 / 31 counts launches)
+#ifdef DSR_SMALL_CLOCKS
+__device__ unsigned long long *g_smallClk;
+#define SMALL_CLK(i) do { if (threadIdx.x == 0) g_smallClk[(i)] = wall_clock64(); } while (0)
+#else
+#define SMALL_CLK(i)
+#endif
+
 constexpr int kSmallThreads = 1024;
 constexpr int kSmallWaves = kSmallThreads / 64;
 constexpr int kSmallRows = 9;                                              // 16-byte loads per lane in a sweep of a bit plane
@@ -31,7 +40,8 @@ constexpr int kSmallMaxTiles = kSmallThreads;                              // on
 struct SmallShared {  // head of the dynamic LDS; the range image follows
   int2 scan[kSmallWaves];
   int waveTotal[kSmallWaves];
-  int oldV, oldE, nPrev, overflowPrev, nVisible, pad0, pad1, pad2;
+  int oldV, oldE, nPrev, overflowPrev;
+  int box[4];  // store_range_image (k_raycast.h): the box of the image's non-empty cells
 };
 static_assert(sizeof(SmallShared) % sizeof(int2) == 0, "the range image behind it is an int2 array");
 constexpr size_t small_lds_bytes(int nCells) { return sizeof(SmallShared) + (size_t)nCells * sizeof(int2); }
@@ -116,7 +126,7 @@ __device__ __forceinline__ int small_sweep_bits(uint32_t *plane, int32_t *ids, i
 __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
                                                          uint8_t *visType, int numTiles, int4 *workList, int32_t *visibleIDs,
                                                          int4 *visBlocks, int capacity, int32_t *__restrict__ publish,
-                                                         int publishSeq, int2 *__restrict__ minmax) {
+                                                         int publishSeq, int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -124,10 +134,12 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const int nCells = mw * mh;
   const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
+  SMALL_CLK(0);
   for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
   if (tid == 0) {
     sh.oldV = s.ctr[CTR_LAST_FREE_BLOCK]; sh.oldE = s.ctr[CTR_LAST_FREE_EXCESS];
     sh.nPrev = s.ctr[CTR_NO_VISIBLE_LIVE]; sh.overflowPrev = s.ctr[CTR_VIS_OVERFLOW];
+    sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1;
   }
   // ---- A
   int2 *allocTile = reinterpret_cast<int2 *>(s.allocTile);
@@ -144,6 +156,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     ctr[CTR_LAST_FREE_EXCESS] = ne < -1 ? -1 : ne;
     if (total.x > oldV + 1 || total.y > oldE + 1) ctr[CTR_STATUS] = DSR_E_OUT_OF_BLOCKS;
   }
+  SMALL_CLK(1);
   // ---- B: the tile's 64 group words (a byte per 8 entries) in four rounds of four 16-byte loads
   if (tv.x != 0) {
     allocTile[tid] = make_int2(0, 0);  // k_alloc_mark accumulates into it again
@@ -205,6 +218,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
       for (int r = 0; r < 4; ++r) grp4[q * 4 + r] = make_uint4(0u, 0u, 0u, 0u);  // ready for the next frame
     }
   }
+  SMALL_CLK(2);
   // ---- D0: the groups of 8 entries the mark touched (a byte each in visGrp, 147 KB, nine 16-byte loads per lane as in the
   // bit sweep): the types that carry kTouchedNow become bits of visBits — the group's 8 bits are ONE byte of that plane, nobody
   // else writes it before the barrier, so a plain byte store does — and go back to the plain type 1.  A lane rarely owns more than
@@ -256,12 +270,14 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     }
   }
   __syncthreads();
+  SMALL_CLK(3);
   // ---- C
   {
     const int avail = oldV + 1;
     const int n = total.x < avail ? total.x : avail;
     for (int i = tid; i < n; i += kSmallThreads) alloc_apply_item<true>(p, s, depth, workList[i], visType);
   }
+  SMALL_CLK(4);
   // ---- D (independent of C: an entry C creates was not visible before, an entry the mark touched is skipped)
   const int nPrev = sh.nPrev;
   for (int i = tid; i < nPrev; i += kSmallThreads) {
@@ -274,6 +290,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     visType[t] = isVisible ? 3 : 0;
     if (isVisible) atomicOr(&s.visBits[t >> 5], m);
   }
+  SMALL_CLK(5);
   // ---- E
   if (sh.overflowPrev) {
     __syncthreads();
@@ -306,6 +323,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     for (int t = (n16 << 4) + tid; t < p.noTotalEntries; t += kSmallThreads) leftover(t, visType[t]);
   }
   __syncthreads();
+  SMALL_CLK(6);
   // ---- F
   const int totalVisible = small_sweep_bits<true>(s.visBits, visibleIDs, capacity, sh);
   const int n = totalVisible < capacity ? totalVisible : capacity;
@@ -322,6 +340,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     if (n > 0) atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
   }
   __syncthreads();
+  SMALL_CLK(7);
   // ---- G
   for (int base = tid & ~63; base < n; base += kSmallThreads) {  // wave-uniform trip count
     const int i = base + lane;
@@ -340,21 +359,24 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   }
   if (n <= 0) return;  // Prepare() is skipped without visible blocks: the image keeps its previous contents
   __syncthreads();
-  for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
+  SMALL_CLK(8);
+  store_range_image(cells, minmax, nCells, mw, rb, sh.box);
+  SMALL_CLK(9);
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p, SceneP s, const float *__restrict__ depth,
                                                                        uint8_t *visType, int numTiles, int4 *workList,
                                                                        int32_t *visibleIDs, int4 *visBlocks, int capacity,
                                                                        int32_t *__restrict__ publish, int publishSeq,
-                                                                       int2 *__restrict__ minmax) {
-  small_alloc_visible_body(p, s, depth, visType, numTiles, workList, visibleIDs, visBlocks, capacity, publish, publishSeq, minmax);
+                                                                       int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
+  small_alloc_visible_body(p, s, depth, visType, numTiles, workList, visibleIDs, visBlocks, capacity, publish, publishSeq, minmax, rb);
 }
 
 // FindVisibleBlocks + CreateExpectedDepths of a free camera for an instance-sized volume: the allocated entries come from
 // allocBits (ascending), are tested against the frustum densely, compacted in order; the range image is folded on the way.
 __device__ __forceinline__ void small_freeview_body(const FrameP &p, const SceneP &s, int32_t *stage, int32_t *__restrict__ visibleIDs,
-                                                    int4 *__restrict__ visBlocks, int capacity, int2 *__restrict__ minmax) {
+                                                    int4 *__restrict__ visBlocks, int capacity, int2 *__restrict__ minmax,
+                                                    int32_t *__restrict__ rb) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -362,10 +384,13 @@ __device__ __forceinline__ void small_freeview_body(const FrameP &p, const Scene
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample, mh = (p.H + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const int nCells = mw * mh;
   const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
+  SMALL_CLK(16);
   for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
+  if (tid == 0) { sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1; }
   const int totalAlloc = small_sweep_bits<false>(s.allocBits, stage, capacity, sh);  // (its barriers publish the image's reset)
   const int nAlloc = totalAlloc < capacity ? totalAlloc : capacity;
   __syncthreads();  // the ids
+  SMALL_CLK(17);
   int carry = 0;
   for (int base = 0; base < nAlloc; base += kSmallThreads) {  // uniform trip count
     const int i = base + tid;
@@ -398,18 +423,21 @@ __device__ __forceinline__ void small_freeview_body(const FrameP &p, const Scene
     fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
     carry += tot.x;
   }
+  SMALL_CLK(18);
   if (tid == 0) {
     const int n = carry < capacity ? carry : capacity;
     s.ctr[CTR_NO_VISIBLE_FREE] = n;
     atomicAdd(&s.work[WORK_V_EXPECTED], (unsigned long long)n);
   }
   __syncthreads();
-  for (int c = tid; c < nCells; c += kSmallThreads) minmax[c] = cells[c];
+  SMALL_CLK(19);
+  store_range_image(cells, minmax, nCells, mw, rb, sh.box);
+  SMALL_CLK(20);
 }
 __global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, SceneP s, int32_t *stage, int32_t *__restrict__ visibleIDs,
                                                                   int4 *__restrict__ visBlocks, int capacity,
-                                                                  int2 *__restrict__ minmax) {
-  small_freeview_body(p, s, stage, visibleIDs, visBlocks, capacity, minmax);
+                                                                  int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
+  small_freeview_body(p, s, stage, visibleIDs, visBlocks, capacity, minmax, rb);
 }
 
 }  // namespace dsr

@@ -18,7 +18,18 @@ torch is plumbing here (process group, device buffers); the arithmetic is the HI
 """
 import ctypes as C
 
+import sys
+
 import numpy as np
+
+_logged = set()
+
+
+def _log_once(key, msg):
+    """A silent fall-back hides a performance regression: say it, once per process, on stderr."""
+    if key not in _logged:
+        _logged.add(key)
+        print(msg, file=sys.stderr)
 
 
 def torch_empty_like_cpu(t):
@@ -266,8 +277,9 @@ class ShardedScene:
         if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1:
             try:
                 next(iter(self.instances.values())).share_stream(self.source)
-            except DsrError:  # engines with a view pipeline of their own (created for a host that waits on them): as they are
-                pass
+            except DsrError as ex:  # engines with a view pipeline of their own (created for a host that waits on them): as they are
+                _log_once("share_stream", f"ShardedScene: the instance volume keeps a stream of its own ({ex}); create the engines "
+                                          "with view_pipeline=VIEW_PIPELINE_OFF to queue the pair on one stream")
         # several instance volumes on this GPU: driven as ONE batch — every kernel of an instance frame launched once for all of
         # them (dsr_batch_*; results identical to the per-volume calls).  Up to 8 per batch; a rank with more keeps the loop.
         self.batch, self.batch_index = None, {}
@@ -277,8 +289,10 @@ class ShardedScene:
             try:
                 self.batch = Batch(self.source, [self.instances[k] for k in order])
                 self.batch_index = {k: i for i, k in enumerate(order)}
-            except DsrError:  # not batchable (pipelined views, other table sizes): the per-volume loop
+            except DsrError as ex:  # not batchable (pipelined views, other table sizes): the per-volume loop
                 self.batch = None
+                _log_once("batch", f"ShardedScene: {len(self.instances)} instance volumes are driven one by one, not as a batch ({ex}); "
+                                   "create the engines with view_pipeline=VIEW_PIPELINE_OFF")
         # GPUs: the C ABI's exchange (RCCL called by the library) whenever RCCL can host the ranks — a process group on "nccl", or a
         # single rank; several ranks on ONE GPU (gloo, tests) and CPU tensors (the oracle, tests) go through torch.distributed
         import torch.distributed as dist

@@ -47,8 +47,9 @@ extern "C" {
  * different sides of the change refuse each other at load (2: dsr_kernel_time grew bytes_layout/units, dsr_stats was
  * extended, DSR_E_IO; 3: the multi-GPU exchange (dsr_exchange_*), dsr_update_view_bgr, host-buffer calls no longer
  * synchronise with the engine's stream; 4: dsr_view_split_silhouette, dsr_engine_share_stream, dsr_pin_host_thread, the volume
- * batch dsr_batch_*, dsr_exchange_set_collective / _timing; the view pipeline is on by default for engines with sync_status) */
-#define DSR_ABI_VERSION 4
+ * batch dsr_batch_*, dsr_exchange_set_collective / _timing; the view pipeline is on by default for engines with sync_status;
+ * 5: dsr_settings.view_pipeline, dsr_measure_copy_bandwidth_spread) */
+#define DSR_ABI_VERSION 5
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
 #define DSR_BLOCK_SIZE 8
@@ -114,8 +115,17 @@ typedef struct dsr_settings {
   int32_t sync_status;         /* 1: dsr_process_frame synchronises and returns
                                   DSR_E_OUT_OF_BLOCKS itself (shim behaviour);
                                   0: fully asynchronous, poll dsr_get_stats   */
-  int32_t reserved[7];
+  int32_t view_pipeline;       /* (ABI 5) how the view's writers are queued (see "view pipeline" in DESIGN.md 6.5):
+                                  DSR_VIEW_PIPELINE_AUTO (0: engines with sync_status get the shared form, others none —
+                                  round 5's default; env DSR_PIPELINED_VIEW=0/1/2 overrides AUTO only), _OFF: one stream for
+                                  everything — what dsr_engine_share_stream and dsr_batch_create need, also for an engine
+                                  whose host waits for its status —, _PER_ENGINE, _SHARED                              */
+  int32_t reserved[6];
 } dsr_settings;
+#define DSR_VIEW_PIPELINE_AUTO 0
+#define DSR_VIEW_PIPELINE_OFF 1
+#define DSR_VIEW_PIPELINE_PER_ENGINE 2
+#define DSR_VIEW_PIPELINE_SHARED 3
 
 /* ITMIntrinsics::projectionParamsSimple + image size
  * (InfiniTamDriver.cpp:55-68). */
@@ -567,6 +577,10 @@ int dsr_selftest_division(int device, uint64_t n, uint64_t seed, uint64_t *misma
  * The roofline harness reports it next to the nominal 8 TB/s.  Allocates 2*bytes of HBM
  * for the duration of the call; synchronises. */
 int dsr_measure_copy_bandwidth(int device, uint64_t bytes, int iters, double *gbps_out);
+/* (ABI 5) The same kernel as the roofline's DENOMINATOR: `bytes` per direction (bench.py: 4 GiB), clocks warmed by ~50 ms of
+ * copies first, six launch shapes (4 / 8 / 16 workgroups per CU x plain / non-temporal accesses) timed launch by launch,
+ * `repeats` (1..64) rounds; a round's figure is its best launch.  out = {max, median, min} over the rounds, GB/s. */
+int dsr_measure_copy_bandwidth_spread(int device, uint64_t bytes, int repeats, double out[3]);
 
 /* ---- per-kernel timing (roofline harness) -------------------------------------- */
 

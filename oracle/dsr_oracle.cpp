@@ -2020,6 +2020,7 @@ int orc_pin_host_thread(int) { return DSR_OK; }  // no GPU to be near to
 int orc_engine_share_stream(dsr_engine *h, dsr_engine *owner) { return (h && owner && h != owner) ? DSR_OK : DSR_E_ARG; }  // no streams here
 int orc_stream_wait_for_engine(dsr_engine *h, void *) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_measure_copy_bandwidth(int, uint64_t, int, double *gbps_out) { if (gbps_out) *gbps_out = 0.0; return DSR_OK; }
+int orc_measure_copy_bandwidth_spread(int, uint64_t, int, double out[3]) { if (out) out[0] = out[1] = out[2] = 0.0; return DSR_OK; }
 
 int orc_profile_enable(dsr_engine *h, int) { return h ? DSR_OK : DSR_E_ARG; }
 int orc_profile_reset(dsr_engine *h) { return h ? DSR_OK : DSR_E_ARG; }

@@ -48,7 +48,7 @@ def main():
     dev = torch.device("cuda", 0)
     from dynslam_amd.engine import EngineCore, default_settings, make_calib
     from dynslam_amd.synth import StreetScene
-    from tests.test_gpu_fullsize import check_structure
+    from dynslam_amd.invariants import check_structure
     W, H = a.width, a.height
     sc = StreetScene(W, H)
     kw = settings_kwargs(a.preset)
