@@ -53,6 +53,8 @@ enum Ctr {
   CTR_SWAP_FIRST_SLOT = 15,   // first host slot of the running swap-out batch
   CTR_NO_ALLOCATED = 16,      // length of the cached list of allocated entries (free-view culling)
   CTR_VIS_OVERFLOW = 17,      // the live visible list was cut at its capacity: entries of type 3 exist outside the list (k_alloc.h K0b)
+  CTR_NO_ALLOC_IDS = 18,      // instance-sized volumes: length of SceneP::allocIds ...
+  CTR_ALLOC_IDS_VALID = 19,   // ... and whether it lists exactly the entries that own a block (k_small.h; the voxel GC clears it)
   CTR_COUNT = 32
 };
 // device-resident 64-bit work counters (roofline bookkeeping + decayed count)
@@ -101,6 +103,8 @@ struct SceneP {
   uint8_t *visGrp;        // one BYTE per 8 entries: the running frame's mark touched an entry of the group (plain stores, no atomics)
   uint32_t *visBits;      // one BIT per entry: visible in the running frame — built and cleared by the list kernel itself
   uint32_t *allocBits;    // entries that own a voxel block (ptr >= 0): set by the commit, cleared by the voxel GC
+  int32_t *allocIds;      // the same set as an ASCENDING list of entry indices (ctr[CTR_NO_ALLOC_IDS] long, valid while
+                          // ctr[CTR_ALLOC_IDS_VALID]): merged by the commit, rebuilt from allocBits after the GC (k_small.h, round 6)
 };
 
 // ------------------------------------------------------------------ conversions

@@ -219,7 +219,7 @@ void free_all(dsr_engine *e) {
   auto F = [](void *p) { if (p) (void)hipFree(p); };
   F(e->scene.table); F(e->scene.vba); F(e->scene.voxelAllocList); F(e->scene.excessAllocList);
   F(e->scene.ctr); F(e->scene.work); F(e->scene.allocKey); F(e->scene.allocGrp); F(e->scene.allocTile);
-  F(e->scene.visGrp); F(e->scene.visBits); F(e->scene.allocBits);
+  F(e->scene.visGrp); F(e->scene.visBits); F(e->scene.allocBits); F(e->scene.allocIds);
   for (RenderStateDev *rs : {&e->live, &e->freeview}) {
     F(rs->visibleIDs); F(rs->visibleIDsAlt); F(rs->visBlocks); F(rs->visBlocksAlt); F(rs->visType); F(rs->minmax); F(rs->raycastResult); F(rs->raycastImage); F(rs->rayBox);
   }
@@ -489,12 +489,11 @@ int allocate_scene(dsr_engine *e) {
       LAUNCH(e, "alloc_mark", k_alloc_mark<true>, dim3(tx1 - tx0, ty1 - ty0), dim3(256), p, e->scene, (const float *)e->depth,
              rs.visType, tx0, ty0);
     if (e->statusDev) e->statusSeq++;
-    const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
     {
       ProfScope _ps(e, "small_alloc_visible");
-      hipLaunchKernelGGL(k_small_alloc_visible, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene,
+      hipLaunchKernelGGL(k_small_alloc_visible, dim3(1), dim3(kSmallThreads), e->smallLdsBytes, e->stream, p, e->scene,
                          (const float *)e->depth, rs.visType, e->numTilesE, e->allocWork, rs.visibleIDs, rs.visBlocks, e->noBlocks,
-                         e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox);
+                         e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox, e->smallLists ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
     { int st = after_fusion(e); if (st) return st; }
@@ -896,6 +895,11 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
       ALLOC(dmalloc(&e->scene.visGrp, (size_t)kSmallBitWords * 4));
       ALLOC(dmalloc(&e->scene.visBits, (size_t)kSmallBitWords));
       ALLOC(dmalloc(&e->scene.allocBits, (size_t)kSmallBitWords));
+      ALLOC(dmalloc(&e->scene.allocIds, (size_t)e->noBlocks));
+      e->smallLdsBytes = small_lds_bytes(cells);
+      const size_t withLists = std::max(e->smallLdsBytes, sizeof(SmallShared) + small_lists_lds_bytes(e->noBlocks));
+      e->smallLists = withLists <= 64 * 1024 && !(getenv("DSR_SMALL_LISTS") && atoi(getenv("DSR_SMALL_LISTS")) == 0);
+      if (e->smallLists) e->smallLdsBytes = withLists;
     }
   }
   ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
@@ -1364,7 +1368,7 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         {
           ProfScope _ps(e, "small_freeview");
           hipLaunchKernelGGL(k_small_freeview, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene, e->allocList,
-                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox);
+                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox, e->smallLists ? 1 : 0);
         }
         e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
         if (outIsDevice) {
@@ -1819,7 +1823,7 @@ static BatchVolP batch_vol_record(dsr_engine *e) {
   v.fvRaycastResult = e->freeview.raycastResult; v.fvRaycastImage = e->freeview.raycastImage; v.allocList = e->allocList;
   v.statusDev = e->statusDev;
   v.rayBox = e->live.rayBox; v.fvRayBox = e->freeview.rayBox;
-  v.numTiles = e->numTilesE; v.noBlocks = e->noBlocks; v.gridIntegrate = e->gridIntegrate;
+  v.numTiles = e->numTilesE; v.noBlocks = e->noBlocks; v.gridIntegrate = e->gridIntegrate; v.lists = e->smallLists ? 1 : 0;
   return v;
 }
 // the voxel GC swaps a volume's list buffers (dsr_decay): bring the device records up to date before they are used
@@ -1967,7 +1971,9 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
   const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
   {
     ProfScope _ps(src, "batch_small_alloc_visible");
-    hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), S, frames,
+    size_t lds = small_lds_bytes(cells);
+    for (dsr_engine *e : b->vols) lds = std::max(lds, e->smallLdsBytes);
+    hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), lds, S, frames,
                        (const BatchVolP *)b->volsDev);
   }
 #define BATCH_INTEGRATE(A, B) LAUNCH(src, "batch_integrate", (k_batch_integrate<A, B>), dim3(maxGrid, nv), dim3(256), frames, (const BatchVolP *)b->volsDev)

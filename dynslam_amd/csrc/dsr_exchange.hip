@@ -155,9 +155,10 @@ extern "C" {
 
 // ---- instance compositing
 
-// pixels per lane of k_composite (k_composite.h): 4; env DSR_COMPOSITE_PX=2 for the A/B (tools/bench_composite.py)
+// pixels per lane of k_composite (k_composite.h): 2 — 4.1-5.0 us for eight layers at 1242x375 against 5.0-6.3 with 4 (more waves in
+// flight beat wider loads: profiles/r06d_composite_px*.json); env DSR_COMPOSITE_PX=4 for the A/B (tools/bench_composite.py)
 static int composite_px_per_lane() {
-  static const int px = (getenv("DSR_COMPOSITE_PX") && atoi(getenv("DSR_COMPOSITE_PX")) == 2) ? 2 : 4;
+  static const int px = (getenv("DSR_COMPOSITE_PX") && atoi(getenv("DSR_COMPOSITE_PX")) == 4) ? 4 : 2;
   return px;
 }
 

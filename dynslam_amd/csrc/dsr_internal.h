@@ -95,6 +95,10 @@ struct dsr_engine {
   // k_small.h — commit + visible list + range image as ONE launch, the free-view list + range image as one (21 -> 9 launches
   // per instance frame); results identical, both paths under test
   bool smallPath = false;
+  // ... with the allocated entries also kept as a sorted list (SceneP::allocIds, k_small.h round 6): the visible lists are dense
+  // passes over it instead of sweeps of the bit planes.  env DSR_SMALL_LISTS=0: the sweeps only (A/B; both under test)
+  bool smallLists = false;
+  size_t smallLdsBytes = 0;  // dynamic LDS of the one-workgroup kernels: the range image, or the merge's scratch aliased with it
   // the box (pixels, end exclusive) outside which the current view's depth is known to be 0: set by the silhouette cut-out
   // that produced an instance's view, the whole image after any other writer.  The allocation's per-pixel mark runs over it.
   int viewBox[4] = {0, 0, 0, 0};

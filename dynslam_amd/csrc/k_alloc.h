@@ -398,9 +398,11 @@ __global__ __launch_bounds__(kTileThreads) void k_alloc_commit(FrameP p, SceneP 
 }
 
 // one item of the ordered work list: the winner's block position (its ray replayed), the table written.  BITS: k_small.h
+// LISTS (with BITS, k_small.h's list path): the new child is flagged "touched now" like the mark's own hits instead of getting
+// its bit in visBits — that plane stays untouched (all zero) while the visible list is built from the sorted list of entries
 template <bool BITS>
 __device__ __forceinline__ void alloc_apply_item(const FrameP &p, const SceneP &s, const float *__restrict__ depth, const int4 w,
-                                                 uint8_t *__restrict__ visType) {
+                                                 uint8_t *__restrict__ visType, bool lists = false) {
   const int t = w.x;
   if (t < 0) return;
   short bx, by, bz;
@@ -418,9 +420,9 @@ __device__ __forceinline__ void alloc_apply_item(const FrameP &p, const SceneP &
     s.table[t].offset = exlOffset + 1;
     const int child = p.noBuckets + exlOffset;
     *reinterpret_cast<int4 *>(s.table + child) = make_int4(px, pz, 0, ptr);
-    visType[child] = 1;
+    visType[child] = (BITS && lists) ? kTouchedNow : (uint8_t)1;
     if (BITS) {
-      atomicOr(&s.visBits[child >> 5], 1u << (child & 31));
+      if (!lists) atomicOr(&s.visBits[child >> 5], 1u << (child & 31));
       atomicOr(&s.allocBits[child >> 5], 1u << (child & 31));
     }
   }

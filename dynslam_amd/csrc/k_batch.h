@@ -39,7 +39,7 @@ struct BatchVolP {  // one volume: what does not change from call to call
   int32_t *allocList;  // free-view render state + the staging list of k_small_freeview
   int32_t *statusDev;
   int32_t *rayBox, *fvRayBox;  // the range images' box records (k_raycast.h RB_*)
-  int numTiles, noBlocks, gridIntegrate, pad;
+  int numTiles, noBlocks, gridIntegrate, lists;  // lists: the sorted list of allocated entries is kept (k_small.h)
 };
 
 struct BatchFrameP {  // one volume, this call
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_batch_small_alloc_visible(con
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.x];
   small_alloc_visible_body(f.p, v.s, v.depth, v.visType, v.numTiles, v.workList, v.visibleIDs, v.visBlocks, v.noBlocks, v.statusDev,
-                           f.publishSeq, v.minmax, v.rayBox);
+                           f.publishSeq, v.minmax, v.rayBox, v.lists);
 }
 
 template <bool RGB_SAME, bool PLAIN>
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_batch_small_freeview(const Ba
   const BatchFrameP &f = frames.f[blockIdx.x];
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.x];
-  small_freeview_body(f.p, v.s, v.allocList, v.fvVisibleIDs, v.fvVisBlocks, v.noBlocks, v.fvMinmax, v.fvRayBox);
+  small_freeview_body(f.p, v.s, v.allocList, v.fvVisibleIDs, v.fvVisBlocks, v.noBlocks, v.fvMinmax, v.fvRayBox, v.lists);
 }
 
 __global__ __launch_bounds__(256) void k_batch_raycast_render(const BatchFrames frames, const BatchVolP *__restrict__ vols) {

@@ -212,7 +212,10 @@ __global__ __launch_bounds__(kTileThreads) void k_decay_commit(SceneP s, const i
       s.voxelAllocList[oldHead + 1 + rank] = he->ptr;
       he->ptr = -2;
       visType[t] = 0;
-      if (s.allocBits) atomicAnd(&s.allocBits[t >> 5], ~(1u << (t & 31)));  // (k_small.h: the free-view list of an instance-sized volume)
+      if (s.allocBits) {  // (k_small.h: the allocated set of an instance-sized volume, as bits and as a sorted list)
+        atomicAnd(&s.allocBits[t >> 5], ~(1u << (t & 31)));
+        s.ctr[CTR_ALLOC_IDS_VALID] = 0;  // the list is rebuilt from the bits by the next allocation
+      }
       if (s.swapState) { s.swapState[t] = 0; s.swapStored[t] = 0; }
       rank++;
     }

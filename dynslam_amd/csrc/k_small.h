@@ -36,15 +36,39 @@ constexpr int kSmallRows = 9;                                              // 16
 constexpr int kSmallBitWords = kSmallWaves * kSmallRows * 64 * 4;          // 36864 words = 1 179 648 entries: upstream's table
 constexpr int kSmallMaxEntries = kSmallBitWords * 32;
 constexpr int kSmallMaxTiles = kSmallThreads;                              // one allocation tile total per thread
+// Round 6 — the sorted LIST of allocated entries (SceneP::allocIds).  The phase clocks of these kernels (tools/small_kernel_clocks.py,
+// profiles/r06a_small_kernel_clocks.json) put 10 + 12 us of k_small_alloc_visible's 43 and 15 of k_small_freeview's 33 into the
+// three sweeps of a 147 KB plane that find ~800 entries: nine 16-byte loads per lane, fifty-four shuffles, and up to nine more
+// dependent reads where a lane holds bits.  An instance volume owns <= 7142 blocks, so the set of its allocated entries fits one
+// list that the commit keeps sorted: a frame's new entries (a handful, ranked among themselves in LDS) are merged in by binary
+// searches in LDS, and the visible list is one dense pass over the list — type and table entry of every allocated entry
+// requested together, "touched by this frame's mark" / "visible last frame, re-test" decided per entry, ordered compaction.  No
+// plane is swept.  The bit planes stay the ground truth: a frame that cannot take the list path — the first after a reset or a
+// GC pass (list invalid), an exhausted block array (entries that are visible without owning a block), a visible list that
+// overflowed, more than kSmallNewMax new entries — runs the sweeps as before and rebuilds the list from allocBits at its end.
+constexpr int kSmallNewMax = 2048;                                         // new entries a frame may merge on the list path
+// dynamic LDS of the two kernels: the range image, or — aliased with it, used before it — the merge's scratch
+// (the old list + the frame's new entries, raw and sorted)
+constexpr size_t small_lists_lds_bytes(int capacity) { return ((size_t)capacity + 2 * (size_t)kSmallNewMax) * sizeof(int32_t); }
 
 struct SmallShared {  // head of the dynamic LDS; the range image follows
   int2 scan[kSmallWaves];
   int waveTotal[kSmallWaves];
   int oldV, oldE, nPrev, overflowPrev;
+  int nIds, idsValid, pad0, pad1;  // SceneP::allocIds: length, validity (read once by thread 0)
   int box[4];  // store_range_image (k_raycast.h): the box of the image's non-empty cells
 };
 static_assert(sizeof(SmallShared) % sizeof(int2) == 0, "the range image behind it is an int2 array");
 constexpr size_t small_lds_bytes(int nCells) { return sizeof(SmallShared) + (size_t)nCells * sizeof(int2); }
+// lower bound in an ascending LDS array: number of elements < x
+__device__ __forceinline__ int small_lower_bound(const int32_t *a, int n, int x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
 
 // (agent scope: served by L2, never allocates a line in this CU's L1 — the planes are also updated by L2 atomics of this very
 //  workgroup, and the 16-byte sweep that follows must not find a line an earlier phase left in L1)
@@ -126,7 +150,8 @@ __device__ __forceinline__ int small_sweep_bits(uint32_t *plane, int32_t *ids, i
 __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
                                                          uint8_t *visType, int numTiles, int4 *workList, int32_t *visibleIDs,
                                                          int4 *visBlocks, int capacity, int32_t *__restrict__ publish,
-                                                         int publishSeq, int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
+                                                         int publishSeq, int2 *__restrict__ minmax, int32_t *__restrict__ rb,
+                                                         int lists) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -139,6 +164,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   if (tid == 0) {
     sh.oldV = s.ctr[CTR_LAST_FREE_BLOCK]; sh.oldE = s.ctr[CTR_LAST_FREE_EXCESS];
     sh.nPrev = s.ctr[CTR_NO_VISIBLE_LIVE]; sh.overflowPrev = s.ctr[CTR_VIS_OVERFLOW];
+    sh.nIds = s.ctr[CTR_NO_ALLOC_IDS]; sh.idsValid = lists ? s.ctr[CTR_ALLOC_IDS_VALID] : 0;
     sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1;
   }
   // ---- A
@@ -147,6 +173,11 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   int2 total;
   const int2 tileOff = wg_exclusive_scan2<kSmallThreads>(tv, total, sh.scan);  // (its barriers also publish sh.* and the image's reset)
   const int oldV = sh.oldV, oldE = sh.oldE;
+  // the list path (uniform): the list is valid, every marked entry gets its block (an entry that stays without one is visible
+  // but not allocated), the previous visible list was complete, the frame's new entries fit the merge
+  const int nOld = sh.nIds;
+  const bool fast = lists && sh.idsValid && !sh.overflowPrev && total.x <= oldV + 1 && total.y <= oldE + 1 &&
+                    total.x <= kSmallNewMax && nOld + total.x <= capacity;
   if (tid == 0) {
     int32_t *ctr = s.ctr;
     ctr[CTR_ALLOC_OLD_HEAD_VBA] = oldV; ctr[CTR_ALLOC_OLD_HEAD_EXC] = oldE;
@@ -223,8 +254,9 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   // bit sweep): the types that carry kTouchedNow become bits of visBits — the group's 8 bits are ONE byte of that plane, nobody
   // else writes it before the barrier, so a plain byte store does — and go back to the plain type 1.  A lane rarely owns more than
   // one marked group per row: the FIRST group's types of all nine rows are requested together (one round trip for the wave, not
-  // nine), the rest goes through the loop behind.
-  {
+  // nine), the rest goes through the loop behind.  (Not on the list path: the touched entries are found through the list, and a
+  // group byte left set only makes a later sweep look at eight types that carry no flag.)
+  if (!fast) {
     const int wave = tid >> 6;
     uint4 *rows = reinterpret_cast<uint4 *>(s.visGrp) + wave * (kSmallRows * 64) + lane;
     uint4 g[kSmallRows];
@@ -275,11 +307,11 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   {
     const int avail = oldV + 1;
     const int n = total.x < avail ? total.x : avail;
-    for (int i = tid; i < n; i += kSmallThreads) alloc_apply_item<true>(p, s, depth, workList[i], visType);
+    for (int i = tid; i < n; i += kSmallThreads) alloc_apply_item<true>(p, s, depth, workList[i], visType, fast);
   }
   SMALL_CLK(4);
   // ---- D (independent of C: an entry C creates was not visible before, an entry the mark touched is skipped)
-  const int nPrev = sh.nPrev;
+  const int nPrev = fast ? 0 : sh.nPrev;
   for (int i = tid; i < nPrev; i += kSmallThreads) {
     const dsr_hash_entry he = entry_of_record(visBlocks[i]);  // the previous frame's stream
     const int t = he.offset;
@@ -292,7 +324,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   }
   SMALL_CLK(5);
   // ---- E
-  if (sh.overflowPrev) {
+  if (!fast && sh.overflowPrev) {
     __syncthreads();
     auto leftover = [&](int t, uint32_t v) {
       if (v == 0u) return;
@@ -324,8 +356,89 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   }
   __syncthreads();
   SMALL_CLK(6);
-  // ---- F
-  const int totalVisible = small_sweep_bits<true>(s.visBits, visibleIDs, capacity, sh);
+  int totalVisible = 0;
+  if (fast) {
+    // ---- M: this frame's new entries (the work list: in-place entries as they are, a chain append's CHILD) merged into the
+    // sorted list.  LDS scratch over the range image's cells, which are reset again behind it.
+    const int nNew = total.x;
+    if (nNew > 0) {
+      int32_t *oldL = reinterpret_cast<int32_t *>(cells), *newRaw = oldL + capacity, *newSorted = newRaw + kSmallNewMax;
+      for (int i = tid; i < nOld; i += kSmallThreads) oldL[i] = s.allocIds[i];
+      for (int j = tid; j < nNew; j += kSmallThreads) {
+        const int4 w = workList[j];
+        newRaw[j] = w.w < 0 ? w.x : p.noBuckets + s.excessAllocList[w.w];
+      }
+      __syncthreads();
+      for (int j = tid; j < nNew; j += kSmallThreads) {  // rank among the new ones (all distinct)
+        const int x = newRaw[j];
+        int r = 0;
+        for (int k = 0; k < nNew; ++k) r += newRaw[k] < x ? 1 : 0;
+        newSorted[r] = x;
+      }
+      __syncthreads();
+      for (int j = tid; j < nNew; j += kSmallThreads) {
+        const int x = newSorted[j];
+        s.allocIds[small_lower_bound(oldL, nOld, x) + j] = x;
+      }
+      for (int i = tid; i < nOld; i += kSmallThreads) {
+        const int x = oldL[i];
+        const int r = small_lower_bound(newSorted, nNew, x);
+        if (r) s.allocIds[i + r] = x;
+      }
+      if (tid == 0) s.ctr[CTR_NO_ALLOC_IDS] = nOld + nNew;
+      __syncthreads();
+      for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
+      __syncthreads();
+    }
+    // ---- H: one dense pass over the allocated entries, in entry order: visible iff this frame's mark touched it, or it was
+    // visible in the previous frame (its type is still 1 / 3) and passes the frustum test (types as phases D0 / D leave them);
+    // ordered compaction -> visibleEntryIDs + the stream, the range image folded on the way (phases F + G)
+    const int nAll = nOld + nNew;
+    int carry = 0;
+    for (int base = 0; base < nAll; base += kSmallThreads) {  // uniform trip count
+      const int i = base + tid;
+      bool vis = false;
+      int t = 0;
+      int4 raw = make_int4(0, 0, 0, -2);
+      if (i < nAll) {
+        t = s.allocIds[i];
+        raw = *reinterpret_cast<const int4 *>(s.table + t);
+        const uint8_t ty = visType[t];
+        if (ty == kTouchedNow) { vis = true; visType[t] = 1; }
+        else if (ty != 0) {
+          const dsr_hash_entry he = entry_of_record(raw);
+          bool isVisible, isVisibleEnlarged;
+          check_block_visibility<false>(isVisible, isVisibleEnlarged, he.pos, p.M, p.proj, p.voxelSize, p.W, p.H);
+          vis = isVisible;
+          visType[t] = isVisible ? 3 : 0;
+        }
+      }
+      int2 tot;
+      const int2 ex = wg_exclusive_scan2<kSmallThreads>(make_int2(vis ? 1 : 0, 0), tot, sh.scan);
+      const int rank = carry + ex.x;
+      bool valid = false;
+      int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
+      float2 zr = make_float2(0.f, 0.f);
+      if (vis && rank < capacity) {
+        const int4 rec = make_vis_record(raw, t);
+        visibleIDs[rank] = t;
+        visBlocks[rank] = rec;
+        const dsr_hash_entry he = entry_of_record(rec);
+        if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+      }
+      fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
+      carry += tot.x;
+    }
+    totalVisible = carry;
+  } else {
+    // ---- F
+    totalVisible = small_sweep_bits<true>(s.visBits, visibleIDs, capacity, sh);
+    if (lists) {  // ... and the sorted list for the frames to come, from the bits (final since phase C)
+      __syncthreads();
+      const int totalAlloc = small_sweep_bits<false>(s.allocBits, s.allocIds, capacity, sh);
+      if (tid == 0) { s.ctr[CTR_NO_ALLOC_IDS] = totalAlloc < capacity ? totalAlloc : capacity; s.ctr[CTR_ALLOC_IDS_VALID] = totalAlloc <= capacity ? 1 : 0; }
+    }
+  }
   const int n = totalVisible < capacity ? totalVisible : capacity;
   if (tid == 0) {
     int32_t *ctr = s.ctr;
@@ -342,21 +455,22 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
   __syncthreads();
   SMALL_CLK(7);
   // ---- G
-  for (int base = tid & ~63; base < n; base += kSmallThreads) {  // wave-uniform trip count
-    const int i = base + lane;
-    bool valid = false;
-    int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
-    float2 zr = make_float2(0.f, 0.f);
-    if (i < n) {
-      const int t = visibleIDs[i];
-      const int4 raw = *reinterpret_cast<const int4 *>(s.table + t);
-      const int4 rec = make_vis_record(raw, t);
-      visBlocks[i] = rec;
-      const dsr_hash_entry he = entry_of_record(rec);
-      if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+  if (!fast)
+    for (int base = tid & ~63; base < n; base += kSmallThreads) {  // wave-uniform trip count
+      const int i = base + lane;
+      bool valid = false;
+      int2 ul = make_int2(0, 0), lr = make_int2(-1, -1);
+      float2 zr = make_float2(0.f, 0.f);
+      if (i < n) {
+        const int t = visibleIDs[i];
+        const int4 raw = *reinterpret_cast<const int4 *>(s.table + t);
+        const int4 rec = make_vis_record(raw, t);
+        visBlocks[i] = rec;
+        const dsr_hash_entry he = entry_of_record(rec);
+        if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+      }
+      fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
     }
-    fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
-  }
   if (n <= 0) return;  // Prepare() is skipped without visible blocks: the image keeps its previous contents
   __syncthreads();
   SMALL_CLK(8);
@@ -368,15 +482,16 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_alloc_visible(FrameP p,
                                                                        uint8_t *visType, int numTiles, int4 *workList,
                                                                        int32_t *visibleIDs, int4 *visBlocks, int capacity,
                                                                        int32_t *__restrict__ publish, int publishSeq,
-                                                                       int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
-  small_alloc_visible_body(p, s, depth, visType, numTiles, workList, visibleIDs, visBlocks, capacity, publish, publishSeq, minmax, rb);
+                                                                       int2 *__restrict__ minmax, int32_t *__restrict__ rb, int lists) {
+  small_alloc_visible_body(p, s, depth, visType, numTiles, workList, visibleIDs, visBlocks, capacity, publish, publishSeq, minmax, rb,
+                           lists);
 }
 
 // FindVisibleBlocks + CreateExpectedDepths of a free camera for an instance-sized volume: the allocated entries come from
 // allocBits (ascending), are tested against the frustum densely, compacted in order; the range image is folded on the way.
 __device__ __forceinline__ void small_freeview_body(const FrameP &p, const SceneP &s, int32_t *stage, int32_t *__restrict__ visibleIDs,
                                                     int4 *__restrict__ visBlocks, int capacity, int2 *__restrict__ minmax,
-                                                    int32_t *__restrict__ rb) {
+                                                    int32_t *__restrict__ rb, int lists) {
   extern __shared__ int2 smallLds[];
   SmallShared &sh = *reinterpret_cast<SmallShared *>(smallLds);
   int2 *cells = smallLds + sizeof(SmallShared) / sizeof(int2);
@@ -386,10 +501,20 @@ __device__ __forceinline__ void small_freeview_body(const FrameP &p, const Scene
   const int farBits = __float_as_int(kFarAway), closeBits = __float_as_int(kVeryClose);
   SMALL_CLK(16);
   for (int c = tid; c < nCells; c += kSmallThreads) cells[c] = make_int2(farBits, closeBits);
-  if (tid == 0) { sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1; }
-  const int totalAlloc = small_sweep_bits<false>(s.allocBits, stage, capacity, sh);  // (its barriers publish the image's reset)
-  const int nAlloc = totalAlloc < capacity ? totalAlloc : capacity;
-  __syncthreads();  // the ids
+  if (tid == 0) {
+    sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1;
+    sh.nIds = s.ctr[CTR_NO_ALLOC_IDS]; sh.idsValid = lists ? s.ctr[CTR_ALLOC_IDS_VALID] : 0;
+  }
+  __syncthreads();
+  // the allocated entries in ascending order: the list the commit keeps (k_small_alloc_visible), or — while it is not valid —
+  // the bits swept into `stage`
+  int nAlloc;
+  if (sh.idsValid) { nAlloc = sh.nIds; stage = s.allocIds; }
+  else {
+    const int totalAlloc = small_sweep_bits<false>(s.allocBits, stage, capacity, sh);
+    nAlloc = totalAlloc < capacity ? totalAlloc : capacity;
+    __syncthreads();  // the ids
+  }
   SMALL_CLK(17);
   int carry = 0;
   for (int base = 0; base < nAlloc; base += kSmallThreads) {  // uniform trip count
@@ -436,8 +561,8 @@ __device__ __forceinline__ void small_freeview_body(const FrameP &p, const Scene
 }
 __global__ __launch_bounds__(kSmallThreads) void k_small_freeview(FrameP p, SceneP s, int32_t *stage, int32_t *__restrict__ visibleIDs,
                                                                   int4 *__restrict__ visBlocks, int capacity,
-                                                                  int2 *__restrict__ minmax, int32_t *__restrict__ rb) {
-  small_freeview_body(p, s, stage, visibleIDs, visBlocks, capacity, minmax, rb);
+                                                                  int2 *__restrict__ minmax, int32_t *__restrict__ rb, int lists) {
+  small_freeview_body(p, s, stage, visibleIDs, visBlocks, capacity, minmax, rb, lists);
 }
 
 }  // namespace dsr
