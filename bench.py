@@ -393,6 +393,11 @@ def frames_for(args, n_inst):
     return _PREGENERATED[n_inst]
 
 
+def _n_inst_of_leg(V, has_static):
+    """Moving boxes in the frames of a leg: none for map volumes (whole frames), V - 1 next to a static map, else V."""
+    return 0 if has_static == "maps" else (V - 1 if has_static else V)
+
+
 def multi_gpu_legs(args, world):
     """-> [(n_volumes, has_static)] of a multi-volume job: the headline leg first.
     --instance-volumes V: north_star's scaling workload, V concurrent instance volumes;  --volumes V: configs[3], the static map
@@ -403,8 +408,11 @@ def multi_gpu_legs(args, world):
         legs.append((args.instance_volumes, False))
     if args.volumes:
         legs.append((args.volumes, True))
+    if args.map_volumes:
+        legs.append((args.map_volumes, "maps"))
     if not legs and world > 1 and not args.replicas:
-        legs = [(SCALING_VOLUMES, False)] + ([] if args.no_configs3 else [(SCALING_VOLUMES, True)])
+        # ... and the case sharding by volume is made for: one MAP-sized volume per GPU ("maps": N volumes at N GPUs)
+        legs = [(SCALING_VOLUMES, False)] + ([] if args.no_configs3 else [(SCALING_VOLUMES, True), (world, "maps")])
     return legs
 
 
@@ -418,7 +426,7 @@ def spawn_ranks(args, legs):
     if args.replicas:
         frames_for(args, args.instances)
     for V, has_static in legs:
-        frames_for(args, V - 1 if has_static else V)
+        frames_for(args, _n_inst_of_leg(V, has_static))
     # The rendezvous port is chosen by rank 0's OWN store (bound to port 0, i.e. by the kernel) and handed to the parent through
     # a pipe before the other ranks are forked: a port picked here and closed again could be taken by another process before
     # rank 0 binds it.
@@ -487,7 +495,7 @@ def main_volumes(args, legs):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    frame_sets = [frames_for(args, V - 1 if has_static else V) for V, has_static in legs]  # before HIP / RCCL start (fork)
+    frame_sets = [frames_for(args, _n_inst_of_leg(V, has_static)) for V, has_static in legs]  # before HIP / RCCL start (fork)
 
     import torch
     tb = _test_backend()
@@ -534,14 +542,45 @@ def main_volumes(args, legs):
             if out is None:
                 out = line
             else:  # the second leg rides along under its own key: ONE line per job
-                out["configs3" if has_static else "instance_volumes"] = {k: line[k] for k in (
+                out["map_volumes" if has_static == "maps" else "configs3" if has_static else "instance_volumes"] = {k: line[k] for k in (
                     "value", "unit", "ms_per_step", "scaling", "config", "value_same_workload_1gpu", "speedup_vs_1gpu", "time_sliced_1gpu",
                     "cpu_baseline", "kernels")}
+    bad = None
     if rank == 0:
+        if world > 1:  # a --gpus N line that does not show N GPUs at work must not pass for a scaling point
+            bad = check_multi_gpu_line(out, world)
+            out["multi_gpu_check"] = {"ok": not bad, "problems": bad}
         print(json.dumps(out), flush=True)
+        if bad:
+            print("bench.py: this line is NOT a valid multi-GPU measurement: " + "; ".join(bad), file=sys.stderr, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if bad:
+        sys.exit(3)
+
+
+def check_multi_gpu_line(line, n):
+    """-> list of reasons why `line` (rank 0's line of a `--gpus n` job, n > 1) is not a measurement on n GPUs; empty when it is.
+    With the product backend the library's own RCCL communicator must span n ranks and the collective must have taken time on the
+    exchange's stream; every backend must report the same workload on one GPU and the ratio, and one rank per GPU with work."""
+    bad = []
+    cfg = line.get("config") or {}
+    if line.get("n_gpus") != n:
+        bad.append(f"n_gpus is {line.get('n_gpus')}, not {n}")
+    per_rank = cfg.get("volumes_per_rank") or []
+    if len(per_rank) != n or sum(per_rank) != cfg.get("volumes") or min(per_rank or [0]) < 1:
+        bad.append(f"volumes_per_rank {per_rank} does not put every one of {cfg.get('volumes')} volumes on one of {n} working ranks")
+    if not (line.get("value_same_workload_1gpu") and line.get("speedup_vs_1gpu")):
+        bad.append("no value_same_workload_1gpu / speedup_vs_1gpu: the same workload was not measured on one GPU")
+    if line.get("backend") == "hip":
+        if cfg.get("rccl_ranks") != n:
+            bad.append(f"rccl_ranks is {cfg.get('rccl_ranks')}: the library's RCCL communicator does not span {n} GPUs")
+        if not (cfg.get("gather_us") or 0) > 0:
+            bad.append("gather_us is 0: no collective ran on the exchange's stream")
+    if cfg.get("status") not in (0, None):
+        bad.append(f"engine status {cfg.get('status')}")
+    return bad
 
 
 def volume_settings(preset):
@@ -550,7 +589,10 @@ def volume_settings(preset):
     inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
                    sdf_local_block_num=7142, hash_bucket_num=0x100000, excess_list_size=0x20000)
     view_kw = dict(kw, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)
-    return {"static": kw, "instance": inst_kw, "view": view_kw}
+    # a map-sized volume of the map_volumes leg: the preset's voxels and table, 2^21 blocks (8 GiB) — the 25 frames of the bench
+    # allocate 1.84 M — so that the leg's 1-GPU denominator (N such volumes time-sliced on one GPU) fits at N = 8
+    map_kw = dict(kw, sdf_local_block_num=min(kw["sdf_local_block_num"], 1 << 21))
+    return {"static": kw, "instance": inst_kw, "view": view_kw, "map": map_kw}
 
 
 def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=None, has_static=True, backend="hip"):
@@ -562,6 +604,8 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     import torch.distributed as dist
     from dynslam_amd.multigpu import ShardedScene, volumes_of_rank
     V = args.volumes
+    maps = has_static == "maps"
+    has_static = bool(has_static) and not maps
     n_inst = V - 1 if has_static else V
     W, H, K, Wm = args.width, args.height, args.steps, args.warmup
     on_gpu = dev.type == "cuda"
@@ -576,6 +620,9 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     track_ids = {k: 1 + k for k in range(n_inst)}
     pose_m = [np.linalg.inv(np.asarray(f[2], np.float64)).astype(np.float32) for f in frames]
     inst_m = [{k: np.linalg.inv(np.asarray(rel, np.float64)).astype(np.float32) for k, _, _, _, rel in f[3]} for f in frames]
+    if maps:  # every volume is previewed from the frame's camera
+        inst_m = [{k: m for k in range(n_inst)} for m in pose_m]
+        masks_in = [[] for _ in frames]
     if on_gpu:
         # poses are input data like the frames: converted to the C ABI's float[16] once, not per call inside the timed loop (a numpy
         # transpose + a ctypes view cost CPython ~10 us each — 16 of them per step of 8 volumes; a C++ host pays nothing for this)
@@ -615,7 +662,7 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
             barrier()
             return time.perf_counter() - t0, t_enq
 
-    scene = ShardedScene(make_engine, W, H, V, world, rank, dev, has_static=has_static)
+    scene = ShardedScene(make_engine, W, H, V, world, rank, dev, has_static=has_static, maps=maps)
     scene.exchange.host_api = host_api
     prof = []
     probe = scene.static if scene.owns_static else (next(iter(scene.instances.values())) if (scene.instances and rank == 0) else None)
@@ -671,7 +718,7 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
 
     sliced = None
     if rank == 0 and world > 1 and not args.no_time_sliced:  # north_star's denominator: the same V volumes on ONE GPU
-        one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True, has_static=has_static)
+        one = ShardedScene(make_engine, W, H, V, 1, 0, dev, local_only=True, has_static=has_static, maps=maps)
         one.exchange.host_api = host_api
         t1, _ = run(one, 1)
         one.close()
@@ -681,14 +728,17 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     if rank != 0:
         return None
     cpu = None
-    if not getattr(args, "no_cpu_baseline", False):  # rank 0's host cores, after the timed region (the other ranks wait at the barrier)
+    if not getattr(args, "no_cpu_baseline", False) and not maps:  # rank 0's host cores, after the timed region (the other ranks wait at the barrier)
         try:
             cpu = cpu_baseline_volumes(frames, W, H, V, has_static, args.preset, getattr(args, "cpu_budget_s", 12.0))
         except Exception as ex:  # the baseline must never take the bench line down
             cpu = {"value": None, "unit": "volume-frames/s", "cores": 1, "kind": "port", "sample": f"failed: {ex}"}
     roofline, kernels = roofline_from_profile(prof, args, None)  # rank 0's probe engine
     per_rank = [len(volumes_of_rank(r, V, world, has_static)) for r in range(world)]
-    if has_static:
+    if maps:
+        what = (f"map volumes: {V} MAP-sized volumes (preset {args.preset} voxels and table, 2^21 blocks each) sharded by volume over "
+                f"{world} GPU(s) (volume k on rank k mod N), each fusing the whole frame (configs[1]'s step)")
+    elif has_static:
         what = (f"configs[3]: static map (preset {args.preset}) + {n_inst} instance volumes (0.035 m, mu 1.0, 7142 blocks) "
                 f"sharded by volume over {world} GPU(s) (the map on rank 0, instance k on rank 1 + k mod (N-1))")
     else:
@@ -702,7 +752,7 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
         "value": value,
         "unit": "volume-frames/s" if volume_rate else "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
         # the SAME V volumes at every N (the driver's 1 / 2 / 4 / 8 curve is one workload): total work fixed = strong scaling
-        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "strong",
+        "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak" if maps else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": backend,
         # north_star: "aggregate at N GPUs over 8 concurrent instance volumes" against the same volumes on ONE GPU
         "value_same_workload_1gpu": same_1gpu,
@@ -887,6 +937,8 @@ def parse_args(argv=None):
     ap.add_argument("--volumes", type=int, default=0,
                     help="configs[3]: static map + (V-1) instance volumes sharded one per GPU with the fused-preview "
                          "all-gather + composite in the timed step (nested under \"configs3\" in the --gpus N > 1 line)")
+    ap.add_argument("--map-volumes", type=int, default=0,
+                    help="V MAP-sized volumes (2^21 blocks of the preset's voxels), volume k on rank k mod N, each fusing the whole frame + the fused preview")
     ap.add_argument("--no-configs3", action="store_true", help="--gpus N > 1: only the instance-volumes leg")
     ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
     ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of a multi-volume line")

@@ -258,7 +258,7 @@ class ShardedScene:
     """
 
     def __init__(self, make_engine, width, height, n_volumes, world_size, rank, device, group=None, local_only=False,
-                 has_static=True, share_streams=True, use_batch=True):
+                 has_static=True, share_streams=True, use_batch=True, maps=False):
         import torch
         self.torch = torch
         self.W, self.H, self.P = int(width), int(height), int(width) * int(height)
@@ -266,15 +266,20 @@ class ShardedScene:
         self.n_volumes = int(n_volumes)
         self.has_static = bool(has_static)
         self.on_gpu = getattr(device, "type", "cpu") == "cuda"
+        # maps=True (bench.py's map_volumes leg): every volume is a MAP-sized volume fed with the whole frame — no view split, no
+        # instance masks; volume k on rank k mod world, the fused preview as for instance volumes.  The case sharding by volume is
+        # made for: a volume's frame is a millisecond of a full GPU.
+        self.maps = bool(maps)
+        assert not (self.maps and self.has_static), "map volumes: has_static=False (every volume is one)"
         self.owns_static = self.has_static and 0 in volumes_of_rank(rank, n_volumes, world_size, True)
         self.static = make_engine("static") if self.owns_static else None
-        self.instances = {k: make_engine("instance") for k in instances_of_rank(rank, n_volumes, world_size, self.has_static)}
+        self.instances = {k: make_engine("map" if self.maps else "instance") for k in instances_of_rank(rank, n_volumes, world_size, self.has_static)}
         # the full frame the instance views are cut from
-        self.source = self.static if self.owns_static else (make_engine("view") if self.instances else None)
+        self.source = self.static if self.owns_static else (make_engine("view") if (self.instances and not self.maps) else None)
         # one instance volume next to its view engine on a GPU of their own (north_star's layout at 8 GPUs): ONE stream for the pair,
         # no cross-stream event in the frame (dsr_engine_share_stream)
         from .engine import DsrError
-        if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1:
+        if self.on_gpu and share_streams and not self.owns_static and len(self.instances) == 1 and not self.maps:
             try:
                 next(iter(self.instances.values())).share_stream(self.source)
             except DsrError as ex:  # engines with a view pipeline of their own (created for a host that waits on them): as they are
@@ -283,7 +288,7 @@ class ShardedScene:
         # several instance volumes on this GPU: driven as ONE batch — every kernel of an instance frame launched once for all of
         # them (dsr_batch_*; results identical to the per-volume calls).  Up to 8 per batch; a rank with more keeps the loop.
         self.batch, self.batch_index = None, {}
-        if self.on_gpu and use_batch and 2 <= len(self.instances) <= 8 and hasattr(self.source.api, "batch_create"):
+        if self.on_gpu and use_batch and not self.maps and 2 <= len(self.instances) <= 8 and hasattr(self.source.api, "batch_create"):
             from .engine import Batch
             order = sorted(self.instances)
             try:
@@ -339,6 +344,16 @@ class ShardedScene:
         does) or a tuple (device pointer, box_w, box_h) of a mask already in HBM (no copy, no synchronisation).
         Order per rank as on one GPU: cut the instance views out of the full frame, blank them in the static view,
         fuse (InstanceReconstructor.cpp:238-263,569-700)."""
+        if self.maps:  # every owned volume fuses the whole frame from the static pose (configs[1]'s step, per volume)
+            for e in self.instances.values():
+                if isinstance(rgba, int):
+                    e.update_view_dev(rgba, depth_mm)
+                else:
+                    e.update_view(rgba, depth_mm)
+                e.set_pose_inv_m(static_pose)
+                e.process_frame()
+                e.prepare()
+            return
         if self.source is not None:
             if isinstance(rgba, int):
                 self.source.update_view_dev(rgba, depth_mm)

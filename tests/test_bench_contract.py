@@ -170,6 +170,40 @@ def test_cli_gpus_n_spawns_its_own_ranks(n):
     assert c3["config"]["workload"].startswith("configs[3]") and c3["config"]["has_static_map"] is True
     assert c3["config"]["volumes_per_rank"] == {2: [1, 7], 3: [1, 4, 3]}[n] and c3["value"] > 0 and c3["time_sliced_1gpu"]["value"] > 0
     assert c3["config"]["static_visible_blocks_last_frame"] > 100 and c3["cpu_baseline"]["value"] > 0
+    # the third leg: one MAP-sized volume per rank, each fusing the whole frame, the same fused preview
+    mv = line["map_volumes"]
+    assert mv["config"]["workload"].startswith("map volumes") and mv["config"]["volumes"] == n and mv["config"]["volumes_per_rank"] == [1] * n
+    assert mv["scaling"] == "weak" and mv["value"] > 0 and mv["time_sliced_1gpu"]["value"] == mv["value_same_workload_1gpu"] > 0
+    assert mv["speedup_vs_1gpu"] > 0 and mv["config"]["preview_hit_fraction"] > 0.3 and mv["config"]["status"] == 0
+    assert all(v > 100 for v in mv["config"]["instance_visible_blocks_last_frame_rank0"])
+    # ... and the line went through the multi-GPU check (the seam's transport is exempt from the RCCL items only)
+    assert line["multi_gpu_check"] == {"ok": True, "problems": []}
+
+
+def test_a_line_that_does_not_show_n_gpus_at_work_is_refused():
+    """`bench.py --gpus N` exits non-zero — after printing the line with the reasons — when the product backend's line does not carry
+    an N-rank RCCL communicator, a collective that took time, and the same workload measured on one GPU."""
+    good = {"n_gpus": 4, "backend": "hip", "value": 40.0, "value_same_workload_1gpu": 10.0, "speedup_vs_1gpu": 4.0,
+            "config": {"volumes": 8, "volumes_per_rank": [2, 2, 2, 2], "rccl_ranks": 4, "gather_us": 31.5, "status": 0}}
+    assert bench.check_multi_gpu_line(good, 4) == []
+    import copy
+    for mutate, word in ((lambda d: d["config"].update(rccl_ranks=0), "rccl_ranks"),
+                         (lambda d: d["config"].update(rccl_ranks=2), "rccl_ranks"),
+                         (lambda d: d["config"].update(gather_us=0.0), "gather_us"),
+                         (lambda d: d.update(speedup_vs_1gpu=None), "speedup_vs_1gpu"),
+                         (lambda d: d.update(value_same_workload_1gpu=None), "speedup_vs_1gpu"),
+                         (lambda d: d.update(n_gpus=1), "n_gpus"),
+                         (lambda d: d["config"].update(volumes_per_rank=[8, 0, 0, 0]), "volumes_per_rank"),
+                         (lambda d: d["config"].update(status=-3), "status")):
+        bad = copy.deepcopy(good)
+        mutate(bad)
+        problems = bench.check_multi_gpu_line(bad, 4)
+        assert problems and any(word in p for p in problems), (word, problems)
+    # a line made through the test seam (gloo, the oracle): no RCCL to show, everything else still required
+    seam = copy.deepcopy(good)
+    seam["backend"] = "test-seam:tests.bench_backend_oracle"
+    seam["config"].update(rccl_ranks=0, gather_us=0.0)
+    assert bench.check_multi_gpu_line(seam, 4) == []
 
 
 def test_seam_refuses_modules_outside_tests(monkeypatch):

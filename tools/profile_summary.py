@@ -4,6 +4,8 @@
   profile_summary.py stats <dir> [n]        -> per-kernel count / total / average duration (+ avg of the last n launches)
   profile_summary.py pmc <dir> [<dir> ...]  -> per-kernel mean of every collected counter
   profile_summary.py traffic <fetch_dir> <write_dir> <n>  -> HBM bytes per launch (last n launches)
+  profile_summary.py timeline <dir> <anchor-kernel> [k]   -> the kernels between the k-th last and the (k-1)-th last launch of the
+                                                             anchor: start / end in us since the anchor's start, queue id
 
 Counters are reported raw; the FETCH_SIZE / WRITE_SIZE -> bytes conversion (KB units, FETCH_SIZE
 x2 for wide reads on gfx950, see tools/pmc_calibrate.py and MI355X_MICROARCH.md) is applied by the
@@ -42,6 +44,24 @@ def stats(d, last_n=0):
             if k in out and len(v) >= last_n:
                 out[k]["avg_us_last_%d" % last_n] = round(sum(tail) / len(tail) / 1e3, 2)
     return dict(sorted(out.items(), key=lambda kv: -kv[1]["total_ns"]))
+
+
+def timeline(d, anchor, back=3):
+    """One steady-state step as the GPU ran it: every kernel dispatch from the `back`-th last launch of `anchor` up to the next
+    one — start and end (us, relative), duration, queue.  Gaps between rows are what the launches of a dependent chain cost."""
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")))
+    rows.sort()
+    idx = [i for i, r in enumerate(rows) if r[2] == anchor]
+    if len(idx) < back + 1:
+        return {"error": "anchor launched %d times" % len(idx)}
+    a, b = idx[-back - 1], idx[-back]
+    t0 = rows[a][0]
+    return {"anchor": anchor, "step_us": round((rows[b][0] - t0) / 1e3, 2),
+            "kernels": [{"name": r[2], "queue": r[3], "start_us": round((r[0] - t0) / 1e3, 2), "end_us": round((r[1] - t0) / 1e3, 2),
+                         "us": round((r[1] - r[0]) / 1e3, 2)} for r in rows[a:b]]}
 
 
 def pmc(dirs):
@@ -98,7 +118,9 @@ def traffic(fetch_dir, write_dir, last_n, bench_line=None):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "traffic":
+    if mode == "timeline":
+        res = timeline(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 3)
+    elif mode == "traffic":
         res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else None)
     else:
         res = stats(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0) if mode == "stats" else pmc(sys.argv[2:])
