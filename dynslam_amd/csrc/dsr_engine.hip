@@ -21,6 +21,13 @@
 #include "k_small.h"
 #include "k_batch.h"
 
+// the volume batch's deferred work (paired render; defined with dsr_batch below, inside its extern "C" block)
+extern "C" {
+int dsri_batch_flush(dsr_batch *b);
+bool dsri_batch_is_live(dsr_batch *b);
+void dsri_batch_drop_deferred(dsr_batch *b);
+}
+
 namespace {
 
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
@@ -605,7 +612,9 @@ int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderState
 
 // ---- the preview branch (dsr_engine::previewBranch): events of the frame, the side stream, the join
 bool preview_branch_default() {
-  static const bool on = !(getenv("DSR_PREVIEW_BRANCH") && atoi(getenv("DSR_PREVIEW_BRANCH")) == 0);
+  // (off by default since the paired render: a cross-queue dependency costs 13-20 us each way and every recorded event ~6 us of the
+  //  fusion chain, profiles/r06g_*timeline.json; the branch still serves a render that finds no deferred tracking render)
+  static const bool on = getenv("DSR_PREVIEW_BRANCH") && atoi(getenv("DSR_PREVIEW_BRANCH")) != 0;
   return on;
 }
 int preview_branch_setup(dsr_engine *e) {  // (lazily: most engines never render on a branch)
@@ -641,6 +650,30 @@ int preview_wait(dsr_engine *e, hipEvent_t early, bool current) {
 int preview_join(dsr_engine *e) {  // the engine's stream continues behind the branch
   HIP_TRY(hipEventRecord(e->evPreview, e->pvStream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->evPreview, 0));
+  return DSR_OK;
+}
+
+// ---- the paired render (dsr_engine::pairRender): the deferred tracking render of one engine
+bool pair_render_default() {
+  static const bool on = !(getenv("DSR_PAIR_RENDER") && atoi(getenv("DSR_PAIR_RENDER")) == 0);
+  return on;
+}
+int launch_icp_maps(dsr_engine *e, const FrameP &p) {
+  RenderStateDev &rs = e->live;
+  dim3 g(div_up(e->W, 16), div_up(e->H, 16));
+  if (rs.rayBox) LAUNCH(e, "icp_maps", k_icp_maps_box, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+                        e->normalsMap, rs.raycastImage, (const int32_t *)rs.rayBox);
+  else LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
+              e->normalsMap, rs.raycastImage);
+  return DSR_OK;
+}
+int flush_track_render(dsr_engine *e) {
+  if (!e->trackRender.pending) return DSR_OK;
+  e->trackRender.pending = false;
+  int st = launch_raycast(e, "raycast", e->trackRender.p, e->live);
+  if (st) return st;
+  if ((st = launch_icp_maps(e, e->trackRender.p))) return st;
+  HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
 
@@ -833,6 +866,15 @@ std::string &dsr_internal::last_error() {
   return message;
 }
 int dsr_internal::engine_set_device(dsr_engine *e) { return set_device(e); }
+int dsr_internal::engine_flush_deferred(dsr_engine *e) {
+  int st = flush_track_render(e);
+  if (st) return st;
+  if (e->ownerBatch) {
+    if (dsri_batch_is_live(e->ownerBatch)) return dsri_batch_flush(e->ownerBatch);
+    e->ownerBatch = nullptr;  // destroyed since
+  }
+  return DSR_OK;
+}
 void dsr_internal::engine_prof_resolve(dsr_engine *e) { prof_resolve(e); }
 
 extern "C" {
@@ -948,6 +990,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
       const size_t withLists = std::max(e->smallLdsBytes, sizeof(SmallShared) + small_lists_lds_bytes(e->noBlocks));
       e->smallLists = withLists <= 64 * 1024 && !(getenv("DSR_SMALL_LISTS") && atoi(getenv("DSR_SMALL_LISTS")) == 0);
       if (e->smallLists) e->smallLdsBytes = withLists;
+      e->pairRender = pair_render_default();  // (takes effect with a range-image box: dsr_prepare)
     }
   }
   ALLOC(dmalloc(&e->allocWork, (size_t)std::min((double)e->noBlocks, (double)e->P * e->maxSteps)));
@@ -1033,6 +1076,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
 void dsr_engine_destroy(dsr_engine *e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  if (e->ownerBatch && dsri_batch_is_live(e->ownerBatch)) dsri_batch_drop_deferred(e->ownerBatch);  // (its deferred work dies with an engine of the batch)
   if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
   if (e->borrowedStream) (void)hipDeviceSynchronize();  // (its owner may have been destroyed already: the handle is not touched)
   else if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -1090,7 +1134,7 @@ int dsr_device_mem_info(int device, uint64_t *free_bytes, uint64_t *total_bytes)
 // ---- stream ordering without host synchronisation (dsr.h)
 
 int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
-  CHECK_E(e);
+  CHECK_E_NOFLUSH(e);  // (deferred work is queued later, i.e. behind this wait as well)
   if (!e->orderEvent) HIP_TRY(hipEventCreateWithFlags(&e->orderEvent, hipEventDisableTiming));  // system scope: the other side is not ours
   HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
@@ -1301,16 +1345,19 @@ int dsr_prepare(dsr_engine *e) {
     int st = expected_depths(e, rs, p);
     if (st) return st;
   }
-  dim3 g(div_up(e->W, 16), div_up(e->H, 16));
   // (Round 4 measured the raycast + ICP maps on the side stream with the next frame's read-only prefix under them: the kernels
   //  overlap and the raycast pays for it, 422 -> 444 us.  Archived: profiles/r05_pruned_variants.diff, r04c_overlap_prepare_ab.log.)
+  if (e->pairRender && rs.rayBox) {
+    // the tracking render waits for the next call: with the preview render it goes out as one launch (dsr_engine::pairRender)
+    e->trackRender.pending = true;
+    e->trackRender.p = p;
+    HIP_TRY(hipGetLastError());
+    return DSR_OK;
+  }
   {
     int st = launch_raycast(e, "raycast", p, rs);
     if (st) return st;
-    if (rs.rayBox) LAUNCH(e, "icp_maps", k_icp_maps_box, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
-                          e->normalsMap, rs.raycastImage, (const int32_t *)rs.rayBox);
-    else LAUNCH(e, "icp_maps", k_icp_maps, g, dim3(256), p, e->scene, (const float4 *)rs.raycastResult, e->pointsMap,
-                e->normalsMap, rs.raycastImage);
+    if ((st = launch_icp_maps(e, p))) return st;
   }
   HIP_TRY(hipGetLastError());
   return DSR_OK;
@@ -1385,6 +1432,15 @@ int dsr_decay(dsr_engine *e, int max_weight, int min_age, int force_all_voxels) 
 
 static int render_common(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out,
                          void *depth_out, bool outIsDevice) {
+  // a deferred tracking render (dsr_prepare) goes out WITH a free-camera render into device buffers; before anything else
+  const bool freeCamera = type >= DSR_IMAGE_FREECAMERA_SHADED && type <= DSR_IMAGE_FREECAMERA_DEPTH;
+  if (!(e->trackRender.pending && freeCamera && outIsDevice && e->smallPath) || !e->hasView) {
+    int st = dsr_internal::engine_flush_deferred(e);
+    if (st) return st;
+  } else if (e->ownerBatch && dsri_batch_is_live(e->ownerBatch)) {
+    int st = dsri_batch_flush(e->ownerBatch);
+    if (st) return st;
+  }
   if (!e->hasView) return fail(DSR_E_NO_VIEW, "no view yet");
   const hipMemcpyKind kind = outIsDevice ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   const size_t P = (size_t)e->P;
@@ -1415,6 +1471,27 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
       dim3 g(div_up(e->W, 16), div_up(e->H, 16));
       const bool cached = e->fvValid && e->fvVersion == e->sceneVersion && memcmp(e->fvM.m, M.m, sizeof M.m) == 0 &&
                           memcmp(e->fvProj, proj, sizeof proj) == 0;
+      if (e->trackRender.pending && cached) { int st = flush_track_render(e); if (st) return st; }
+      if (!cached && e->smallPath && outIsDevice && e->trackRender.pending) {
+        // PAIRED: the free-view list, then the tracking raycast and the preview raycast as ONE launch, then the ICP maps
+        const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
+        {
+          ProfScope _ps(e, "small_freeview");
+          hipLaunchKernelGGL(k_small_freeview, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene, e->allocList,
+                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox, e->smallLists ? 1 : 0);
+        }
+        RenderHalfP fv;
+        fv.minmax = (const float2 *)rs.minmax; fv.raycastResult = rs.raycastResult; fv.outRgba = rs.raycastImage;
+        fv.outDepth = (float *)depth_out; fv.outRgba2 = (uchar4 *)rgba_out; fv.rb = rs.rayBox; fv.type = type;
+        e->trackRender.pending = false;
+        LAUNCH(e, "raycast_pair", k_raycast_pair, dim3(g.x, g.y, 2), dim3(256), e->trackRender.p, p, e->scene,
+               (const float2 *)e->live.minmax, e->live.raycastResult, e->live.rayBox, fv);
+        int st = launch_icp_maps(e, e->trackRender.p);
+        if (st) return st;
+        HIP_TRY(hipGetLastError());
+        e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
+        break;
+      }
       if (!cached && e->smallPath && e->previewBranch && outIsDevice) {
         // the same two kernels on the preview branch (dsr_engine::previewBranch): the list as soon as the frame's allocation is
         // final, the raycast as soon as its integration is — side by side with the tracking render on the engine's stream
@@ -1539,13 +1616,13 @@ extern "C" {
 
 int dsr_get_image(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], uint8_t *rgba_out,
                   float *depth_out) {
-  CHECK_E(e);
+  CHECK_E_NOFLUSH(e);  // (render_common queues or consumes the deferred tracking render itself)
   return render_common(e, type, pose_m, intrinsics, rgba_out, depth_out, false);
 }
 
 int dsr_get_image_dev(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out_dev,
                       void *depth_out_dev) {
-  CHECK_E(e);
+  CHECK_E_NOFLUSH(e);
   return render_common(e, type, pose_m, intrinsics, rgba_out_dev, depth_out_dev, true);
 }
 
@@ -1892,7 +1969,32 @@ struct dsr_batch {
   // every volume the last dsr_batch_fuse's two events stand for
   bool branch = false;
   std::vector<unsigned long long> fusedList, fusedScene;
+  // the paired render of the batch (dsr_engine::pairRender): dsr_batch_fuse defers the tracking render of its volumes; the next
+  // dsr_batch_render sends it out with the preview raycasts as one launch, any other call on an engine of the batch queues it
+  bool pair = false, pendingTrack = false;
+  BatchFrames liveFrames;
+  BatchFrameP *freeTableDev = nullptr;
 };
+namespace {
+std::mutex g_batchMutex;
+std::vector<dsr_batch *> g_liveBatches;  // (an engine's ownerBatch may outlive the batch)
+}
+bool dsri_batch_is_live(dsr_batch *b) {
+  std::lock_guard<std::mutex> lock(g_batchMutex);
+  return std::find(g_liveBatches.begin(), g_liveBatches.end(), b) != g_liveBatches.end();
+}
+void dsri_batch_drop_deferred(dsr_batch *b) { b->pendingTrack = false; }
+int dsri_batch_flush(dsr_batch *b) {
+  if (!b->pendingTrack) return DSR_OK;
+  b->pendingTrack = false;
+  dsr_engine *src = b->source;
+  const int nv = (int)b->vols.size();
+  const dim3 img(div_up(src->W, 16), div_up(src->H, 16), nv);
+  LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), b->liveFrames, (const BatchVolP *)b->volsDev);
+  LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), b->liveFrames, (const BatchVolP *)b->volsDev);
+  HIP_TRY(hipGetLastError());
+  return DSR_OK;
+}
 
 static BatchVolP batch_vol_record(dsr_engine *e) {
   BatchVolP v;
@@ -1950,12 +2052,21 @@ int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volum
   }
   b->branch = preview_branch_default();
   b->fusedList.assign(n_volumes, ~0ull); b->fusedScene.assign(n_volumes, ~0ull);
+  b->pair = pair_render_default();
+  for (int k = 0; k < n_volumes; ++k) b->pair = b->pair && volumes[k]->live.rayBox && volumes[k]->freeview.rayBox;
   if (hipMalloc(reinterpret_cast<void **>(&b->volsDev), sizeof(BatchVolP) * kBatchMax) != hipSuccess ||
-      hipMemcpy(b->volsDev, b->volsHost.data(), sizeof(BatchVolP) * b->vols.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      hipMalloc(reinterpret_cast<void **>(&b->freeTableDev), sizeof(BatchFrameP) * kBatchMax) != hipSuccess ||
+      hipMemcpy(b->volsDev, b->volsHost.data(), sizeof(BatchVolP) * b->vols.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(b->freeTableDev, 0, sizeof(BatchFrameP) * kBatchMax) != hipSuccess) {
     if (b->volsDev) (void)hipFree(b->volsDev);
+    if (b->freeTableDev) (void)hipFree(b->freeTableDev);
     delete b;
     return fail(DSR_E_NOMEM, "batch tables");
   }
+  // calls on any engine of the batch queue the batch's deferred work first (CHECK_E)
+  source->ownerBatch = b;
+  for (dsr_engine *e : b->vols) { e->ownerBatch = b; e->pairRender = false; }  // (rendered through the batch: its own deferral)
+  { std::lock_guard<std::mutex> lock(g_batchMutex); g_liveBatches.push_back(b); }
   *out = b;
   return DSR_OK;
 }
@@ -1964,7 +2075,12 @@ void dsr_batch_destroy(dsr_batch *b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   (void)hipDeviceSynchronize();
+  {  // (deferred work is dropped: the engines may be gone, and nobody can ask for its results through this batch any more)
+    std::lock_guard<std::mutex> lock(g_batchMutex);
+    g_liveBatches.erase(std::remove(g_liveBatches.begin(), g_liveBatches.end(), b), g_liveBatches.end());
+  }
   (void)hipFree(b->volsDev);
+  (void)hipFree(b->freeTableDev);
   delete b;
 }
 
@@ -2074,8 +2190,13 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
     for (int v = 0; v < nv; ++v)
       if (itemOf[v] >= 0) { b->fusedList[v] = b->vols[v]->listVersion; b->fusedScene[v] = b->vols[v]->sceneVersion; }
   }
-  LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
-  LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
+  if (b->pair) {  // the tracking render goes out with the preview raycasts of the next dsr_batch_render, or with the next other call
+    b->pendingTrack = true;
+    b->liveFrames = frames;
+  } else {
+    LAUNCH(src, "batch_raycast", k_batch_raycast, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
+    LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, img, dim3(256), frames, (const BatchVolP *)b->volsDev);
+  }
   HIP_TRY(hipGetLastError());
   if (status_out) {
     for (int i = 0; i < n_items; ++i) status_out[i] = DSR_OK;
@@ -2098,7 +2219,8 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
 int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items, int n_items) {
   if (!b || !items || n_items <= 0) return fail(DSR_E_ARG, "bad batch arguments");
   dsr_engine *src = b->source;
-  CHECK_E(src);
+  CHECK_E_NOFLUSH(src);  // (the batch's deferred tracking render is consumed below)
+  { int st0 = flush_track_render(src); if (st0) return st0; }
   if (type < DSR_IMAGE_FREECAMERA_SHADED || type > DSR_IMAGE_FREECAMERA_DEPTH) return fail(DSR_E_ARG, "unsupported image type");
   const int nv = (int)b->vols.size();
   int st = batch_refresh(b);
@@ -2125,6 +2247,22 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
   }
   if (!any) return DSR_OK;
   const int cells = ((src->W + 7) / 8) * ((src->H + 7) / 8);
+  if (b->pendingTrack) {
+    // PAIRED: the free-view lists, then the tracking raycasts and the preview raycasts of every volume as ONE launch, then the
+    // ICP maps (k_batch.h k_batch_raycast_pair)
+    {
+      ProfScope _ps(src, "batch_small_freeview");
+      hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, frames,
+                         (const BatchVolP *)b->volsDev, b->freeTableDev);
+    }
+    b->pendingTrack = false;
+    LAUNCH(src, "batch_raycast_pair", k_batch_raycast_pair, dim3(div_up(src->W, 16), div_up(src->H, 16), 2 * nv), dim3(256),
+           b->liveFrames, (const BatchFrameP *)b->freeTableDev, (const BatchVolP *)b->volsDev, nv);
+    LAUNCH(src, "batch_icp_maps", k_batch_icp_maps, dim3(div_up(src->W, 16), div_up(src->H, 16), nv), dim3(256), b->liveFrames,
+           (const BatchVolP *)b->volsDev);
+    HIP_TRY(hipGetLastError());
+    return DSR_OK;
+  }
   if (b->branch) {
     // the two preview kernels on the source engine's preview branch (dsr_engine::previewBranch): the lists behind the frame's
     // allocation, the raycasts behind its integration — next to the tracking render the fusion call queued on the main stream
@@ -2140,7 +2278,7 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
       StreamSwap sw(src, src->pvStream);
       ProfScope _ps(src, "batch_small_freeview");
       hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, frames,
-                         (const BatchVolP *)b->volsDev);
+                         (const BatchVolP *)b->volsDev, (BatchFrameP *)nullptr);
     }
     if ((st = preview_wait(src, src->evFused, sceneCurrent))) return st;
     {
@@ -2154,7 +2292,7 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
   {
     ProfScope _ps(src, "batch_small_freeview");
     hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, frames,
-                       (const BatchVolP *)b->volsDev);
+                       (const BatchVolP *)b->volsDev, (BatchFrameP *)nullptr);
   }
   LAUNCH(src, "batch_raycast_render", k_batch_raycast_render, dim3(div_up(src->W, 16), div_up(src->H, 16), nv), dim3(256),
          frames, (const BatchVolP *)b->volsDev);

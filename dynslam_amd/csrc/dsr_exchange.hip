@@ -86,6 +86,7 @@ struct dsr_exchange {
     uint8_t *all = nullptr;                 // gathered layers
     uchar4 *targetRgba = nullptr;           // the exchange's own composite target (lazily)
     float *targetDepth = nullptr;
+    bool targetClearPending = false;        // dsr_exchange_clear_target: folded into the next composite over this target
     ncclComm_t comm = nullptr;
   };
   std::vector<Dev> devs;                    // local GPUs
@@ -185,10 +186,21 @@ int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_
   return DSR_OK;
 }
 
+static int composite_layer_ptrs(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
+                                const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
+                                int dim_background, int clear_target);
 int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
                                  const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
                                  const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
                                  int dim_background) {
+  return composite_layer_ptrs(device, hip_stream, target_rgba_dev, target_depth_dev, layer_rgba_ptrs, layer_depth_ptrs, track_ids,
+                              n_layers, n_pixels, tint_strength, dim_background, 0);
+}
+static int composite_layer_ptrs(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
+                                const void *const *layer_rgba_ptrs, const void *const *layer_depth_ptrs,
+                                const int32_t *track_ids, int n_layers, int n_pixels, float tint_strength,
+                                int dim_background, int clear_target) {
   if (!target_depth_dev || n_layers < 0 || n_pixels <= 0) return fail(DSR_E_ARG, "bad composite arguments");
   if (n_layers > 0 && (!layer_depth_ptrs || !track_ids || (target_rgba_dev && !layer_rgba_ptrs)))
     return fail(DSR_E_ARG, "null layer buffers");
@@ -201,7 +213,8 @@ int dsr_composite_layer_ptrs_dev(int device, void *hip_stream, void *target_rgba
     if (!lp.depth[l] || (target_rgba_dev && !lp.rgba[l])) return fail(DSR_E_ARG, "null layer buffers");
   }
   if (device >= 0) HIP_TRY(hipSetDevice(device));
-  const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
+  c.clearTarget = clear_target;
   if (composite_px_per_lane() == 2)
     hipLaunchKernelGGL((k_composite<true, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
                        (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
@@ -456,11 +469,13 @@ int dsr_exchange_timing(dsr_exchange *x, int enable, double *gather_ms, double *
   return DSR_OK;
 }
 
+static int materialise_target_clear(dsr_exchange *x, dsr_exchange::Dev *d);
 int dsr_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba_dev, void **depth_dev) {
   dsr_exchange::Dev *d = local_dev(x, rank);
   if (!d) return fail(DSR_E_ARG, "bad exchange rank");
   int st = exchange_target(x, d);
   if (st) return st;
+  if ((st = materialise_target_clear(x, d))) return st;  // (the caller is about to look at the buffers)
   if (rgba_dev) *rgba_dev = d->targetRgba;
   if (depth_dev) *depth_dev = d->targetDepth;
   return DSR_OK;
@@ -471,6 +486,16 @@ int dsr_exchange_clear_target(dsr_exchange *x, int rank) {
   if (!d) return fail(DSR_E_ARG, "bad exchange rank");
   int st = exchange_target(x, d);
   if (st) return st;
+  // Folded into the next composite over this target (k_composite's clearTarget: the target is not read, every pixel is written):
+  // two memsets per frame on the exchange's stream ran NEXT to the following frame's fusion kernels and slowed them
+  // (k_batch_alloc_mark 21 -> 76 us under a 54 us fill, profiles/r06g_batch_step_timeline.json).  Anything else that looks at
+  // the target first (dsr_exchange_read_target, _target_ptrs) performs the clear.
+  d->targetClearPending = true;
+  return DSR_OK;
+}
+static int materialise_target_clear(dsr_exchange *x, dsr_exchange::Dev *d) {
+  if (!d->targetClearPending) return DSR_OK;
+  d->targetClearPending = false;
   HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipMemsetAsync(d->targetRgba, 0, (size_t)x->P * 4, d->stream));
   HIP_TRY(hipMemsetAsync(d->targetDepth, 0, (size_t)x->P * 4, d->stream));
@@ -491,6 +516,13 @@ int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_en
     if ((st = exchange_target(x, d))) return st;
     target_rgba_dev = d->targetRgba; target_depth_dev = d->targetDepth;
   }
+  // a pending dsr_exchange_clear_target of the exchange's own target: done by the composite itself, or — nothing to composite —
+  // by the memsets it stands for
+  int clearTarget = 0;
+  if (d->targetClearPending && target_depth_dev == d->targetDepth && (target_rgba_dev == d->targetRgba || !target_rgba_dev)) {
+    if (n_layers > 0 && target_rgba_dev) { clearTarget = 1; d->targetClearPending = false; }
+    else if ((st = materialise_target_clear(x, d))) return st;
+  }
   if (target_engine) {
     if (target_engine->device != d->device) return fail(DSR_E_ARG, "the target's engine does not live on the root's GPU");
     if ((st = dsr_stream_wait_for_engine(target_engine, d->stream))) return st;  // its render of the target
@@ -505,8 +537,8 @@ int dsr_exchange_composite(dsr_exchange *x, int root_rank, dsr_engine *target_en
   if (n_layers > 0) {
     HIP_TRY(hipSetDevice(d->device));
     timed_begin(x, *d, 1, devIndex);
-    if ((st = dsr_composite_layer_ptrs_dev(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
-                                           track_ids, n_layers, x->P, tint_strength, dim_background)))
+    if ((st = composite_layer_ptrs(d->device, d->stream, target_rgba_dev, target_depth_dev, target_rgba_dev ? rp : nullptr, dp,
+                                   track_ids, n_layers, x->P, tint_strength, dim_background, clearTarget)))
       return st;
     timed_end(x, *d, 1, devIndex);
   }
@@ -529,6 +561,7 @@ int dsr_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float
   if (!d) return fail(DSR_E_ARG, "bad exchange rank");
   int st = exchange_target(x, d);
   if (st) return st;
+  if ((st = materialise_target_clear(x, d))) return st;
   HIP_TRY(hipSetDevice(d->device));
   if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, d->targetRgba, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));
   if (depth_out) HIP_TRY(hipMemcpyAsync(depth_out, d->targetDepth, (size_t)x->P * 4, hipMemcpyDeviceToHost, d->stream));

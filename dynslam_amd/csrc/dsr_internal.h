@@ -237,6 +237,16 @@ struct dsr_engine {
   hipEvent_t evAlloc = nullptr, evFused = nullptr, evPreview = nullptr, evNow = nullptr;
   unsigned long long evAllocList = ~0ull, evFusedScene = ~0ull;  // the listVersion / sceneVersion the two events stand for
 
+  // PAIRED RENDER (round 6; instance-sized volumes).  dsr_prepare's tracking render (k_raycast_box + k_icp_maps_box) is not queued
+  // at once: it is DEFERRED until the next call on this engine.  When that call is the preview render (dsr_get_image_dev /
+  // dsr_exchange_render_slot) — the reference's order per instance: Integrate, PrepareNextStep, later GetImage from the GUI's
+  // camera — both raycasts go out as ONE launch (k_raycast.h k_raycast_pair) and overlap on one queue; any other call
+  // (CHECK_E below) queues the deferred work first, so no caller ever sees a stream without it.  What the pending launch needs is
+  // kept here: the camera of the prepare call.  env DSR_PAIR_RENDER=0: off.
+  bool pairRender = false;
+  struct { bool pending = false; FrameP p; } trackRender;
+  struct dsr_batch *ownerBatch = nullptr;  // the volume batch this engine is a source / volume of (it may hold deferred work too)
+
   // profiling
   int profiling = 0;  // 0 off, 1 every kernel, 2 the two dominant kernels only
   std::vector<ProfRec> profRecs;
@@ -249,6 +259,7 @@ struct dsr_engine {
 namespace dsr_internal {
 // dsr_engine.hip
 int engine_set_device(dsr_engine *e);
+int engine_flush_deferred(dsr_engine *e);  // queue what dsr_prepare / dsr_batch_fuse deferred (paired render)
 void engine_prof_resolve(dsr_engine *e);
 int engine_render(dsr_engine *e, int type, const float pose_m[16], const float intrinsics[4], void *rgba_out, void *depth_out,
                   bool outIsDevice);
@@ -265,6 +276,11 @@ int device_alloc(T **p, size_t n) {
 using dsr_internal::host_range_pinned;
 using dsr_internal::short_division_exact;
 
-#define CHECK_E(e)                                          \
+// entry of (nearly) every engine call: the engine's GPU becomes current and work this engine — or the batch it belongs to — has
+// deferred (paired render) is queued; CHECK_E_NOFLUSH: the few calls that consume the deferred work or cannot be affected by it
+#define CHECK_E_NOFLUSH(e)                                  \
   if (!(e)) return fail(DSR_E_ARG, "null engine");          \
   { int _st = dsr_internal::engine_set_device(e); if (_st) return _st; }
+#define CHECK_E(e)                                          \
+  CHECK_E_NOFLUSH(e)                                        \
+  if ((e)->trackRender.pending || (e)->ownerBatch) { int _st = dsr_internal::engine_flush_deferred(e); if (_st) return _st; }

@@ -160,9 +160,17 @@ __global__ __launch_bounds__(256) void k_batch_icp_maps(const BatchFrames frames
 }
 
 // ---- the preview: free-view list + range image, then the raycast that shades its own pixels, of every active volume
+// frameTable (may be null): the volume's record of THIS call is also left in HBM for the paired render that follows — two
+// BatchFrames do not fit one launch's kernel arguments (k_batch_raycast_pair)
 __global__ __launch_bounds__(kSmallThreads) void k_batch_small_freeview(const BatchFrames frames,
-                                                                        const BatchVolP *__restrict__ vols) {
+                                                                        const BatchVolP *__restrict__ vols,
+                                                                        BatchFrameP *__restrict__ frameTable) {
   const BatchFrameP &f = frames.f[blockIdx.x];
+  if (frameTable) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&frames.f[blockIdx.x]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(frameTable + blockIdx.x);
+    if (threadIdx.x < sizeof(BatchFrameP) / 4) dst[threadIdx.x] = src[threadIdx.x];
+  }
   if (!f.active) return;
   const BatchVolP &v = vols[blockIdx.x];
   small_freeview_body(f.p, v.s, v.allocList, v.fvVisibleIDs, v.fvVisBlocks, v.noBlocks, v.fvMinmax, v.fvRayBox, v.lists);
@@ -194,6 +202,25 @@ __global__ __launch_bounds__(256) void k_batch_raycast_render(const BatchFrames 
   v.fvRaycastImage[locId] = out;
   if (f.outRgba) f.outRgba[locId] = out;
   if (f.outDepth) f.outDepth[locId] = render_depth(f.p, pt);
+}
+
+// k_raycast_pair for a batch: blockIdx.z < nv is k_batch_raycast of volume z (this frame's fusion cameras, kernel arguments),
+// blockIdx.z >= nv is k_batch_raycast_render of volume z - nv (the preview cameras, from the table k_batch_small_freeview left)
+__global__ __launch_bounds__(256) void k_batch_raycast_pair(const BatchFrames live, const BatchFrameP *__restrict__ freeTable,
+                                                            const BatchVolP *__restrict__ vols, int nv) {
+  __shared__ int s_blocks[256][9];
+  if ((int)blockIdx.z < nv) {
+    const BatchFrameP &f = live.f[blockIdx.z];
+    if (!f.active) return;
+    const BatchVolP &v = vols[blockIdx.z];
+    raycast_box_tile(f.p, v.s, CTR_NO_VISIBLE_LIVE, reinterpret_cast<const float2 *>(v.minmax), v.raycastResult, v.rayBox, blockIdx.x, blockIdx.y);
+  } else {
+    const BatchFrameP &f = freeTable[blockIdx.z - nv];
+    if (!f.active) return;
+    const BatchVolP &v = vols[blockIdx.z - nv];
+    raycast_render_tile(f.p, v.s, reinterpret_cast<const float2 *>(v.fvMinmax), v.fvRaycastResult, f.type, v.fvRaycastImage, f.outDepth,
+                        f.outRgba, v.fvRayBox, blockIdx.x, blockIdx.y, s_blocks[threadIdx.x]);
+  }
 }
 
 }  // namespace dsr

@@ -18,6 +18,7 @@ constexpr int kMaxCompositeLayers = 64;
 struct CompositeP {
   int nLayers, nPixels, dimBackground;
   float tintStrength;
+  int clearTarget;  // the target counts as empty (colour 0, depth 0) and is not read: dsr_exchange_clear_target folded into the composite
   uchar4 tint[kMaxCompositeLayers];  // kMatplotlib2Palette[track_id % 10], resolved on the host
 };
 struct CompositeLayers {  // one (colour, depth) pointer pair per layer: the layers stay where the all-gather left them
@@ -70,10 +71,10 @@ template <bool PTRS>
 __host__ __device__ __forceinline__ void composite_px(int i, const CompositeP &c, uchar4 *__restrict__ tRgba, float *__restrict__ tDepth,
                                                       const uchar4 *__restrict__ lRgba, const float *__restrict__ lDepth,
                                                       const CompositeLayers &lp) {
-  float t = tDepth[i];
+  float t = c.clearTarget ? 0.0f : tDepth[i];
   uchar4 col = make_uchar4(0, 0, 0, 0);
   if (tRgba) {
-    col = tRgba[i];
+    if (!c.clearTarget) col = tRgba[i];
     if (c.dimBackground) col = composite_dim(col);
   }
   int winner = -1;
@@ -117,8 +118,11 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
   }
   typedef CompVec<PX> Vec;
   auto depth_of = [&](int l) { return PTRS ? lp.depth[l] + i0 : lDepth + (size_t)l * c.nPixels + i0; };
+  const bool clr = c.clearTarget != 0;  // (uniform) nothing of the target is read, every pixel of it is written
   float t[PX];
-  {
+#pragma unroll
+  for (int k = 0; k < PX; ++k) t[k] = 0.0f;
+  if (!clr) {
     const Vec t4 = *reinterpret_cast<const Vec *>(tDepth + i0);
 #pragma unroll
     for (int k = 0; k < PX; ++k) t[k] = t4.v[k];
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
   uint32_t colRaw[PX];
 #pragma unroll
   for (int k = 0; k < PX; ++k) colRaw[k] = 0u;
-  if (tRgba) {
+  if (tRgba && !clr) {
     const CompVec<PX> raw = *reinterpret_cast<const CompVec<PX> *>(tRgba + i0);  // (bit pattern only)
 #pragma unroll
     for (int k = 0; k < PX; ++k) colRaw[k] = __float_as_uint(raw.v[k]);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
 #pragma unroll
   for (int k = 0; k < PX; ++k) andW &= winner[k];
   const bool won = andW >= 0;  // some pixel of this lane changed
-  if (won) {
+  if (won || clr) {
     Vec o;
 #pragma unroll
     for (int k = 0; k < PX; ++k) o.v[k] = t[k];
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void k_composite(CompositeP c, uchar4 *__restr
     for (int k = 0; k < PX; ++k)
       if (winner[k] >= 0) col[k] = composite_tinted(col[k], sc[k], sTint[winner[k]], c.tintStrength);
   }
-  if (!c.dimBackground && !won) return;  // nothing of this lane's colours changed
+  if (!c.dimBackground && !won && !clr) return;  // nothing of this lane's colours changed
   CompVec<PX> out;
 #pragma unroll
   for (int k = 0; k < PX; ++k)

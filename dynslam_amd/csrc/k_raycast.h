@@ -681,20 +681,25 @@ __global__ __launch_bounds__(256, 8) void k_raycast(FrameP p, SceneP s, int ctrI
 #endif
 }
 
-// k_raycast for a volume whose range image carries a box (see RB_*): tiles outside DIRTY keep their miss
-__global__ __launch_bounds__(256, 8) void k_raycast_box(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
-                                                        float4 *__restrict__ raycastResult, int32_t *__restrict__ rb) {
+// k_raycast for a volume whose range image carries a box (see RB_*): tiles outside DIRTY keep their miss.
+// (the body, by one 16x16-pixel workgroup (wgx, wgy): the kernel below, or the live half of k_raycast_pair)
+__device__ __forceinline__ void raycast_box_tile(const FrameP &p, const SceneP &s, int ctrIdx, const float2 *__restrict__ minmax,
+                                                 float4 *__restrict__ raycastResult, int32_t *__restrict__ rb, int wgx, int wgy) {
   if (s.ctr[ctrIdx] <= 0 && ctrIdx == CTR_NO_VISIBLE_LIVE) return;  // Prepare() is skipped without visible blocks
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
-  if (!raybox_tile(rb, RB_DIRTY, blockIdx.x, blockIdx.y)) return;
+  if (wgx == 0 && wgy == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
+  if (!raybox_tile(rb, RB_DIRTY, wgx, wgy)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int x = wgx * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = wgy * 16 + (wave >> 1) * 8 + (lane >> 3);
   if (x >= p.W || y >= p.H) return;
   const int mw = (p.W + kMinmaxSubsample - 1) / kMinmaxSubsample;
   const float2 mm = minmax[(x >> 3) + (y >> 3) * mw];
   RC_STAT(RcStats st;)
   raycastResult[x + y * p.W] = cast_ray<DeviceOps>(p, s, x, y, mm RC_STAT(, st));
+}
+__global__ __launch_bounds__(256, 8) void k_raycast_box(FrameP p, SceneP s, int ctrIdx, const float2 *__restrict__ minmax,
+                                                        float4 *__restrict__ raycastResult, int32_t *__restrict__ rb) {
+  raycast_box_tile(p, s, ctrIdx, minmax, raycastResult, rb, blockIdx.x, blockIdx.y);
 }
 
 // dsr_dump_render_state: the miss pixels outside the last raycast's box get the value that raycast would have written — the
@@ -1014,17 +1019,17 @@ __global__ __launch_bounds__(256) void k_render(FrameP p, SceneP s, int type, co
 // 34.4 + 12.2 us as two launches, 38.1 us as one.
 // rb (may be null): the range image's box record — outside DIRTY the engine's own buffers (raycastResult, outRgba) keep their
 // miss, the CALLER's buffers (outDepth, outRgba2) get it written.
-__global__ __launch_bounds__(256) void k_raycast_render(FrameP p, SceneP s, const float2 *__restrict__ minmax,
-                                                        float4 *__restrict__ raycastResult, int type, uchar4 *__restrict__ outRgba,
-                                                        float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2,
-                                                        int32_t *__restrict__ rb) {
-  __shared__ int s_blocks[256][9];
+// (the body, by one 16x16-pixel workgroup: the kernel below, or the preview half of k_raycast_pair)
+__device__ __forceinline__ void raycast_render_tile(const FrameP &p, const SceneP &s, const float2 *__restrict__ minmax,
+                                                    float4 *__restrict__ raycastResult, int type, uchar4 *__restrict__ outRgba,
+                                                    float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2,
+                                                    int32_t *__restrict__ rb, int wgx, int wgy, int *__restrict__ bptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-  const int y = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const int x = wgx * 16 + (wave & 1) * 8 + (lane & 7);
+  const int y = wgy * 16 + (wave >> 1) * 8 + (lane >> 3);
   if (rb) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
-    if (!raybox_tile(rb, RB_DIRTY, blockIdx.x, blockIdx.y)) {
+    if (wgx == 0 && wgy == 0 && threadIdx.x == 0) raybox_mark_ran(rb, p);
+    if (!raybox_tile(rb, RB_DIRTY, wgx, wgy)) {
       if (x >= p.W || y >= p.H) return;
       if (outRgba2) outRgba2[x + y * p.W] = make_uchar4(0, 0, 0, 0);
       if (outDepth) outDepth[x + y * p.W] = 0.0f;
@@ -1038,10 +1043,40 @@ __global__ __launch_bounds__(256) void k_raycast_render(FrameP p, SceneP s, cons
   const float4 pt = cast_ray<DeviceOps>(p, s, x, y, mm RC_STAT(, st));
   const int locId = x + y * p.W;
   raycastResult[locId] = pt;
-  const uchar4 out = render_pixel<DeviceOps>(p, s, type, pt, s_blocks[threadIdx.x]);
+  const uchar4 out = render_pixel<DeviceOps>(p, s, type, pt, bptr);
   if (outRgba) outRgba[locId] = out;
   if (outRgba2) outRgba2[locId] = out;
   if (outDepth) outDepth[locId] = render_depth(p, pt);
+}
+__global__ __launch_bounds__(256) void k_raycast_render(FrameP p, SceneP s, const float2 *__restrict__ minmax,
+                                                        float4 *__restrict__ raycastResult, int type, uchar4 *__restrict__ outRgba,
+                                                        float *__restrict__ outDepth, uchar4 *__restrict__ outRgba2,
+                                                        int32_t *__restrict__ rb) {
+  __shared__ int s_blocks[256][9];
+  raycast_render_tile(p, s, minmax, raycastResult, type, outRgba, outDepth, outRgba2, rb, blockIdx.x, blockIdx.y, s_blocks[threadIdx.x]);
+}
+
+// The tracking render and the preview render of ONE frame of an instance-sized volume in ONE launch (round 6).  Both are chains
+// of dependent gathers for a few hundred live rays in a frame of 465 k pixels: one after the other they cost 25 + 27 us of an
+// instance frame, side by side the time of one.  Two streams do not get there — a cross-queue dependency costs 13-20 us each
+// way on this part (profiles/r06g_*timeline.json) —, one grid does: blockIdx.z = 0 is k_raycast_box for the live render state,
+// 1 is k_raycast_render for the free camera.  The engine defers the tracking render of dsr_prepare until the next call; when
+// that call is the preview render, both go out together (dsr_engine.hip "paired render").
+struct RenderHalfP {  // the free-camera half's buffers
+  const float2 *minmax;
+  float4 *raycastResult;
+  uchar4 *outRgba;
+  float *outDepth;
+  uchar4 *outRgba2;
+  int32_t *rb;
+  int type;
+};
+__global__ __launch_bounds__(256) void k_raycast_pair(FrameP pLive, FrameP pFree, SceneP s, const float2 *__restrict__ minmaxLive,
+                                                      float4 *__restrict__ raycastResultLive, int32_t *__restrict__ rbLive, RenderHalfP fv) {
+  __shared__ int s_blocks[256][9];
+  if (blockIdx.z == 0) raycast_box_tile(pLive, s, CTR_NO_VISIBLE_LIVE, minmaxLive, raycastResultLive, rbLive, blockIdx.x, blockIdx.y);
+  else raycast_render_tile(pFree, s, fv.minmax, fv.raycastResult, fv.type, fv.outRgba, fv.outDepth, fv.outRgba2, fv.rb, blockIdx.x,
+                           blockIdx.y, s_blocks[threadIdx.x]);
 }
 
 }  // namespace dsr

@@ -62,7 +62,9 @@ def main():
                       PoseArg(np.linalg.inv(rel.astype(np.float64)).astype(np.float32))))
     out_rgba = torch.zeros((W * H, 4), dtype=torch.uint8, device=dev)
     out_depth = torch.zeros((W * H,), dtype=torch.float32, device=dev)
-    names_a = ["lds_init+A(tile scan)", "B(commit)", "D0(touched groups)", "C(apply)", "D(retest prev)", "E", "F(sweep visBits)",
+    # (on the list path — round 6 — D0 / D / E / G are skipped and "F" is M + H: the merge of the frame's new entries and the dense pass
+    #  over the sorted list with the ordered compaction, the stream and the range image)
+    names_a = ["lds_init+A(tile scan)", "B(commit)", "D0(touched groups)", "C(apply)", "D(retest prev)", "E", "F(sweep visBits) | M+H(list path)",
                "G(stream+project+fold)", "store range image"]
     names_f = ["lds_init+sweep allocBits", "frustum+scan+project+fold", "ctr", "store range image"]
     acc_a, acc_f, acc_f2, n = np.zeros(9), np.zeros(4), np.zeros(4), 0
