@@ -112,7 +112,6 @@ void prof_resolve(dsr_engine *e) {
   if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
   (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
-  if (e->pvStream) (void)hipStreamSynchronize(e->pvStream);
   if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
   for (auto &p : e->profPending) {
     float ms = 0.0f;
@@ -259,8 +258,6 @@ void free_all(dsr_engine *e) {
   for (auto ev : e->eventPool) (void)hipEventDestroy(ev);
   if (e->evList) (void)hipEventDestroy(e->evList);
   if (e->evExpected) (void)hipEventDestroy(e->evExpected);
-  for (hipEvent_t ev : {e->evAlloc, e->evFused, e->evPreview, e->evNow}) if (ev) (void)hipEventDestroy(ev);
-  if (e->pvStream) (void)hipStreamDestroy(e->pvStream);
   if (e->sideStream) (void)hipStreamDestroy(e->sideStream);
   if (e->stream && e->ownsStream) (void)hipStreamDestroy(e->stream);
 }
@@ -478,8 +475,6 @@ int convert_view(dsr_engine *e, const void *rgbDev, const void *depthDev, bool u
 
 // AllocateSceneFromDepth: mark -> ordered commit -> ordered visible list
 int expected_depths(dsr_engine *e, RenderStateDev &rs, const FrameP &p);
-int preview_mark_alloc(dsr_engine *e);
-int preview_mark_fused(dsr_engine *e);
 
 int allocate_scene(dsr_engine *e) {
   e->sceneVersion++;
@@ -508,7 +503,6 @@ int allocate_scene(dsr_engine *e) {
                          e->statusDev, e->statusSeq, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox, e->smallLists ? 1 : 0);
     }
     HIP_TRY(hipGetLastError());
-    { int st = preview_mark_alloc(e); if (st) return st; }
     { int st = after_fusion(e); if (st) return st; }
     e->liveExp.valid = true; e->liveExp.onSide = false; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
     memcpy(e->liveExp.proj, proj, sizeof proj);
@@ -574,7 +568,6 @@ int integrate_scene(dsr_engine *e) {
 #undef LAUNCH_INTEGRATE_V
 #undef LAUNCH_INTEGRATE
   HIP_TRY(hipGetLastError());
-  { int st = preview_mark_fused(e); if (st) return st; }
   return after_fusion(e);
 }
 
@@ -607,49 +600,6 @@ int launch_raycast(dsr_engine *e, const char *name, const FrameP &p, RenderState
   dim3 g(div_up(e->W, 16), div_up(e->H, 16));
   if (rs.rayBox) LAUNCH(e, name, k_raycast_box, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult, rs.rayBox);
   else LAUNCH(e, name, k_raycast, g, dim3(256), p, e->scene, rs.ctrIdx, (const float2 *)rs.minmax, rs.raycastResult);
-  return DSR_OK;
-}
-
-// ---- the preview branch (dsr_engine::previewBranch): events of the frame, the side stream, the join
-bool preview_branch_default() {
-  // (off by default since the paired render: a cross-queue dependency costs 13-20 us each way and every recorded event ~6 us of the
-  //  fusion chain, profiles/r06g_*timeline.json; the branch still serves a render that finds no deferred tracking render)
-  static const bool on = getenv("DSR_PREVIEW_BRANCH") && atoi(getenv("DSR_PREVIEW_BRANCH")) != 0;
-  return on;
-}
-int preview_branch_setup(dsr_engine *e) {  // (lazily: most engines never render on a branch)
-  if (e->pvStream) return DSR_OK;
-  HIP_TRY(create_stream(&e->pvStream));
-  for (hipEvent_t *ev : {&e->evAlloc, &e->evFused, &e->evPreview, &e->evNow}) { int st = make_event(ev); if (st) return st; }
-  return DSR_OK;
-}
-// the frame's two events, recorded on the engine's stream by the fusion calls of an engine with the branch enabled
-int preview_mark_alloc(dsr_engine *e) {
-  if (!e->previewBranch) return DSR_OK;
-  int st = preview_branch_setup(e);
-  if (st) return st;
-  HIP_TRY(hipEventRecord(e->evAlloc, e->stream));
-  e->evAllocList = e->listVersion;
-  return DSR_OK;
-}
-int preview_mark_fused(dsr_engine *e) {
-  if (!e->previewBranch) return DSR_OK;
-  int st = preview_branch_setup(e);
-  if (st) return st;
-  HIP_TRY(hipEventRecord(e->evFused, e->stream));
-  e->evFusedScene = e->sceneVersion;
-  return DSR_OK;
-}
-// the branch waits for `early` when it still stands for the current state (`current`), else for the stream as it is now
-int preview_wait(dsr_engine *e, hipEvent_t early, bool current) {
-  if (current) { HIP_TRY(hipStreamWaitEvent(e->pvStream, early, 0)); return DSR_OK; }
-  HIP_TRY(hipEventRecord(e->evNow, e->stream));
-  HIP_TRY(hipStreamWaitEvent(e->pvStream, e->evNow, 0));
-  return DSR_OK;
-}
-int preview_join(dsr_engine *e) {  // the engine's stream continues behind the branch
-  HIP_TRY(hipEventRecord(e->evPreview, e->pvStream));
-  HIP_TRY(hipStreamWaitEvent(e->stream, e->evPreview, 0));
   return DSR_OK;
 }
 
@@ -1081,7 +1031,6 @@ void dsr_engine_destroy(dsr_engine *e) {
   if (e->borrowedStream) (void)hipDeviceSynchronize();  // (its owner may have been destroyed already: the handle is not touched)
   else if (e->stream) (void)hipStreamSynchronize(e->stream);
   if (e->sideStream) (void)hipStreamSynchronize(e->sideStream);
-  if (e->pvStream) (void)hipStreamSynchronize(e->pvStream);
   if (e->device >= 0 && e->device < 64 && g_ioStream[e->device]) (void)hipStreamSynchronize(g_ioStream[e->device]);
   if (e->device < 64) g_enginesOnDevice[e->device].fetch_sub(1);
   free_all(e);
@@ -1098,7 +1047,6 @@ int dsr_sync(dsr_engine *e) {
   if (e->viewStream) HIP_TRY(hipStreamSynchronize(e->viewStream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   if (e->sideStream) HIP_TRY(hipStreamSynchronize(e->sideStream));
-  if (e->pvStream) HIP_TRY(hipStreamSynchronize(e->pvStream));
   return DSR_OK;
 }
 
@@ -1139,9 +1087,6 @@ int dsr_wait_for_stream(dsr_engine *e, void *hip_stream) {
   HIP_TRY(hipEventRecord(e->orderEvent, (hipStream_t)hip_stream));
   HIP_TRY(hipStreamWaitEvent(e->stream, e->orderEvent, 0));
   if (e->pipelinedView) HIP_TRY(hipStreamWaitEvent(e->viewStream, e->orderEvent, 0));  // "_dev" view inputs are read there
-  // ... and the preview branch: its kernels write the caller's buffers (an exchange slot the other stream may still be reading)
-  // and wait for events recorded on the engine's stream BEFORE this call
-  if (e->pvStream) HIP_TRY(hipStreamWaitEvent(e->pvStream, e->orderEvent, 0));
   return DSR_OK;
 }
 
@@ -1489,30 +1434,6 @@ static int render_common(dsr_engine *e, int type, const float pose_m[16], const 
         int st = launch_icp_maps(e, e->trackRender.p);
         if (st) return st;
         HIP_TRY(hipGetLastError());
-        e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
-        break;
-      }
-      if (!cached && e->smallPath && e->previewBranch && outIsDevice) {
-        // the same two kernels on the preview branch (dsr_engine::previewBranch): the list as soon as the frame's allocation is
-        // final, the raycast as soon as its integration is — side by side with the tracking render on the engine's stream
-        int st = preview_branch_setup(e);
-        if (st) return st;
-        const int cells = ((e->W + 7) / 8) * ((e->H + 7) / 8);
-        if ((st = preview_wait(e, e->evAlloc, e->evAllocList == e->listVersion))) return st;
-        {
-          StreamSwap sw(e, e->pvStream);
-          ProfScope _ps(e, "small_freeview");
-          hipLaunchKernelGGL(k_small_freeview, dim3(1), dim3(kSmallThreads), small_lds_bytes(cells), e->stream, p, e->scene, e->allocList,
-                             rs.visibleIDs, rs.visBlocks, e->noBlocks, reinterpret_cast<int2 *>(rs.minmax), rs.rayBox, e->smallLists ? 1 : 0);
-        }
-        if ((st = preview_wait(e, e->evFused, e->evFusedScene == e->sceneVersion))) return st;
-        {
-          StreamSwap sw(e, e->pvStream);
-          LAUNCH(e, "raycast_freeview", k_raycast_render, g, dim3(256), p, e->scene, (const float2 *)rs.minmax,
-                 rs.raycastResult, type, rs.raycastImage, (float *)depth_out, (uchar4 *)rgba_out, rs.rayBox);
-        }
-        HIP_TRY(hipGetLastError());
-        if ((st = preview_join(e))) return st;
         e->fvValid = true; e->fvVersion = e->sceneVersion; e->fvM = M; memcpy(e->fvProj, proj, sizeof proj);
         break;
       }
@@ -1925,7 +1846,6 @@ int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner) {
   e->borrowedStream = true;
   e->overlapExpected = false;  // (the side stream's events assume a stream of the engine's own)
   e->liveExp.valid = false;
-  e->previewBranch = e->smallPath && preview_branch_default();
   return DSR_OK;
 }
 
@@ -1965,10 +1885,6 @@ struct dsr_batch {
   std::vector<dsr_engine *> vols;
   std::vector<BatchVolP> volsHost;
   BatchVolP *volsDev = nullptr;  // (the per-call records travel as kernel arguments: k_batch.h BatchFrames)
-  // the preview branch of the batch (dsr_engine::previewBranch; stream and events are the source engine's): the versions of
-  // every volume the last dsr_batch_fuse's two events stand for
-  bool branch = false;
-  std::vector<unsigned long long> fusedList, fusedScene;
   // the paired render of the batch (dsr_engine::pairRender): dsr_batch_fuse defers the tracking render of its volumes; the next
   // dsr_batch_render sends it out with the preview raycasts as one launch, any other call on an engine of the batch queues it
   bool pair = false, pendingTrack = false;
@@ -2046,12 +1962,9 @@ int dsr_batch_create(dsr_engine *source, dsr_engine *const *volumes, int n_volum
       int st = dsr_engine_share_stream(e, source);
       if (st) { delete b; return st; }
     }
-    e->previewBranch = false;  // (rendered through the batch: its branch is the source engine's)
     b->vols.push_back(e);
     b->volsHost.push_back(batch_vol_record(e));
   }
-  b->branch = preview_branch_default();
-  b->fusedList.assign(n_volumes, ~0ull); b->fusedScene.assign(n_volumes, ~0ull);
   b->pair = pair_render_default();
   for (int k = 0; k < n_volumes; ++k) b->pair = b->pair && volumes[k]->live.rayBox && volumes[k]->freeview.rayBox;
   if (hipMalloc(reinterpret_cast<void **>(&b->volsDev), sizeof(BatchVolP) * kBatchMax) != hipSuccess ||
@@ -2177,19 +2090,10 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
     hipLaunchKernelGGL(k_batch_small_alloc_visible, dim3(nv), dim3(kSmallThreads), lds, S, frames,
                        (const BatchVolP *)b->volsDev);
   }
-  if (b->branch) {  // the allocation state of every volume of this frame is final behind this point
-    if ((st = preview_branch_setup(src))) return st;
-    HIP_TRY(hipEventRecord(src->evAlloc, S));
-  }
 #define BATCH_INTEGRATE(A, B) LAUNCH(src, "batch_integrate", (k_batch_integrate<A, B>), dim3(maxGrid, nv), dim3(256), frames, (const BatchVolP *)b->volsDev)
   if (rgbSame) { if (plain) BATCH_INTEGRATE(true, true); else BATCH_INTEGRATE(true, false); }
   else { if (plain) BATCH_INTEGRATE(false, true); else BATCH_INTEGRATE(false, false); }
 #undef BATCH_INTEGRATE
-  if (b->branch) {  // ... and its voxels behind this one
-    HIP_TRY(hipEventRecord(src->evFused, S));
-    for (int v = 0; v < nv; ++v)
-      if (itemOf[v] >= 0) { b->fusedList[v] = b->vols[v]->listVersion; b->fusedScene[v] = b->vols[v]->sceneVersion; }
-  }
   if (b->pair) {  // the tracking render goes out with the preview raycasts of the next dsr_batch_render, or with the next other call
     b->pendingTrack = true;
     b->liveFrames = frames;
@@ -2262,32 +2166,6 @@ int dsr_batch_render(dsr_batch *b, int type, const dsr_batch_render_item *items,
            (const BatchVolP *)b->volsDev);
     HIP_TRY(hipGetLastError());
     return DSR_OK;
-  }
-  if (b->branch) {
-    // the two preview kernels on the source engine's preview branch (dsr_engine::previewBranch): the lists behind the frame's
-    // allocation, the raycasts behind its integration — next to the tracking render the fusion call queued on the main stream
-    if ((st = preview_branch_setup(src))) return st;
-    bool listCurrent = true, sceneCurrent = true;
-    for (int v = 0; v < nv; ++v) {
-      if (!fr[v].active) continue;
-      listCurrent = listCurrent && b->fusedList[v] == b->vols[v]->listVersion;
-      sceneCurrent = sceneCurrent && b->fusedScene[v] == b->vols[v]->sceneVersion;
-    }
-    if ((st = preview_wait(src, src->evAlloc, listCurrent))) return st;
-    {
-      StreamSwap sw(src, src->pvStream);
-      ProfScope _ps(src, "batch_small_freeview");
-      hipLaunchKernelGGL(k_batch_small_freeview, dim3(nv), dim3(kSmallThreads), small_lds_bytes(cells), src->stream, frames,
-                         (const BatchVolP *)b->volsDev, (BatchFrameP *)nullptr);
-    }
-    if ((st = preview_wait(src, src->evFused, sceneCurrent))) return st;
-    {
-      StreamSwap sw(src, src->pvStream);
-      LAUNCH(src, "batch_raycast_render", k_batch_raycast_render, dim3(div_up(src->W, 16), div_up(src->H, 16), nv), dim3(256),
-             frames, (const BatchVolP *)b->volsDev);
-    }
-    HIP_TRY(hipGetLastError());
-    return preview_join(src);
   }
   {
     ProfScope _ps(src, "batch_small_freeview");

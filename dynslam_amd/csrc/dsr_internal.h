@@ -223,20 +223,6 @@ struct dsr_engine {
   hipEvent_t orderEvent = nullptr;   // dsr_wait_for_stream / dsr_stream_wait_for_engine
   uint8_t *decayFlags = nullptr;
 
-  // PREVIEW BRANCH (round 6; instance-sized volumes that are driven on a shared stream: dsr_engine_share_stream, a volume batch).
-  // The preview of an instance — free-view list + range image (k_small_freeview), then the raycast that shades its own pixels —
-  // needs the ALLOCATION state of the frame for the first kernel and the fused voxels for the second; neither depends on the
-  // tracking render (k_raycast + k_icp_maps) that the same stream runs behind the integration.  Both raycasts are chains of
-  // dependent gathers for a few hundred live rays: side by side they take the time of one.  So a render call that finds the
-  // frame's events still current queues the two preview kernels on a stream of their own — the list behind evAlloc (recorded after
-  // the allocation's last kernel), the raycast behind evFused (after the integration) — and the engine's stream waits for their
-  // end before anything else: every other entry point still sees ONE ordered stream.  A render after anything else changed the
-  // scene (listVersion / sceneVersion moved on) orders the branch behind the stream as it is.  env DSR_PREVIEW_BRANCH=0: off.
-  bool previewBranch = false;
-  hipStream_t pvStream = nullptr;  // created on first use
-  hipEvent_t evAlloc = nullptr, evFused = nullptr, evPreview = nullptr, evNow = nullptr;
-  unsigned long long evAllocList = ~0ull, evFusedScene = ~0ull;  // the listVersion / sceneVersion the two events stand for
-
   // PAIRED RENDER (round 6; instance-sized volumes).  dsr_prepare's tracking render (k_raycast_box + k_icp_maps_box) is not queued
   // at once: it is DEFERRED until the next call on this engine.  When that call is the preview render (dsr_get_image_dev /
   // dsr_exchange_render_slot) — the reference's order per instance: Integrate, PrepareNextStep, later GetImage from the GUI's

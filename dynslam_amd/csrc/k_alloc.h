@@ -135,24 +135,43 @@ __host__ __device__ __forceinline__ bool alloc_ray(const FrameP &p, const float 
 // the byte of the entry's group of 8 in s.visGrp is set; the list kernel reads the few marked groups' types, turns them into
 // bits and puts the plain 1 back (k_small.h phase D0).
 constexpr uint8_t kTouchedNow = 0x81;
+// Called by EVERY lane of the wave (inImage: the lane's pixel exists) — round 6: the order keys of a wave are de-duplicated before
+// they go out.  An instance volume's blocks are large on the image (0.28 m at 5 m: 40 pixels across) and a ray names ~15 of
+// them: hundreds of lanes raise the key of the same entry, serialised at L2 — in frames that allocate, k_batch_alloc_mark took
+// 73 us for eight volumes where the same launch takes 21 us once every block exists (profiles/r06i_batch_step_timeline.json).
+// Only the LARGEST key of an entry matters (atomicMax) and exactly one writer must see the key still 0 and count the entry; so a
+// lane drops a target when a lane whose key is certainly larger names the same entry in the same batch of steps: its own later
+// step, its right neighbour in the row (pixel + 1) or the pixel below (pixel + W) — the 16x4 pixels of a wave.  Whoever is not
+// covered issues; the chain of coverers ends at a lane that does, with a key at least as large.  The result — every key, every
+// count — is the one all writers together produce.
 template <bool BITS>
 __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &s, const float *__restrict__ depth,
-                                                 uint8_t *__restrict__ visType, int x, int y) {
+                                                 uint8_t *__restrict__ visType, int x, int y, bool inImage) {
   AllocRay r;
-  if (!alloc_ray(p, depth, x, y, r)) return;
-  if ((uint32_t)(r.noSteps > 0 ? r.noSteps : 0) > p.maxSteps) {
+  r.px = r.py = r.pz = r.dx = r.dy = r.dz = 0.0f; r.noSteps = 0;
+  bool ok = inImage && alloc_ray(p, depth, x, y, r);
+  if (ok && (uint32_t)(r.noSteps > 0 ? r.noSteps : 0) > p.maxSteps) {
     // the order key holds maxSteps steps per pixel (bound derived for a rigid pose, dsr_engine.hip):
     // a scaled / non-orthonormal pose would make the commit replay the wrong step — report it
     // instead of writing a wrong block position
     s.ctr[CTR_STATUS] = DSR_E_ARG;
-    return;
+    ok = false;
   }
+  const int noSteps = ok ? r.noSteps : 0;
+  // (BITS = the instance-sized volumes: there the de-duplication pays — 73 -> 30 us for eight volumes; a map's 4 cm blocks are 2-3
+  //  pixels across and its mark read 34.5 -> 35.6 us with it, profiles/r06j_bench_profile_all_*.json: not used there)
+  int waveSteps = noSteps;  // the wave runs as many batches as its longest ray needs (the shuffles below need every lane)
+  if (BITS) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_xor(waveSteps, d); waveSteps = o > waveSteps ? o : waveSteps; }
+  }
+  const int lane = threadIdx.x & 63;
   const uint32_t keyBase = (uint32_t)(x + y * p.W) * p.maxSteps + 1u;
   float px = r.px, py = r.py, pz = r.pz;
   // The steps of a ray are independent (stores of the same value, atomicMax, exactly-once counting),
   // so they are taken four at a time: positions first (the same running additions as the serial
   // loop), then the four bucket heads are requested together — one round trip instead of four.
-  for (int i0 = 0; i0 < r.noSteps; i0 += 4) {
+  for (int i0 = 0; i0 < waveSteps; i0 += 4) {
     short cb[4][3];
     uint32_t ch[4];
     dsr_hash_entry head[4];
@@ -160,7 +179,7 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
     for (int k = 0; k < 4; ++k) {
       cb[k][0] = f2s(floorf(px)); cb[k][1] = f2s(floorf(py)); cb[k][2] = f2s(floorf(pz));
       ch[k] = hash_index(cb[k][0], cb[k][1], cb[k][2], p.hashMask);
-      if (i0 + k < r.noSteps) head[k] = load_entry(s.table, ch[k]);
+      if (i0 + k < noSteps) head[k] = load_entry(s.table, ch[k]);
       px += r.dx; py += r.dy; pz += r.dz;
     }
     // what each of the four steps marks for allocation: entry index (kNoTarget: nothing) and whether it is a chain append
@@ -170,7 +189,7 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int i = i0 + k;
-      if (i >= r.noSteps) break;
+      if (i >= noSteps) break;
       const short bx = cb[k][0], by = cb[k][1], bz = cb[k][2];
       uint32_t hashIdx = ch[k];
       bool isFound = false;
@@ -205,20 +224,33 @@ __device__ __forceinline__ void alloc_mark_pixel(const FrameP &p, const SceneP &
         }
       }
     }
+    // de-duplication (see above): targets of the right neighbour in the row and of the pixel below, this batch
+    bool covered[4] = {false, false, false, false};
+    if (BITS) {
+      const bool hasRight = (lane & 15) != 15, hasBelow = lane < 48;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const uint32_t right = (uint32_t)__shfl_down((int)tgt[kk], 1), below = (uint32_t)__shfl_down((int)tgt[kk], 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (hasRight && right == tgt[k]) covered[k] = true;
+          if (hasBelow && below == tgt[k]) covered[k] = true;
+          if (kk > k && tgt[kk] == tgt[k]) covered[k] = true;  // this ray's own later step
+        }
+      }
+    }
     // The order keys of the (up to) four steps go out TOGETHER and their results are looked at afterwards: an atomic whose
     // result is used inside its own `if` is a basic block with its own wait — four serialised round trips per batch for the
-    // wave.  Atomics of one lane on one address are performed in program order, so when two steps of a ray name the same
-    // entry the first still sees 0 and counts it, the second does not.  (Sending the idle steps to one spare word instead of
-    // predicating them was tried: 16 ms of same-address contention.)
+    // wave.  (Sending the idle steps to one spare word instead of predicating them was tried: 16 ms of same-address contention.)
     uint32_t old[4] = {1u, 1u, 1u, 1u};
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (tgt[k] != kNoTarget) old[k] = atomicMax(&s.allocKey[tgt[k]], keyBase + (uint32_t)(i0 + k));  // step < maxSteps (checked above)
+      if (tgt[k] != kNoTarget && !covered[k]) old[k] = atomicMax(&s.allocKey[tgt[k]], keyBase + (uint32_t)(i0 + k));  // step < maxSteps (checked above)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       // the first writer of an entry in this frame (its key was still 0) also counts it: per group of 8 entries and per sweep
       // tile, so that the commit finds the ~1 % marked entries without reading all the keys
-      if (tgt[k] != kNoTarget && old[k] == 0u) {
+      if (tgt[k] != kNoTarget && !covered[k] && old[k] == 0u) {
         const uint32_t one = exc[k] ? 0x11u : 0x01u;
         atomicAdd(&s.allocGrp[tgt[k] >> 5], one << (((tgt[k] >> 3) & 3u) * 8u));
         atomicAdd(&s.allocTile[tgt[k] / (uint32_t)kTile], exc[k] ? 0x100000001ull : 1ull);
@@ -339,8 +371,7 @@ template <bool BITS>
 __global__ __launch_bounds__(256) void k_alloc_mark(FrameP p, SceneP s, const float *__restrict__ depth,
                                                     uint8_t *__restrict__ visType, int tileX0, int tileY0) {
   const int x = (blockIdx.x + tileX0) * 16 + (threadIdx.x & 15), y = (blockIdx.y + tileY0) * 16 + (threadIdx.x >> 4);
-  if (x >= p.W || y >= p.H) return;
-  alloc_mark_pixel<BITS>(p, s, depth, visType, x, y);
+  alloc_mark_pixel<BITS>(p, s, depth, visType, x, y, x < p.W && y < p.H);  // (every lane: the wave de-duplicates its keys)
 }
 
 // K2: commit in ascending entry order (the serial loop of AllocateSceneFromDepth), in two

@@ -102,8 +102,7 @@ __global__ __launch_bounds__(256) void k_batch_alloc_mark(const BatchFrames fram
   if (!f.active || (int)blockIdx.x >= f.tilesX || (int)blockIdx.y >= f.tilesY) return;
   const BatchVolP &v = vols[blockIdx.z];
   const int x = ((int)blockIdx.x + f.tileX0) * 16 + (threadIdx.x & 15), y = ((int)blockIdx.y + f.tileY0) * 16 + (threadIdx.x >> 4);
-  if (x >= f.p.W || y >= f.p.H) return;
-  alloc_mark_pixel<true>(f.p, v.s, v.depth, v.visType, x, y);
+  alloc_mark_pixel<true>(f.p, v.s, v.depth, v.visType, x, y, x < f.p.W && y < f.p.H);
 }
 
 __global__ __launch_bounds__(kSmallThreads) void k_batch_small_alloc_visible(const BatchFrames frames,
