@@ -1,5 +1,7 @@
 // dsr_internal.h — what the translation units of libdsr_hip.so share (NOT part of the C ABI: include/dsr.h is):
-//   dsr_engine.hip    the engine — view, allocation, integration, GC, swapping, raycast / render, meshing, the view split, dumps
+//   dsr_engine.hip    the engine — creation, allocation, integration, GC, swapping, raycast / render, the volume batch, meshing, dumps
+//   dsr_view.hip      the view and the edges of the path — frames in, the view pipeline, the instance view split, layout conversions,
+//                     depth ingest, the two previews
 //   dsr_exchange.hip  the multi-GPU layer exchange (RCCL, loaded on first use) and the compositing entry points
 //   dsr_hostio.hip    host-side I/O of the boundary: precomputed depth / disparity files, page-locking of the host's buffers
 //   dsr_profile.hip   HIP-event profile read-out, the division self-tests, the HBM copy probe
@@ -243,7 +245,66 @@ struct dsr_engine {
 };
 
 namespace dsr_internal {
+// ---- small helpers every translation unit of the engine uses
+inline int set_device(dsr_engine *e) {
+  HIP_TRY(hipSetDevice(e->device));
+  return DSR_OK;
+}
+inline hipEvent_t get_event(dsr_engine *e) {
+  if (!e->eventPool.empty()) { hipEvent_t ev = e->eventPool.back(); e->eventPool.pop_back(); return ev; }
+  hipEvent_t ev = nullptr;
+  (void)hipEventCreate(&ev);
+  return ev;
+}
+void prof_resolve_pending(dsr_engine *e);  // dsr_engine.hip: resolve the HIP-event pairs recorded so far
+struct ProfScope {  // HIP events around the launches of a scope, on e->stream (dsr_profile_*)
+  dsr_engine *e; int rec = -1; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(dsr_engine *e_, const char *name) : e(e_) {
+    if (!e->profiling) return;
+    if (e->profiling == 2 && strcmp(name, "integrate") != 0 && strcmp(name, "raycast") != 0 && strcmp(name, "raycast_tail") != 0) return;
+    auto it = e->profIndex.find(name);
+    if (it == e->profIndex.end()) {
+      rec = (int)e->profRecs.size();
+      e->profIndex[name] = rec;
+      ProfRec r; r.name = name; e->profRecs.push_back(r);
+    } else rec = it->second;
+    if (e->profPending.size() > 8192) prof_resolve_pending(e);
+    a = get_event(e); b = get_event(e);
+    (void)hipEventRecord(a, e->stream);
+  }
+  ~ProfScope() {
+    if (rec < 0) return;
+    (void)hipEventRecord(b, e->stream);
+    e->profPending.push_back({rec, a, b});
+  }
+};
+// kernels enqueued inside the scope go to `s` (LAUNCH and ProfScope read e->stream)
+struct StreamSwap {
+  dsr_engine *e; hipStream_t saved;
+  StreamSwap(dsr_engine *e_, hipStream_t s) : e(e_), saved(e_->stream) { e->stream = s; }
+  ~StreamSwap() { e->stream = saved; }
+};
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+template <class T>
+int dmalloc(T **p, size_t n) {
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+  return DSR_OK;
+}
+// ---- dsr_view.hip: the I/O stream of a GPU, event flavours, the ordering of the view's writers and readers
+extern std::mutex g_ioMutex;
+extern hipStream_t g_ioStream[64];
+hipError_t create_stream(hipStream_t *out);
+int io_stream(dsr_engine *e, hipStream_t *out);
+unsigned order_event_flags();
+int make_event(hipEvent_t *ev, bool hostWaits = false);
+int before_view_write(dsr_engine *e, hipStream_t stream);
+int view_written(dsr_engine *e, hipStream_t stream);
+int begin_view_modify(dsr_engine *e);
+int before_fusion(dsr_engine *e);
+int after_fusion(dsr_engine *e);
+hipStream_t vstream(dsr_engine *e);
 // dsr_engine.hip
+extern std::atomic<int> g_enginesOnDevice[64];  // live engines per device (range-image overlap policy, preview stores)
 int engine_set_device(dsr_engine *e);
 int engine_flush_deferred(dsr_engine *e);  // queue what dsr_prepare / dsr_batch_fuse deferred (paired render)
 void engine_prof_resolve(dsr_engine *e);
@@ -264,6 +325,12 @@ using dsr_internal::short_division_exact;
 
 // entry of (nearly) every engine call: the engine's GPU becomes current and work this engine — or the batch it belongs to — has
 // deferred (paired render) is queued; CHECK_E_NOFLUSH: the few calls that consume the deferred work or cannot be affected by it
+#define LAUNCH(e, name, kernel, grid, block, ...)                                \
+  do {                                                                           \
+    dsr_internal::ProfScope _ps((e), (name));                                    \
+    hipLaunchKernelGGL(kernel, grid, block, 0, (e)->stream, __VA_ARGS__);        \
+  } while (0)
+
 #define CHECK_E_NOFLUSH(e)                                  \
   if (!(e)) return fail(DSR_E_ARG, "null engine");          \
   { int _st = dsr_internal::engine_set_device(e); if (_st) return _st; }

@@ -8,6 +8,79 @@
 
 namespace dsr {
 
+// ---------------------------------------------------------------------- K0: view
+
+// ITMViewBuilder.h convertDepthAffineToFloat: int16 mm -> float m, <=0 or >32000 -> -1.
+__global__ __launch_bounds__(256) void k_depth_to_float(const short *__restrict__ in, float *__restrict__ out, int n,
+                                                        float a, float b) {
+  // 4 pixels per thread: 8 B load, 16 B store
+  int i4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 + 3 < n) {
+    short4 d = *reinterpret_cast<const short4 *>(in + i4);
+    float4 o;
+    o.x = (d.x <= 0 || d.x > 32000) ? -1.0f : (float)d.x * a + b;
+    o.y = (d.y <= 0 || d.y > 32000) ? -1.0f : (float)d.y * a + b;
+    o.z = (d.z <= 0 || d.z > 32000) ? -1.0f : (float)d.z * a + b;
+    o.w = (d.w <= 0 || d.w > 32000) ? -1.0f : (float)d.w * a + b;
+    *reinterpret_cast<float4 *>(out + i4) = o;
+  } else {
+    for (int i = i4; i < n; ++i) {
+      short d = in[i];
+      out[i] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
+  }
+}
+
+// UpdateView from device-resident inputs in ONE launch: copy the RGBA frame (16 B per thread) and
+// convert the depth (4 pixels per thread) — two hipMemcpyAsync D2D + a kernel cost ~60 us of
+// launch latency per frame, this one ~5 us.  Both input pointers must be 16-byte aligned.
+__global__ __launch_bounds__(256) void k_view_ingest(const uint4 *__restrict__ rgbIn, uint4 *__restrict__ rgbOut, int nRgbVec,
+                                                     int nRgbPixels, const short *__restrict__ depthIn,
+                                                     float *__restrict__ depthOut, int n, float a, float b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nRgbVec) rgbOut[i] = rgbIn[i];
+  if (i < nRgbPixels - nRgbVec * 4)  // the 0..3 pixels after the last whole 16-byte vector
+    reinterpret_cast<uint32_t *>(rgbOut)[nRgbVec * 4 + i] = reinterpret_cast<const uint32_t *>(rgbIn)[nRgbVec * 4 + i];
+  const int i4 = i * 4;
+  if (i4 + 3 < n) {
+    short4 d = *reinterpret_cast<const short4 *>(depthIn + i4);
+    float4 o;
+    o.x = (d.x <= 0 || d.x > 32000) ? -1.0f : (float)d.x * a + b;
+    o.y = (d.y <= 0 || d.y > 32000) ? -1.0f : (float)d.y * a + b;
+    o.z = (d.z <= 0 || d.z > 32000) ? -1.0f : (float)d.z * a + b;
+    o.w = (d.w <= 0 || d.w > 32000) ? -1.0f : (float)d.w * a + b;
+    *reinterpret_cast<float4 *>(depthOut + i4) = o;
+  } else {
+    for (int k = i4; k < n; ++k) {
+      short d = depthIn[k];
+      depthOut[k] = (d <= 0 || d > 32000) ? -1.0f : (float)d * a + b;
+    }
+  }
+}
+
+// ITMViewBuilder.h filterDepth (one bilateral pass); borders keep their old value.
+__global__ __launch_bounds__(256) void k_filter_depth(const float *__restrict__ in, float *__restrict__ out, int W, int H) {
+  const float MEAN_SIGMA_L = 1.2232f;
+  int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x < 2 || x >= W - 2 || y < 2 || y >= H - 2) return;
+  float z = in[x + y * W];
+  if (z < 0.0f) { out[x + y * W] = -1.0f; return; }
+  float final_depth = 0.0f, w_sum = 0.0f;
+  float sigma_z = 1.0f / (0.0012f + 0.0019f * (z - 0.4f) * (z - 0.4f) + 0.0001f / sqrtf(z) * 0.25f);
+  for (int i = -2; i <= 2; i++)
+    for (int j = -2; j <= 2; j++) {
+      float tmpz = in[(x + j) + (y + i) * W];
+      if (tmpz < 0.0f) continue;
+      float dz = (tmpz - z); dz *= dz;
+      float w = expf(-0.5f * ((abs(i) + abs(j)) * MEAN_SIGMA_L * MEAN_SIGMA_L + dz * sigma_z * sigma_z));
+      w_sum += w;
+      final_depth += w * tmpz;
+    }
+  final_depth /= w_sum;
+  out[x + y * W] = final_depth;
+}
+
+
 // Each kernel below is "one thread per element" around a per-element function; those are __host__ __device__ templates over
 // Ops (dsr_device.h) so that tests/test_reference_edges.py can run them on the CPU against the REFERENCE'S OWN functions
 // (oracle/_ref) as well as on the GPU.

@@ -48,7 +48,8 @@ extern "C" {
  * extended, DSR_E_IO; 3: the multi-GPU exchange (dsr_exchange_*), dsr_update_view_bgr, host-buffer calls no longer
  * synchronise with the engine's stream; 4: dsr_view_split_silhouette, dsr_engine_share_stream, dsr_pin_host_thread, the volume
  * batch dsr_batch_*, dsr_exchange_set_collective / _timing; the view pipeline is on by default for engines with sync_status;
- * 5: dsr_settings.view_pipeline, dsr_measure_copy_bandwidth_spread) */
+ * 5: dsr_settings.view_pipeline, dsr_measure_copy_bandwidth_spread; dsr_prepare / dsr_batch_fuse defer the tracking render of an
+ * instance-sized volume to the next call (paired render); dsr_exchange_clear_target is carried out by the next composite) */
 #define DSR_ABI_VERSION 5
 
 /* SDF_BLOCK_SIZE / SDF_BLOCK_SIZE3 (InfiniTamDriver.h:243,247). */
@@ -225,7 +226,10 @@ int dsr_stream_wait_for_engine(dsr_engine *e, void *hip_stream);
 /* (ABI 4) `e` queues its work on `owner`'s stream from now on (its own stream is released).  For ONE instance volume next to
  * the engine that holds the full frame on a GPU of their own — the one-volume-per-GPU layout: the view split, the fusion and
  * the renders of the pair are then ordered by one queue and the frame contains no cross-stream event.  Both engines on one
- * GPU, driven from one thread, `e` idle, neither with a pipelined view; destroy `e` before or after `owner`, either works. */
+ * GPU, driven from one thread, `e` idle, neither with a pipelined view.  LIFETIME: the stream stays `owner`'s — `owner` must
+ * outlive every CALL on `e` (a sync, a dump, a frame), not only its destruction; dsr_engine_destroy(e) itself is safe in either
+ * order.  The same holds for the volumes of a batch (dsr_batch_create puts them on its source's stream and dsr_batch_destroy
+ * does not give them streams of their own back) and for the batch handle: destroy it before the engines it names. */
 int dsr_engine_share_stream(dsr_engine *e, dsr_engine *owner);
 
 /* ---- volume batch (ABI 4): the instance volumes of ONE GPU driven together.  An instance frame is eight small launches; N
@@ -322,7 +326,13 @@ int dsr_allocate_scene_from_depth(dsr_engine *e);
 int dsr_integrate_into_scene(dsr_engine *e);
 /* trackingController->Prepare(trackingState, view, renderState_live)
  * (InfiniTamDriver.h:152): CreateExpectedDepths + CreateICPMaps.  A no-op when
- * noVisibleBlocks == 0 (InfiniTamDriver.h:150). */
+ * noVisibleBlocks == 0 (InfiniTamDriver.h:150).
+ * (ABI 5) For an instance-sized volume the raycast + ICP maps of this call are DEFERRED: they are queued by the next call that
+ * names this engine — together with the preview raycast, as one launch, when that call is dsr_get_image_dev /
+ * dsr_exchange_render_slot from a free camera (the reference's order per instance: Integrate, PrepareNextStep, later GetImage);
+ * every other call queues them first.  No caller can observe the difference through this API: results, stream order as seen by
+ * dsr_stream_wait_for_engine / dsr_sync, dumps.  dsr_batch_fuse defers the tracking render of its volumes the same way (the
+ * next dsr_batch_render pairs it, any other call on the source or a volume queues it).  env DSR_PAIR_RENDER=0: queued at once. */
 int dsr_prepare(dsr_engine *e);
 
 /* denseMapper->Decay(scene, renderState, maxWeight, minAge, forceAllVoxels)
@@ -512,7 +522,9 @@ int dsr_exchange_gather_and_composite(dsr_exchange *x, int root_rank, dsr_engine
                                       void *target_depth_dev, const int32_t *ranks, const int32_t *slots,
                                       const int32_t *track_ids, int n_layers, float tint_strength, int dim_background);
 /* The exchange's own composite target on the GPU of local rank `rank` (RGBA + float depth, n_pixels each), its
- * clearing (no static map: instances over an empty frame) and its read-back (synchronises). */
+ * clearing (no static map: instances over an empty frame) and its read-back (synchronises).  (ABI 5) The clear is carried
+ * out by the next composite over the target (which then does not read it), or by _target_ptrs / _read_target: buffers looked at
+ * through pointers obtained EARLIER show it only after one of these. */
 int dsr_exchange_target_ptrs(dsr_exchange *x, int rank, void **rgba_dev, void **depth_dev);
 int dsr_exchange_clear_target(dsr_exchange *x, int rank);
 int dsr_exchange_read_target(dsr_exchange *x, int rank, uint8_t *rgba_out, float *depth_out);

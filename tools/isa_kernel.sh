@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../dynslam_amd/csrc" || exit 1
 # (all translation units of the library, concatenated: tools/isa_diff.py compares two such dumps)
 : > /tmp/eng.s
-for tu in dsr_engine dsr_exchange dsr_hostio dsr_profile; do
+for tu in dsr_engine dsr_view dsr_exchange dsr_hostio dsr_profile; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fno-fast-math -Wno-unused-function --cuda-device-only -S -o /tmp/eng_$tu.s $tu.hip 2>&1 | grep -E "error" | head
   cat /tmp/eng_$tu.s >> /tmp/eng.s
 done
