@@ -348,6 +348,48 @@ def test_gpu_split_silhouette_equals_the_two_steps(hip_api, oracle_lib, monkeypa
 
 
 @pytest.mark.gpu
+def test_gpu_split_silhouette_mask_ring_grows_between_the_two_masks(hip_api, oracle_lib):
+    """host masks are staged through a pinned ring whose slots hold 1.5x the largest mask seen so far.  An
+    earlier SMALL mask sizes the ring; then one split whose copy mask still fits a slot while its (larger) delete mask does not:
+    growing the ring for the second mask used to free the memory the first one had just been staged in.  The cut-out and the
+    blanking must equal the reference's two host loops."""
+    W, H = 320, 96
+    rng = np.random.default_rng(11)
+    sc, gm, gi = make_engines(hip_factory, W, H)
+    _, om, oi = make_engines(oracle_factory, W, H)
+    rgba, d, T, _ = StreetScene(W, H).frame(1)
+    for m in (gm, om):
+        m.update_view(rgba, d)
+    small = (rng.random((20, 100)) < 0.5).astype(np.uint8)          # 2000 B -> slots of 4096 B
+    gm.remove_silhouette(small, 5, 5)
+    om.remove_silhouette(small, 5, 5)
+    copy = (rng.random((40, 100)) < 0.6).astype(np.uint8)           # 4000 B: fits a slot
+    delete = (rng.random((48, 120)) < 0.7).astype(np.uint8)         # 5760 B: does not -> the ring grows inside the call
+    gm.split_silhouette(gi, copy, 60, 20, delete, 50, 16)
+    om.extract_silhouette(oi, copy, 60, 20)
+    om.remove_silhouette(delete, 50, 16)
+    for a, b in ((gm, om), (gi, oi)):
+        va, vb = a.get_view(), b.get_view()
+        assert np.array_equal(va[0], vb[0]) and np.array_equal(va[1], vb[1])
+    assert (gi.get_view()[1] > 0).sum() > 100  # the cut-out is not empty: the copy mask was read where it was staged
+    # ... and once more with masks that grow from call to call (every call re-sizes the ring)
+    for k in range(3):
+        h, w = 50 + 10 * k, 130 + 40 * k
+        copy = (rng.random((h, w)) < 0.6).astype(np.uint8)
+        delete = (rng.random((h + 12, w + 30)) < 0.7).astype(np.uint8)
+        for m in (gm, om):
+            m.update_view(rgba, d)
+        gm.split_silhouette(gi, copy, 10, 8, delete, 2, 4)
+        om.extract_silhouette(oi, copy, 10, 8)
+        om.remove_silhouette(delete, 2, 4)
+        for a, b in ((gm, om), (gi, oi)):
+            va, vb = a.get_view(), b.get_view()
+            assert np.array_equal(va[0], vb[0]) and np.array_equal(va[1], vb[1])
+    for e in (gm, gi, om, oi):
+        e.close()
+
+
+@pytest.mark.gpu
 def test_gpu_view_previews_and_visible_count(hip_api, oracle_lib):
     """dsr_get_view_previews (ItmToCv + ItmDepthToCv of the current view, InfiniTamDriver.h:154-156, from HBM with one
     synchronisation) and dsr_get_no_visible_blocks (the count the host reads after fusion) against the oracle and against

@@ -123,6 +123,47 @@ def test_free_view_render_types(hip_api, image_type):
         assert ig[..., :3].any()
 
 
+def test_instance_volume_list_path_through_gc_exhaustion_and_reset(hip_api):
+    """Round 6: an instance-sized volume keeps its allocated entries as a sorted list (k_small.h list path) and falls back to the
+    bit-plane sweeps — rebuilding the list — after a GC pass, with an exhausted block array and after a reset; its tracking render
+    is deferred and goes out paired with the preview render into device buffers.  One sequence that crosses every transition, the
+    whole state and both render states against the oracle after every frame."""
+    import torch
+    # 600 blocks: exhausted within the first frames (entries that are visible without owning a block), freed again by the GC
+    sc, g, o = make_pair(W=256, H=80, voxel_size=0.035, mu=1.0, sdf_local_block_num=600, view_frustum_max=12.0,
+                         scene_kw=dict(noise_px=0.4))
+    out_rgba = torch.zeros((80 * 256, 4), dtype=torch.uint8, device="cuda")
+    out_depth = torch.zeros((80 * 256,), dtype=torch.float32, device="cuda")
+    seen_oob, freed = False, 0
+    for i in range(14):
+        r = feed((g, o), sc, i, ignore_oob=True)   # update_view, pose, process_frame, prepare (deferred on the GPU side)
+        assert r[0] == r[1]
+        seen_oob |= r[0]
+        M = np.linalg.inv(sc.pose(max(0, i - 1)).astype(np.float64)).astype(np.float32)
+        # the preview into device buffers: pairs with the deferred tracking render
+        g.get_image_dev(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, M, None, out_rgba.data_ptr(), out_depth.data_ptr())
+        oc, od = o.get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+        g.sync()
+        assert np.array_equal(out_depth.cpu().numpy().reshape(80, 256), od)
+        assert np.array_equal(out_rgba.cpu().numpy().reshape(80, 256, 4), oc)
+        assert_scene_equal(g, o, voxels=False)
+        assert_render_equal(g, o)
+        assert_render_equal(g, o, freeview=True)
+        assert np.array_equal(g.dump_visible_list(True), o.dump_visible_list(True))
+        if i in (3, 4, 8):           # GC passes: the list is invalidated, the next frame sweeps and rebuilds it
+            for e in (g, o):
+                e.decay(2 if i < 8 else 100, 0, i == 8)   # frame 8: Reap with a weight nothing exceeds — every block goes
+            assert_scene_equal(g, o, voxels=False)
+            freed = max(freed, o.get_stats().decayed_block_count)
+        if i == 10:                  # a reset in the middle: everything starts over (the first raycasts are full-frame again)
+            for e in (g, o):
+                e.reset_scene()
+    assert seen_oob, "the sequence must exhaust the block array"
+    assert freed > 100, "the GC passes must free blocks (the list is invalidated through them)"
+    assert_scene_equal(g, o)
+    g.close(); o.close()
+
+
 def test_scene_raycast_and_original_rgb(hip_api):
     sc, g, o = make_pair()
     feed((g, o), sc, 0)
