@@ -696,10 +696,14 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
     # preview: no render, no collective, no composite), and — N > 1 — the same workload with the OTHER collective (gather to the
     # consumer's GPU instead of the in-place all-gather)
     scene.after_warmup = None
+    # (from EMPTY volumes, like the timed region: frames that allocate cost more than the same frames fused a second time — the
+    #  allocation mark's atomics, the merge of the new entries — and a replay would under-report the chain)
+    scene.reset()
     chain_s, _ = run(scene, world, preview=False)
     alt = None
     if native and world > 1 and use_dist:
         scene.exchange.x.set_collective(1, 0)
+        scene.reset()
         scene.after_warmup = lambda: scene.exchange.x.timing(True)
         alt_s, _ = run(scene, world)
         alt_t = scene.exchange.x.timing(False)

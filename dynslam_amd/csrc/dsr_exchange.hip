@@ -156,13 +156,6 @@ extern "C" {
 
 // ---- instance compositing
 
-// pixels per lane of k_composite (k_composite.h): 2 — 4.1-5.0 us for eight layers at 1242x375 against 5.0-6.3 with 4 (more waves in
-// flight beat wider loads: profiles/r06d_composite_px*.json); env DSR_COMPOSITE_PX=4 for the A/B (tools/bench_composite.py)
-static int composite_px_per_lane() {
-  static const int px = (getenv("DSR_COMPOSITE_PX") && atoi(getenv("DSR_COMPOSITE_PX")) == 4) ? 4 : 2;
-  return px;
-}
-
 int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_dev, void *target_depth_dev,
                                 const void *layers_rgba_dev, const void *layers_depth_dev, const int32_t *track_ids,
                                 int n_layers, int n_pixels, float tint_strength, int dim_background) {
@@ -174,14 +167,11 @@ int dsr_composite_instances_dev(int device, void *hip_stream, void *target_rgba_
   const CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
   CompositeLayers none;
   memset(&none, 0, sizeof none);
-  if (composite_px_per_lane() == 2)
-    hipLaunchKernelGGL((k_composite<false, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
-                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
-                       (const float *)layers_depth_dev, none);
-  else
-    hipLaunchKernelGGL((k_composite<false, 4>), dim3((n_pixels + 1023) / 1024), dim3(256), 0, (hipStream_t)hip_stream, c,
-                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
-                       (const float *)layers_depth_dev, none);
+  // (two pixels per lane: 4.1-5.0 us for eight layers at 1242x375 against 5.0-6.3 with four — more waves in flight beat wider
+  //  loads, profiles/r06d_composite_px*.json)
+  hipLaunchKernelGGL((k_composite<false, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
+                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)layers_rgba_dev,
+                     (const float *)layers_depth_dev, none);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }
@@ -215,12 +205,8 @@ static int composite_layer_ptrs(int device, void *hip_stream, void *target_rgba_
   if (device >= 0) HIP_TRY(hipSetDevice(device));
   CompositeP c = composite_params(track_ids, n_layers, n_pixels, tint_strength, dim_background);
   c.clearTarget = clear_target;
-  if (composite_px_per_lane() == 2)
-    hipLaunchKernelGGL((k_composite<true, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
-                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
-  else
-    hipLaunchKernelGGL((k_composite<true, 4>), dim3((n_pixels + 1023) / 1024), dim3(256), 0, (hipStream_t)hip_stream, c,
-                       (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
+  hipLaunchKernelGGL((k_composite<true, 2>), dim3((n_pixels + 511) / 512), dim3(256), 0, (hipStream_t)hip_stream, c,
+                     (uchar4 *)target_rgba_dev, (float *)target_depth_dev, (const uchar4 *)nullptr, (const float *)nullptr, lp);
   HIP_TRY(hipGetLastError());
   return DSR_OK;
 }

@@ -329,6 +329,11 @@ class ShardedScene:
         for e in self.engines():
             e.close()
 
+    def reset(self):
+        """ResetScene of every volume this rank holds (bench.py: a diagnostic leg starts from empty volumes again)."""
+        for e in self.engines():
+            e.reset_scene()
+
     def sync(self):
         for e in self.engines():
             e.sync()

@@ -2,7 +2,8 @@
 """k_composite alone: 8 layers at 1242x375 through dsr_composite_layer_ptrs_dev (the exchange's form: one pointer pair per layer),
 torch events over many launches.  Scenarios: depth only / colour + dimmed background / colour; layers that cover 0 %, 3 % and
 28 % of the frame (the bench's preview_hit_fraction); planes 16-byte aligned or only 8-byte aligned (as in the exchange buffer).
-usage (GPU box): python tools/bench_composite.py [--iters 200]      env DSR_COMPOSITE_PX=2: two pixels per lane"""
+usage (GPU box): python tools/bench_composite.py [--iters 200]
+(round 6 measured two against four pixels per lane with it — profiles/r06d_composite_px*.json; the library keeps two)"""
 import argparse
 import ctypes as C
 import json
@@ -27,7 +28,7 @@ def main():
     W, H, L = 1242, 375, a.layers
     P = W * H
     rng = np.random.default_rng(7)
-    res = {"px_per_lane": os.environ.get("DSR_COMPOSITE_PX", "4"), "layers": L, "pixels": P}
+    res = {"px_per_lane": 2, "layers": L, "pixels": P}
     stream = torch.cuda.current_stream().cuda_stream
     for cover in (0.0, 0.03, 0.28):
         # every layer a rectangle of `cover / L * 2` of the frame at a random place, depth 5..15 m

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--two-renders", action="store_true", help="colour and depth as two get_image calls (round 2's preview)")
     ap.add_argument("--two-step-split", action="store_true", help="extract + remove as two calls (round 4's view split)")
     ap.add_argument("--share-stream", action="store_true", help="the instance queues its work on the view engine's stream (dsr_engine_share_stream)")
+    ap.add_argument("--reset-every", type=int, default=0, help="ResetScene of the instance volume every N frames: the sequence has 16 unique "
+                    "frames, so without it every frame after the first pass re-fuses blocks that exist (no allocation); with 16 every pass "
+                    "allocates again")
     args = ap.parse_args()
     import bench
     W, H = 1242, 375
@@ -73,6 +76,8 @@ def main():
 
     def frame(i):
         j = i % n_unique
+        if args.reset_every and i % args.reset_every == 0:
+            call("reset_scene", inst.reset_scene)
         x0, y0, mk, mk_dev, rel, pose_m = masks[j]
         call("update_view_dev", view.update_view_dev, rgb[j].data_ptr(), dep[j].data_ptr())
         if not args.two_step_split and hasattr(view, "split_silhouette_dev"):
@@ -103,7 +108,7 @@ def main():
         frame(i)
     drain()
     res = {"frames": args.frames, "host_masks": args.host_masks, "two_renders": args.two_renders, "two_step_split": args.two_step_split,
-           "share_stream": args.share_stream, "lib": os.environ.get("DSR_HIP_LIB", "default")}
+           "share_stream": args.share_stream, "reset_every": args.reset_every, "lib": os.environ.get("DSR_HIP_LIB", "default")}
     # (a) free-running: host enqueues ahead, one drain at the end
     host.clear()
     t0 = time.perf_counter()
