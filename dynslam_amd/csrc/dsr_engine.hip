@@ -35,6 +35,8 @@ std::atomic<int> g_enginesOnDevice[64];  // live engines per device (range-image
 namespace {
 
 std::atomic<unsigned long long> g_devMask{0};  // devices engines were created on (dsr_device_synchronize)
+std::mutex g_engineMutex;
+std::vector<dsr_engine *> g_liveEngines;         // every engine of the process: dsr_device_synchronize queues their deferred work first
 // DSR_PIPELINED_VIEW=2: per GPU ONE view stream for all engines and ONE fusion stream for all instance-sized volumes (a host drives
 // its instance volumes one after the other anyway): a map + N instances are then 4-5 streams instead of 2N + 4, and the map's
 // fusion stream need not share a hardware queue with anybody
@@ -711,12 +713,17 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   if (hipStreamSynchronize(e->stream) != hipSuccess) { free_all(e); delete e; return fail(DSR_E_DEVICE, "engine initialisation failed"); }
 #undef ALLOC
   if (countedDevice < 64) g_enginesOnDevice[countedDevice].fetch_add(1);
+  { std::lock_guard<std::mutex> lock(g_engineMutex); g_liveEngines.push_back(e); }
   *out = e;
   return DSR_OK;
 }
 
 void dsr_engine_destroy(dsr_engine *e) {
   if (!e) return;
+  {
+    std::lock_guard<std::mutex> lock(g_engineMutex);
+    g_liveEngines.erase(std::remove(g_liveEngines.begin(), g_liveEngines.end(), e), g_liveEngines.end());
+  }
   (void)hipSetDevice(e->device);
   if (e->ownerBatch && dsri_batch_is_live(e->ownerBatch)) dsri_batch_drop_deferred(e->ownerBatch);  // (its deferred work dies with an engine of the batch)
   if (e->viewStream) (void)hipStreamSynchronize(e->viewStream);
@@ -747,6 +754,17 @@ int dsr_device_synchronize(void) {
   const bool havePrev = hipGetDevice(&prev) == hipSuccess;
   const unsigned long long mask = g_devMask.load();
   int rc = DSR_OK;
+  {  // the host's "everything is done" point: deferred tracking renders (paired render) are queued first — like every call that
+     // names an engine, this one is made from the thread that drives the engines (dsr.h threading contract)
+    std::vector<dsr_engine *> engines;
+    { std::lock_guard<std::mutex> lock(g_engineMutex); engines = g_liveEngines; }
+    for (dsr_engine *e : engines)
+      if (e->trackRender.pending || e->ownerBatch) {
+        if (hipSetDevice(e->device) != hipSuccess) continue;
+        const int st = dsr_internal::engine_flush_deferred(e);
+        if (st) rc = st;
+      }
+  }
   for (int d = 0; d < 64; d++) {
     if (!((mask >> d) & 1ull)) continue;
     hipError_t err = hipSetDevice(d);

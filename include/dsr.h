@@ -202,7 +202,8 @@ int dsr_reset_scene(dsr_engine *e);
 int dsr_sync(dsr_engine *e);
 /* Blocks until all work of EVERY engine of this process is done, on every device an engine was
  * created on (the host's per-frame "final sanity check": ITMSafeCall(cudaDeviceSynchronize()) +
- * cudaGetLastError(), DynSlam.cpp:163-172).  Returns DSR_E_DEVICE if a device reports an error. */
+ * cudaGetLastError(), DynSlam.cpp:163-172) — including tracking renders that dsr_prepare / dsr_batch_fuse deferred (ABI 5):
+ * they are queued first, so call it from the thread that drives the engines.  Returns DSR_E_DEVICE if a device reports an error. */
 int dsr_device_synchronize(void);
 /* Free / total memory of a device in bytes (device < 0: the calling thread's current device): the GUI's memory read-out,
  * cudaMemGetInfo at DynSLAMGUI.cpp:912. */
