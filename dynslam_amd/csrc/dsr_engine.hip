@@ -1349,6 +1349,10 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
         dsr_engine *e = b->vols[it.volume];
         o.mask = (const uint8_t *)it.copy_mask_dev; o.x0 = it.x0; o.y0 = it.y0; o.bw = it.box_w; o.bh = it.box_h;
         o.dstRgb = e->rgb; o.dstDepth = e->depth;
+        int wr[4];
+        cutout_write_region(e, true, it.x0, it.y0, it.box_w, it.box_h, wr);  // (batch volumes: one view buffer each, written here)
+        o.wx0 = wr[0]; o.wy0 = wr[1]; o.wx1 = wr[2]; o.wy1 = wr[3];
+        cutout_written(e, true, it.x0, it.y0, it.box_w, it.box_h);
       }
     }
     LAUNCH(src, "batch_split", k_batch_split, dim3(div_up(src->W, 16), div_up(src->H, 16)), dim3(256), src->rgb, src->depth, src->W, src->H, sp, n);

@@ -104,6 +104,10 @@ struct dsr_engine {
   // the box (pixels, end exclusive) outside which the current view's depth is known to be 0: set by the silhouette cut-out
   // that produced an instance's view, the whole image after any other writer.  The allocation's per-pixel mark runs over it.
   int viewBox[4] = {0, 0, 0, 0};
+  // ... and (round 6) the box outside which the view BUFFER is known to hold the blank constants of a cut-out (rgb 255, depth 0):
+  // the next cut-out writes only its own box and this one.  Invalid after any other writer of the view.
+  int blankBox[4] = {0, 0, 0, 0};
+  bool blankValid = false;
   int gridExpected = 128;  // workgroups of k_expected_depth_lds (env DSR_GRID_EXPECTED; 64: 60 us, 128: 44, 256: 84)
   Mat4 calibInv, M_d, invM_d;
 
@@ -303,6 +307,9 @@ int begin_view_modify(dsr_engine *e);
 int before_fusion(dsr_engine *e);
 int after_fusion(dsr_engine *e);
 hipStream_t vstream(dsr_engine *e);
+// the pixels a cut-out into `instance`'s view has to write for a mask box (x0, y0, w, h), and the bookkeeping behind it
+void cutout_write_region(const dsr_engine *instance, bool direct, int x0, int y0, int w, int h, int wr[4]);
+void cutout_written(dsr_engine *instance, bool direct, int x0, int y0, int w, int h);
 // dsr_engine.hip
 extern std::atomic<int> g_enginesOnDevice[64];  // live engines per device (range-image overlap policy, preview stores)
 int engine_set_device(dsr_engine *e);

@@ -83,6 +83,25 @@ int io_read_done(dsr_engine *e, hipStream_t io) {
 // ---- the pipelined view (see dsr_engine): which stream a view operation of `e` runs on, and the hand-over of buffers
 hipStream_t vstream(dsr_engine *e) { return e->pipelinedView ? e->viewStream : e->stream; }
 
+// `direct`: the cut-out kernel writes the instance's ONE view buffer itself (no double buffering, no transfer pair)
+void cutout_write_region(const dsr_engine *instance, bool direct, int x0, int y0, int w, int h, int wr[4]) {
+  const int W = instance->W, H = instance->H;
+  wr[0] = 0; wr[1] = 0; wr[2] = W; wr[3] = H;
+  if (!direct || !instance->blankValid) return;
+  const int b[4] = {std::max(0, x0), std::max(0, y0), std::min(W, x0 + w), std::min(H, y0 + h)};
+  const int *o = instance->blankBox;
+  const bool bEmpty = b[0] >= b[2] || b[1] >= b[3], oEmpty = o[0] >= o[2] || o[1] >= o[3];
+  if (bEmpty && oEmpty) { wr[2] = 0; wr[3] = 0; return; }
+  if (bEmpty) { for (int k = 0; k < 4; ++k) wr[k] = o[k]; return; }
+  if (oEmpty) { for (int k = 0; k < 4; ++k) wr[k] = b[k]; return; }
+  wr[0] = std::min(b[0], o[0]); wr[1] = std::min(b[1], o[1]); wr[2] = std::max(b[2], o[2]); wr[3] = std::max(b[3], o[3]);
+}
+void cutout_written(dsr_engine *instance, bool direct, int x0, int y0, int w, int h) {  // (after begin_view_replace, which invalidates)
+  instance->blankValid = direct;
+  instance->blankBox[0] = std::max(0, x0); instance->blankBox[1] = std::max(0, y0);
+  instance->blankBox[2] = std::min(instance->W, x0 + w); instance->blankBox[3] = std::min(instance->H, y0 + h);
+}
+
 struct ViewTarget { uchar4 *rgb; float *depth; };
 
 // `ws` is about to REPLACE e's whole view (ingest, SetView, a cut-out from another engine's view): -> the buffers to write
@@ -90,6 +109,7 @@ int begin_view_replace(dsr_engine *e, hipStream_t ws, ViewTarget *t) {
   int st = before_view_write(e, ws);  // readers on the I/O stream
   if (st) return st;
   e->viewBox[0] = 0; e->viewBox[1] = 0; e->viewBox[2] = e->W; e->viewBox[3] = e->H;  // (a cut-out narrows it afterwards)
+  e->blankValid = false;  // (... and says what it left blank)
   if (!e->pipelinedView) { t->rgb = e->rgb; t->depth = e->depth; return DSR_OK; }
   if (!e->rgbAlt) {
     if ((st = dmalloc(&e->rgbAlt, (size_t)e->Wr * e->Hr)) || (st = dmalloc(&e->depthAlt, (size_t)e->P))) return st;
@@ -113,6 +133,7 @@ int end_view_replace(dsr_engine *e, hipStream_t ws, bool recordView = true) {
 }
 // an in-place modification of the CURRENT view on e's view stream (blanking a silhouette): after the fusion that read this buffer
 int begin_view_modify(dsr_engine *e) {
+  e->blankValid = false;  // (a blanked silhouette is rgb 0, not the cut-out's blank)
   hipStream_t ws = vstream(e);
   int st = before_view_write(e, ws);
   if (st) return st;
@@ -561,6 +582,9 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     HIP_TRY(hipStreamWaitEvent(ws, instance->xEvent, 0));
   }
   if (blank) { int st = begin_view_modify(e); if (st) return st; }
+  const bool direct = !peer && !instance->pipelinedView;
+  int wr[4];
+  cutout_write_region(instance, direct, x0, y0, box_w, box_h, wr);
   ViewTarget t;
   {
     // (a pipelined instance allocates its spare view buffers and their events on first use: on ITS GPU, not on main's)
@@ -589,7 +613,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     StreamSwap sw(e, ws);
     if (blank)
       LAUNCH(e, "split_silhouette", k_split_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256), e->rgb, e->depth, dstRgb,
-             dstDepth, e->W, e->H, maskDev, x0, y0, box_w, box_h, rmaskDev, rx0, ry0, rbw, rbh);
+             dstDepth, e->W, e->H, maskDev, x0, y0, box_w, box_h, rmaskDev, rx0, ry0, rbw, rbh, make_int4(wr[0], wr[1], wr[2], wr[3]));
     else
       LAUNCH(e, "extract_silhouette", k_extract_silhouette, dim3(div_up(e->W, 16), div_up(e->H, 16)), dim3(256),
              (const uchar4 *)e->rgb, (const float *)e->depth, dstRgb, dstDepth, e->W, e->H,
@@ -625,6 +649,7 @@ static int extract_silhouette(dsr_engine *main_engine, dsr_engine *instance, con
     }
     if (peer) HIP_TRY(hipSetDevice(e->device));
   }
+  if (blank) cutout_written(instance, direct, x0, y0, box_w, box_h);  // (the extract-only kernel writes the whole frame)
   // outside the mask's box the cut-out is empty (depth 0): the instance's allocation mark need not look there
   instance->viewBox[0] = std::max(0, x0); instance->viewBox[1] = std::max(0, y0);
   instance->viewBox[2] = std::min(e->W, x0 + box_w); instance->viewBox[3] = std::min(e->H, y0 + box_h);

@@ -63,6 +63,7 @@ struct BatchSplitItem {
   uchar4 *dstRgb;
   float *dstDepth;
   int x0, y0, bw, bh, rx0, ry0, rbw, rbh;
+  int wx0, wy0, wx1, wy1;  // the pixels of the cut-out that have to be written (k_edges.h k_split_silhouette `wr`)
 };
 struct BatchSplit { BatchSplitItem it[kBatchMax]; };
 __global__ __launch_bounds__(256) void k_batch_split(uchar4 *srcRgb, float *srcDepth, int W, int H, BatchSplit b, int n) {
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_batch_split(uchar4 *srcRgb, float *srcD
   bool blanked = false;
   for (int k = 0; k < n; ++k) {
     const BatchSplitItem &it = b.it[k];
-    if (it.mask) {
+    if (it.mask && x >= it.wx0 && x < it.wx1 && y >= it.wy0 && y < it.wy1) {
       const int col = x - it.x0, row = y - it.y0;
       if (col >= 0 && col < it.bw && row >= 0 && row < it.bh && it.mask[row * it.bw + col] == 1) {
         it.dstRgb[idx] = c;

@@ -192,20 +192,26 @@ __global__ __launch_bounds__(256) void k_extract_silhouette(const uchar4 *__rest
 // ProcessSilhouette_CPU + RemoveSilhouette_CPU of one instance in ONE pass over the frame (dsr_view_split_silhouette): the
 // cut-out is taken from the pixel as it is BEFORE this instance's blanking, which is the order of the two host loops
 // (InstanceReconstructor.cpp:238-263).  The two masks differ in the reference (copy mask x1.0, delete mask x1.2: Utils/Mask.cpp).
+// wr (round 6): the pixels of the cut-out that have to be WRITTEN — the instance's view is known to hold the blank constants
+// outside the box of its previous cut-out (dsr_engine::blankBox), so only the new box and the old one are; the whole image when
+// nothing is known about the buffer.  (An instance covers a few per cent of the frame: 3.7 MB of constants per instance and frame.)
 __global__ __launch_bounds__(256) void k_split_silhouette(uchar4 *srcRgb, float *srcDepth, uchar4 *__restrict__ dstRgb,
                                                           float *__restrict__ dstDepth, int W, int H,
                                                           const uint8_t *__restrict__ mask, int x0, int y0, int bw, int bh,
-                                                          const uint8_t *__restrict__ rmask, int rx0, int ry0, int rbw, int rbh) {
+                                                          const uint8_t *__restrict__ rmask, int rx0, int ry0, int rbw, int rbh,
+                                                          int4 wr) {
   const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
   if (x >= W || y >= H) return;
   const int idx = x + y * W;
   const int col = x - x0, row = y - y0;
-  if (col >= 0 && col < bw && row >= 0 && row < bh && mask[row * bw + col] == 1) {
-    dstRgb[idx] = srcRgb[idx];
-    dstDepth[idx] = srcDepth[idx];
-  } else {
-    dstRgb[idx] = make_uchar4(255, 255, 255, 255);
-    dstDepth[idx] = 0.0f;
+  if (x >= wr.x && x < wr.z && y >= wr.y && y < wr.w) {
+    if (col >= 0 && col < bw && row >= 0 && row < bh && mask[row * bw + col] == 1) {
+      dstRgb[idx] = srcRgb[idx];
+      dstDepth[idx] = srcDepth[idx];
+    } else {
+      dstRgb[idx] = make_uchar4(255, 255, 255, 255);
+      dstDepth[idx] = 0.0f;
+    }
   }
   const int rcol = x - rx0, rrow = y - ry0;
   if (rcol >= 0 && rcol < rbw && rrow >= 0 && rrow < rbh && rmask[rrow * rbw + rcol] == 1) {

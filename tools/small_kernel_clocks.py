@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--twice", action="store_true", help="render the preview twice per frame (second pose perturbed: not served from the "
                     "free-view cache) and report the second launch too: code and data of the first are still in the caches")
+    ap.add_argument("--reset-every", type=int, default=0, help="ResetScene of the instance volume every N frames (16: every pass over the "
+                    "sequence allocates again; without it every frame after the first pass re-fuses blocks that exist)")
     a = ap.parse_args()
     if a.build:
         return build()
@@ -71,6 +73,8 @@ def main():
     for i in range(n_unique + a.frames):
         j = i % n_unique
         x0, y0, mk, mk_dev, rel, pose_m = masks[j]
+        if a.reset_every and i % a.reset_every == 0:
+            inst.reset_scene()
         view.update_view_dev(rgb[j].data_ptr(), dep[j].data_ptr())
         view.split_silhouette_dev(inst, mk_dev.data_ptr(), x0, y0, mk.shape[1], mk.shape[0])
         inst.set_pose_inv_m(rel)
@@ -90,7 +94,7 @@ def main():
             t2 = buf.cpu().numpy().astype(np.int64)
             acc_f2 += np.diff(t2[16:21]) / 100.0
         n += 1
-    res = {"frames": n,
+    res = {"frames": n, "reset_every": a.reset_every,
            "small_alloc_visible_us": {k: round(float(v / n), 2) for k, v in zip(names_a, acc_a)},
            "small_alloc_visible_total_us": round(float(acc_a.sum() / n), 2),
            "small_freeview_us": {k: round(float(v / n), 2) for k, v in zip(names_f, acc_f)},
