@@ -592,15 +592,21 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   // shared stream asks for _OFF instead of switching the whole process with the environment variable.
   if (s.view_pipeline < DSR_VIEW_PIPELINE_AUTO || s.view_pipeline > DSR_VIEW_PIPELINE_SHARED) { delete e; return fail(DSR_E_ARG, "bad view_pipeline"); }
   const int pvMode = s.view_pipeline == DSR_VIEW_PIPELINE_OFF ? 0 : s.view_pipeline == DSR_VIEW_PIPELINE_PER_ENGINE ? 1
-                     : s.view_pipeline == DSR_VIEW_PIPELINE_SHARED ? 2
-                     : getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : (s.sync_status ? 2 : 0);
+                     : s.view_pipeline == DSR_VIEW_PIPELINE_SHARED ? 3
+                     : getenv("DSR_PIPELINED_VIEW") ? atoi(getenv("DSR_PIPELINED_VIEW")) : (s.sync_status ? 3 : 0);
   auto shared_stream = [&](hipStream_t *table) -> hipStream_t {
     if (e->device < 0 || e->device >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_ioMutex);
     if (!table[e->device] && create_stream(&table[e->device]) != hipSuccess) table[e->device] = nullptr;
     return table[e->device];
   };
-  if (pvMode == 2 && s.sdf_local_block_num <= 16384 && (e->stream = shared_stream(g_sharedSmallStream))) e->ownsStream = false;
+  // Form 3 (round 6, the default of engines a host waits on): as form 2, but the instance-sized volumes fuse on the shared VIEW
+  // stream itself — an instance's cut-out, mark, lists, integration and renders are then ordered by ONE queue, where form 2 paid a
+  // cross-queue dependency (13-20 us on this part) between the view stream and the small volumes' fusion stream per instance and
+  // frame: configs[2] through the C++ host 696-702 -> 748-756 frames/s at 20 steps, 774-776 -> 808-814 at 45, identical results
+  // (profiles/r06q_through_shim_pv3.log).  env DSR_PIPELINED_VIEW=2: form 2.
+  if (pvMode == 3 && s.sdf_local_block_num <= 16384 && (e->stream = shared_stream(g_sharedViewStream))) e->ownsStream = false;
+  else if (pvMode >= 2 && s.sdf_local_block_num <= 16384 && (e->stream = shared_stream(g_sharedSmallStream))) e->ownsStream = false;
   else if (create_stream(&e->stream) != hipSuccess) { delete e; return fail(DSR_E_DEVICE, "hipStreamCreate failed"); }
   // The side stream exists only for volumes whose integration is long enough to hide something under (not for instance-sized
   // ones, not for a map at the reference's 5 cm / 2^18 blocks, whose whole frame is 0.24 ms), and at DEFAULT priority: every stream of a process competes for the same few hardware queues, and a scene of one
@@ -686,7 +692,7 @@ int dsr_engine_create(const dsr_settings *settings, const dsr_calib *calib, dsr_
   // (form 1 — a view stream and a fusion stream PER ENGINE — measured in round 4: 388 frames/s at the runtime's default of 4 hardware
   //  queues against 453 without a view pipeline, 488-498 only with GPU_MAX_HW_QUEUES=16: twice the streams share the queues)
   e->pipelinedView = pvMode != 0;
-  if (e->pipelinedView && pvMode == 2 && (e->viewStream = shared_stream(g_sharedViewStream))) e->ownsViewStream = false;
+  if (e->pipelinedView && pvMode >= 2 && (e->viewStream = shared_stream(g_sharedViewStream))) e->ownsViewStream = false;
   else if (e->pipelinedView && create_stream(&e->viewStream) != hipSuccess) {
     free_all(e); delete e; return fail(DSR_E_DEVICE, "view stream creation failed");
   }

@@ -120,7 +120,8 @@ typedef struct dsr_settings {
                                   DSR_VIEW_PIPELINE_AUTO (0: engines with sync_status get the shared form, others none —
                                   round 5's default; env DSR_PIPELINED_VIEW=0/1/2 overrides AUTO only), _OFF: one stream for
                                   everything — what dsr_engine_share_stream and dsr_batch_create need, also for an engine
-                                  whose host waits for its status —, _PER_ENGINE, _SHARED                              */
+                                  whose host waits for its status —, _PER_ENGINE, _SHARED (one view stream per GPU, on which the
+                                  instance-sized volumes of that GPU also fuse: AUTO's choice for sync_status engines)   */
   int32_t reserved[6];
 } dsr_settings;
 #define DSR_VIEW_PIPELINE_AUTO 0
