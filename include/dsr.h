@@ -22,8 +22,8 @@
  *     distinct threads — with two things shared per GPU and process: the I/O stream
  *     (frame uploads, previews, view read-backs of ALL engines of that GPU queue on
  *     it in call order) and, for engines a host waits on (sync_status), the view
- *     stream and the instance-sized volumes' fusion stream (DSR_PIPELINED_VIEW=2,
- *     the default for them).  DynSLAM drives all its drivers from one thread
+ *     stream, on which the instance-sized volumes of that GPU also fuse
+ *     (dsr_settings.view_pipeline, the SHARED form: their default).  DynSLAM drives all its drivers from one thread
  *     (SURVEY 8b); a host that drives a map and its instance drivers from several
  *     threads gets correct results and head-of-line waits on those streams.
  *     Engines that share a stream explicitly (dsr_engine_share_stream, a
