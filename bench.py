@@ -639,6 +639,8 @@ def run_volumes(args, frames, make_engine, dev, world, rank, use_dist, host_api=
                 scene.step(frames[i][0], frames[i][1], frames[i][2], masks_in[i])
             if preview:
                 scene.preview(pose_m[i], inst_m[i], track_ids)
+            if getattr(args, "sync_every_step", False):
+                scene.sync()
 
         def barrier():
             scene.sync()
@@ -946,6 +948,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs3", action="store_true", help="--gpus N > 1: only the instance-volumes leg")
     ap.add_argument("--replicas", action="store_true", help="--gpus N: N independent configs[1] replicas, no collective")
     ap.add_argument("--no-time-sliced", action="store_true", help="skip the 1-GPU time-sliced leg of a multi-volume line")
+    ap.add_argument("--sync-every-step", action="store_true",
+                    help="diagnostic (multi-volume legs): the host waits for every step before it queues the next — a GUI host's "
+                         "pattern; ms_per_step is then a step's LATENCY, not the rate of a full queue")
     ap.add_argument("--no-nested-legs", action="store_true", help="skip configs[2] / configs[3] on one GPU / the short configs[4] leg of the N = 1 line")
     ap.add_argument("--no-scaling-leg", action="store_true",
                     help="N = 1: do not append north_star's scaling workload (8 instance volumes on this GPU) to the line")
