@@ -44,8 +44,8 @@ constexpr int kSmallMaxTiles = kSmallThreads;                              // on
 // searches in LDS, and the visible list is one dense pass over the list — type and table entry of every allocated entry
 // requested together, "touched by this frame's mark" / "visible last frame, re-test" decided per entry, ordered compaction.  No
 // plane is swept.  The bit planes stay the ground truth: a frame that cannot take the list path — the first after a reset or a
-// GC pass (list invalid), an exhausted block array (entries that are visible without owning a block), a visible list that
-// overflowed, more than kSmallNewMax new entries — runs the sweeps as before and rebuilds the list from allocBits at its end.
+// GC pass (list invalid), an exhausted block array, every frame whose PREVIOUS visible list holds an entry without a block (such
+// an entry is re-tested and stays visible while it is in the frustum; the list does not know it), a visible list that overflowed, more than kSmallNewMax new entries — runs the sweeps as before and rebuilds the list from allocBits at its end.
 constexpr int kSmallNewMax = 2048;                                         // new entries a frame may merge on the list path
 // dynamic LDS of the two kernels: the range image, or — aliased with it, used before it — the merge's scratch
 // (the old list + the frame's new entries, raw and sorted)
@@ -55,7 +55,8 @@ struct SmallShared {  // head of the dynamic LDS; the range image follows
   int2 scan[kSmallWaves];
   int waveTotal[kSmallWaves];
   int oldV, oldE, nPrev, overflowPrev;
-  int nIds, idsValid, pad0, pad1;  // SceneP::allocIds: length, validity (read once by thread 0)
+  int nIds, idsValid;  // SceneP::allocIds: length, validity (read once by thread 0)
+  int ghost, pad1;     // the visible list of this frame holds an entry WITHOUT a block (phase G)
   int box[4];  // store_range_image (k_raycast.h): the box of the image's non-empty cells
 };
 static_assert(sizeof(SmallShared) % sizeof(int2) == 0, "the range image behind it is an int2 array");
@@ -166,6 +167,7 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
     sh.nPrev = s.ctr[CTR_NO_VISIBLE_LIVE]; sh.overflowPrev = s.ctr[CTR_VIS_OVERFLOW];
     sh.nIds = s.ctr[CTR_NO_ALLOC_IDS]; sh.idsValid = lists ? s.ctr[CTR_ALLOC_IDS_VALID] : 0;
     sh.box[0] = sh.box[1] = 0x7fffffff; sh.box[2] = sh.box[3] = -1;
+    sh.ghost = 0;
   }
   // ---- A
   int2 *allocTile = reinterpret_cast<int2 *>(s.allocTile);
@@ -468,11 +470,17 @@ __device__ __forceinline__ void small_alloc_visible_body(const FrameP &p, const 
         visBlocks[i] = rec;
         const dsr_hash_entry he = entry_of_record(rec);
         if (he.ptr >= 0) valid = project_single_block<DeviceOps>(he.pos, p, mw, mh, ul, lr, zr);
+        else sh.ghost = 1;
       }
       fold_wave_boxes(cells, mw, valid, ul, lr, zr, lane);
     }
-  if (n <= 0) return;  // Prepare() is skipped without visible blocks: the image keeps its previous contents
   __syncthreads();
+  // An entry that is visible WITHOUT owning a block (the mark named it as an allocation target while the block array was
+  // exhausted; upstream keeps it visible, and re-tests it like every other entry of the list in the frames that follow) is not in
+  // the sorted list of allocated entries, so phase H would never look at it again: while the visible list holds one, the list
+  // path stays off (found by tests/test_gpu_fuzz.py, seeds 188 and 398)
+  if (!fast && lists && tid == 0 && sh.ghost) s.ctr[CTR_ALLOC_IDS_VALID] = 0;
+  if (n <= 0) return;  // Prepare() is skipped without visible blocks: the image keeps its previous contents
   SMALL_CLK(8);
   store_range_image(cells, minmax, nCells, mw, rb, sh.box);
   SMALL_CLK(9);

@@ -561,7 +561,10 @@ int dsr_dump_allocation_lists(dsr_engine *e, int32_t *voxel_alloc_list, int32_t 
  *   points/normals: 4*W*H floats (trackingState->pointCloud; live only)
  *   raycast_image : 4*W*H bytes   (The range image of the LIVE view is computed right after the visible list,
  * under the integration — so between dsr_process_frame and dsr_prepare a dump already shows the new frame's image; the
- * reference's structure of the same name is internal to its visualisation engine and never read by the host.) */
+ * reference's structure of the same name is internal to its visualisation engine and never read by the host.  For the same
+ * reason, after dsr_process_frame calls that were not followed by dsr_prepare, a frame WITHOUT visible blocks — dsr_prepare is
+ * skipped, the image "keeps its previous contents" — leaves the image of the last dsr_process_frame here, where the serial engine
+ * has the image of its last Prepare(); nothing reads it before the next frame with visible blocks rebuilds it: DESIGN.md 5.) */
 int dsr_dump_render_state(dsr_engine *e, int which, float *minmax, float *raycast_result,
                           float *points, float *normals, uint8_t *raycast_image);
 

@@ -49,19 +49,19 @@ def feed(engines, sc, i, prepare=True, ignore_oob=False):
 
 def assert_scene_equal(g, o, voxels=True):
     sg, so = g.get_stats(), o.get_stats()
-    assert sg.last_free_block_id == so.last_free_block_id
-    assert sg.last_free_excess_list_id == so.last_free_excess_list_id
-    assert sg.no_visible_blocks == so.no_visible_blocks
-    assert sg.decayed_block_count == so.decayed_block_count
+    for k in ("last_free_block_id", "last_free_excess_list_id", "no_visible_blocks", "decayed_block_count"):
+        assert getattr(sg, k) == getattr(so, k), f"{k}: {getattr(sg, k)} vs {getattr(so, k)}"
     hg, ho = g.dump_hash_table(), o.dump_hash_table()
     assert np.array_equal(hg, ho), f"hash table differs in {(hg != ho).sum()} entries"
-    assert np.array_equal(g.dump_visible_list(), o.dump_visible_list())
-    assert np.array_equal(g.dump_visible_types(), o.dump_visible_types())
+    lg, lo = g.dump_visible_list(), o.dump_visible_list()
+    assert np.array_equal(lg, lo), f"visible list differs: {len(lg)} vs {len(lo)} entries, only here {np.setdiff1d(lg, lo)[:8]}, only there {np.setdiff1d(lo, lg)[:8]}"
+    tg, to = g.dump_visible_types(), o.dump_visible_types()
+    assert np.array_equal(tg, to), f"visible types differ at {np.nonzero(tg != to)[0][:8]}: {tg[tg != to][:8]} vs {to[tg != to][:8]}"
     vg, vo = g.dump_allocation_lists(), o.dump_allocation_lists()
     n = so.last_free_block_id + 1  # only the live part of the free list is defined
-    assert np.array_equal(vg[0][:n], vo[0][:n])
+    assert np.array_equal(vg[0][:n], vo[0][:n]), "the live part of the block free list differs"
     m = so.last_free_excess_list_id + 1
-    assert np.array_equal(vg[1][:m], vo[1][:m])
+    assert np.array_equal(vg[1][:m], vo[1][:m]), "the live part of the excess free list differs"
     if voxels:
         bg, bo = g.dump_voxel_blocks(), o.dump_voxel_blocks()
         if not np.array_equal(bg, bo):
@@ -70,9 +70,9 @@ def assert_scene_equal(g, o, voxels=True):
                                  f"{bg[tuple(bad[0])]} vs {bo[tuple(bad[0])]}")
 
 
-def assert_render_equal(g, o, freeview=False):
+def assert_render_equal(g, o, freeview=False, skip=()):
     rg, ro = g.dump_render_state(freeview), o.dump_render_state(freeview)
-    keys = ["minmax", "raycast_result", "raycast_image"] + ([] if freeview else ["points", "normals"])
+    keys = [k for k in ["minmax", "raycast_result", "raycast_image"] + ([] if freeview else ["points", "normals"]) if k not in skip]
     for k in keys:
         a, b = rg[k], ro[k]
         if not np.array_equal(a, b):
