@@ -166,7 +166,10 @@ int reset_scene(dsr_engine *e) {
   e->fifoHead = 0; e->fifoLen = 0;
   // (the render buffers keep whatever the previous scene left in them: the next raycast of each render state is a full-frame one)
   for (RenderStateDev *rs : {&e->live, &e->freeview})
-    if (rs->rayBox) hipLaunchKernelGGL(k_raybox_reset, dim3(1), dim3(RB_WORDS), 0, e->stream, rs->rayBox, (e->W + 7) / 8, (e->H + 7) / 8);
+    if (rs->rayBox) {
+      hipLaunchKernelGGL(k_raybox_reset, dim3(1), dim3(RB_WORDS), 0, e->stream, rs->rayBox, (e->W + 7) / 8, (e->H + 7) / 8, e->rayBoxLive ? 1 : 0);
+    }
+  e->rayBoxLive = true;
   HIP_TRY(hipGetLastError());
   if (e->statusHost) {
     // the published words describe a scene that no longer exists; the next allocation publishes number statusSeq + 1
@@ -1396,7 +1399,10 @@ int dsr_batch_fuse(dsr_batch *b, const dsr_batch_item *items, int n_items, int32
     e->liveExp.valid = true; e->liveExp.onSide = false; e->liveExp.version = e->listVersion; e->liveExp.M = e->M_d;
     memcpy(e->liveExp.proj, proj, sizeof proj);
   }
-  if (rgbSame < 0) return DSR_OK;  // only blanking in this frame
+  if (rgbSame < 0) {  // only blanking in this frame
+    if (status_out) for (int i = 0; i < n_items; ++i) status_out[i] = DSR_OK;
+    return DSR_OK;
+  }
   const dim3 img(div_up(src->W, 16), div_up(src->H, 16), nv);
   if (maxTilesX > 0 && maxTilesY > 0)
     LAUNCH(src, "batch_alloc_mark", k_batch_alloc_mark, dim3(maxTilesX, maxTilesY, nv), dim3(256), frames, (const BatchVolP *)b->volsDev);

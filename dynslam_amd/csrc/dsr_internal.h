@@ -236,6 +236,7 @@ struct dsr_engine {
   // (CHECK_E below) queues the deferred work first, so no caller ever sees a stream without it.  What the pending launch needs is
   // kept here: the camera of the prepare call.  env DSR_PAIR_RENDER=0: off.
   bool pairRender = false;
+  bool rayBoxLive = false;   // the ray-box records have been initialised once (a later reset keeps their LAST / POSE part)
   struct { bool pending = false; FrameP p; } trackRender;
   struct dsr_batch *ownerBatch = nullptr;  // the volume batch this engine is a source / volume of (it may hold deferred work too)
 

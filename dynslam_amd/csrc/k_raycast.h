@@ -353,16 +353,20 @@ __device__ __forceinline__ void fold_wave_boxes(int2 *cellsLds, int mw, bool val
 // render_pixel, render_depth test w first).  The xyz of a miss (the ray's far-plane start point: pose dependent, never read by
 // the path) goes stale outside DIRTY; dsr_dump_render_state — the parity tests' view of the buffer — completes it with
 // k_raycast_fill_outside from LAST + POSE, so a dump equals the serial engine's buffer bit for bit as before.
-// After creation / a reset DIRTY is the whole image: the first raycast is a full-frame one.
+// After creation / a reset DIRTY is the whole image: the first raycast is a full-frame one (a reset keeps LAST / EVER / POSE: the
+// buffers still hold the previous scene's renders until then).
 constexpr int RB_CUR = 0, RB_DIRTY = 4, RB_RAN = 8, RB_LAST = 9, RB_EVER = 13, RB_POSE = 16, RB_WORDS = 128;
 static_assert(RB_POSE * 4 + sizeof(FrameP) <= RB_WORDS * 4, "the pose record must fit");
 static_assert(sizeof(FrameP) % 4 == 0, "FrameP is copied word by word");
 
-__global__ void k_raybox_reset(int32_t *rb, int mw, int mh) {
-  if (threadIdx.x < RB_WORDS) rb[threadIdx.x] = 0;
+// keepLast (a ResetScene, not the creation): LAST / EVER / POSE stay — the render buffers keep what the previous scene's raycasts
+// left in them (as the serial engine's do), and until the next raycast runs a dump still needs that record to complete them
+__global__ void k_raybox_reset(int32_t *rb, int mw, int mh, int keepLast) {
+  if (threadIdx.x < (keepLast ? RB_LAST : RB_WORDS)) rb[threadIdx.x] = 0;
   __syncthreads();
   if (threadIdx.x == 0) { rb[RB_DIRTY + 2] = mw; rb[RB_DIRTY + 3] = mh; }
 }
+static_assert(RB_CUR < RB_LAST && RB_DIRTY < RB_LAST && RB_RAN < RB_LAST && RB_EVER > RB_LAST && RB_POSE > RB_LAST, "k_raybox_reset's split");
 
 // All threads of the ONE workgroup that holds the finished range image in LDS: store it, find the box of its non-empty cells,
 // update the record.  boxLds: 4 ints of LDS set to {INT_MAX, INT_MAX, -1, -1} before the barrier that precedes this call.

@@ -77,5 +77,9 @@ def assert_render_equal(g, o, freeview=False, skip=()):
         a, b = rg[k], ro[k]
         if not np.array_equal(a, b):
             bad = np.argwhere(a != b)
+            where = ""
+            if a.ndim == 3:  # an image: rows x columns x components
+                where = (f"; rows {bad[:, 0].min()}..{bad[:, 0].max()}, columns {bad[:, 1].min()}..{bad[:, 1].max()}, per component "
+                         f"{[int((bad[:, 2] == c).sum()) for c in range(a.shape[2])]}")
             raise AssertionError(f"render state '{k}' differs at {len(bad)} elements, first {bad[0]}: "
-                                 f"{a[tuple(bad[0])]} vs {b[tuple(bad[0])]}")
+                                 f"{a[tuple(bad[0])]} vs {b[tuple(bad[0])]}{where}")

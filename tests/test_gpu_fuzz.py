@@ -116,3 +116,147 @@ def test_random_call_sequences_equal_the_oracle(hip_api, seed):
         raise AssertionError(f"seed {seed} kind {kind} {W}x{H} {kw}\ncalls: {log}\n{ex}") from None
     finally:
         g.close(); o.close()
+
+
+def _batch_seeds():
+    spec = os.environ.get("DSR_FUZZ_BATCH_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    # 2, 219: a frame that only blanks (no volume of the batch has a detection) left the status words of the call undefined;
+    # 412: a reset followed by a frame without visible blocks — the ray box forgot which pose the buffer's misses belong to
+    return [1, 2, 3, 4, 219, 412]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _batch_seeds())
+def test_random_batch_sequences_equal_the_oracle(hip_api, monkeypatch, seed):
+    """The volume batch (dsr_batch_*: one launch of every kernel for all instance volumes of a GPU, the tracking render deferred and
+    paired with the preview render) against the oracle running the reference's per-instance loop, over a random sequence: frames
+    from jumping poses, detections that come and go, steps without a preview, previews of a subset from perturbed cameras, and
+    per-volume calls in between (a voxel GC pass, a reset, a host-buffer image: each has to flush what the batch deferred)."""
+    import torch
+    monkeypatch.setenv("DSR_PIPELINED_VIEW", "0")
+    from dynslam_amd.engine import Batch, EngineCore, OutOfBlocksError, default_settings, make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, oracle_settings
+    rng = np.random.default_rng(7000 + seed)
+    W, H = [(256, 80), (320, 96), (251, 83)][rng.integers(3)]
+    n_inst = int(rng.integers(2, 7))
+    nv = int(rng.integers(2, min(n_inst, 5) + 1))
+    owned = {int(k): v for v, k in enumerate(sorted(rng.choice(n_inst, nv, replace=False)))}   # instance -> volume of the batch
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=int(rng.choice([3, 100])), view_frustum_min=0.2, view_frustum_max=float(rng.choice([12.0, 30.0])),
+                   sdf_local_block_num=int(rng.choice([300, 2000, 7142])), hash_bucket_num=0x100000, excess_list_size=0x20000)
+    view_kw = dict(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0, sdf_local_block_num=64,
+                   hash_bucket_num=64, excess_list_size=64)
+    sc = StreetScene(W, H, n_instances=n_inst, noise_px=float(rng.choice([0.0, 0.4])))
+    calib = make_calib(*sc.intrinsics(), W, H)
+    sync_status = int(rng.integers(2))
+    bs = EngineCore(default_settings(**view_kw, sync_status=sync_status), calib)
+    bi = [EngineCore(default_settings(**inst_kw, sync_status=sync_status), calib) for _ in range(nv)]
+    os_ = OracleEngine(oracle_settings(**view_kw), calib, threads=8)
+    oi = [OracleEngine(oracle_settings(**inst_kw), calib, threads=8) for _ in range(nv)]
+    batch = Batch(bs, bi)
+    dev = torch.device("cuda", 0)
+    out = [(torch.zeros((H * W, 4), dtype=torch.uint8, device=dev), torch.zeros((H * W,), dtype=torch.float32, device=dev)) for _ in range(nv)]
+    frame, log = int(rng.integers(0, 3)), []
+    fused = [False] * nv
+    try:
+        for step in range(int(rng.integers(6, 12))):
+            frame = max(0, frame + int(rng.choice([1, 1, 1, 2, 4, -2])))
+            rgba, d, T, inst_id = sc.frame(frame)
+            masks = []
+            for k in range(n_inst):
+                ys, xs = np.nonzero(inst_id == k)
+                if len(ys) == 0 or rng.random() < 0.2:       # no detection of this instance in this frame
+                    continue
+                y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+                m = np.ascontiguousarray((inst_id[y0:y1, x0:x1] == k).astype(np.uint8))
+                rel = (np.linalg.inv(sc.instance_pose(k, frame).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
+                masks.append((k, int(x0), int(y0), m, rel))
+            log.append(("frame", frame, [k for k, *_ in masks]))
+            for e in (bs, os_):
+                e.update_view(rgba, d)
+            if masks:
+                mt = [torch.from_numpy(m).to(dev) for _, _, _, m, _ in masks]
+                items = []
+                for (k, x0, y0, m, rel), t in zip(masks, mt):
+                    mk = (t.data_ptr(), m.shape[1], m.shape[0])
+                    items.append((owned.get(k, -1), mk if k in owned else None, x0, y0, mk, x0, y0, rel if k in owned else None))
+                status = batch.fuse(items, want_status=bool(sync_status))
+                oob = set()
+                for k, x0, y0, m, rel in masks:               # the reference's loop on the oracle
+                    if k in owned:
+                        os_.extract_silhouette(oi[owned[k]], m, x0, y0)
+                    os_.remove_silhouette(m, x0, y0)
+                    if k in owned:
+                        e = oi[owned[k]]
+                        e.set_pose_inv_m(rel)
+                        try:
+                            e.process_frame()
+                        except OutOfBlocksError:
+                            oob.add(owned[k])
+                        e.prepare()
+                        fused[owned[k]] = True
+                if sync_status:
+                    assert {items[i][0] for i, s in enumerate(status) if s != 0} == oob, (log, status, oob)
+                del mt
+            vb, vo = bs.get_view(), os_.get_view()
+            assert np.array_equal(vb[0], vo[0]) and np.array_equal(vb[1], vo[1]), (log, "blanked main view differs")
+            touched = [owned[k] for k, *_ in masks if k in owned]
+            # a per-volume call between the batch's two calls: it has to see (and flush) what the batch deferred
+            between = rng.choice(["none", "none", "decay", "reset", "image"], p=[0.35, 0.25, 0.15, 0.1, 0.15])
+            v0 = int(rng.integers(nv))
+            if between == "decay":
+                args = (int(rng.choice([1, 5, 100])), int(rng.choice([0, 1, 2])), bool(rng.random() < 0.3))
+                log.append(("decay", v0) + args)
+                for e in (bi[v0], oi[v0]):
+                    e.decay(*args)
+            elif between == "reset":
+                log.append(("reset", v0))
+                for e in (bi[v0], oi[v0]):
+                    e.reset_scene()
+                fused[v0] = False
+            elif between == "image" and fused[v0]:
+                log.append(("image", v0))
+                a = bi[v0].get_image(_capi.IMAGE_SCENERAYCAST)[0]
+                b = oi[v0].get_image(_capi.IMAGE_SCENERAYCAST)[0]
+                assert np.array_equal(a, b), (log, "tracking render image differs")
+            for v in touched:
+                gb, go = bi[v].get_view(), oi[v].get_view()
+                assert np.array_equal(gb[0], go[0]) and np.array_equal(gb[1], go[1]), (log, f"cut-out of volume {v} differs")
+            for v in range(nv):
+                assert_scene_equal(bi[v], oi[v], voxels=False)
+                if v in touched and not (between == "reset" and v == v0):
+                    empty = oi[v].get_stats().no_visible_blocks == 0
+                    try:
+                        assert_render_equal(bi[v], oi[v], skip=("minmax",) if empty else ())
+                    except AssertionError as ex:
+                        raise AssertionError(f"volume {v}: {ex}") from None
+            # the previews: a subset of the volumes that hold something, from perturbed cameras; some steps have none
+            if rng.random() < 0.75:
+                cand = [(k, rel) for k, _, _, _, rel in masks if k in owned and fused[owned[k]]]
+                picks = [c for c in cand if rng.random() < 0.8]
+                ritems = []
+                for k, rel in picks:
+                    M = np.linalg.inv(np.asarray(rel, np.float64))
+                    M[:3, 3] += rng.normal(0, 0.03, 3)
+                    ritems.append((owned[k], M.astype(np.float32)))
+                if ritems:
+                    log.append(("render", [v for v, _ in ritems]))
+                    batch.render([(v, M, out[v][0].data_ptr(), out[v][1].data_ptr()) for v, M in ritems])
+                    bs.sync()
+                    for v, M in ritems:
+                        oc, od = oi[v].get_image(_capi.IMAGE_FREECAMERA_COLOUR_FROM_VOLUME, pose_m=M, want_rgba=True, want_depth=True)
+                        assert np.array_equal(out[v][1].cpu().numpy().reshape(H, W), od), (log, f"preview depth of volume {v}")
+                        assert np.array_equal(out[v][0].cpu().numpy().reshape(H, W, 4), oc), (log, f"preview colour of volume {v}")
+                        assert np.array_equal(bi[v].dump_visible_list(True), oi[v].dump_visible_list(True)), log
+                        assert_render_equal(bi[v], oi[v], freeview=True)
+        for v in range(nv):
+            assert_scene_equal(bi[v], oi[v])   # every voxel
+    except AssertionError as ex:
+        raise AssertionError(f"batch seed {seed}: {W}x{H}, {n_inst} instances, volumes {owned}, {inst_kw}\ncalls: {log}\n{ex}") from None
+    finally:
+        batch.close()
+        for e in [bs, os_] + bi + oi:
+            e.close()
