@@ -260,3 +260,139 @@ def test_random_batch_sequences_equal_the_oracle(hip_api, monkeypatch, seed):
         batch.close()
         for e in [bs, os_] + bi + oi:
             e.close()
+
+
+def _host_seeds():
+    spec = os.environ.get("DSR_FUZZ_HOST_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return [1, 2, 3, 4, 5, 6]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _host_seeds())
+def test_random_host_pipelines_equal_the_oracle(hip_api, monkeypatch, seed):
+    """The reference host's frame (InfiniTamDriver + InstanceReconstructor: view upload, per detection ProcessSilhouette +
+    RemoveSilhouette + the instance's ProcessFrame / Prepare, then the map's; previews in between) through the per-engine calls on
+    engines a host WAITS on (sync_status), with the view pipeline in each of its forms (the views, their double buffers and the
+    streams the forms share are the asynchronous part of the library): cut-outs as one call or two, masks on the host or in HBM,
+    detections that come and go, previews and view read-backs at random places, a GC pass on the map now and then — views, scenes and
+    render states against the oracle after every frame."""
+    import torch
+    from dynslam_amd.engine import EngineCore, OutOfBlocksError, default_settings, make_calib
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, oracle_settings
+    rng = np.random.default_rng(9000 + seed)
+    pv = int(rng.integers(0, 4))
+    monkeypatch.setenv("DSR_PIPELINED_VIEW", str(pv))
+    if rng.random() < 0.25:
+        monkeypatch.setenv("DSR_FORCE_PEER_PATH", "1")
+    W, H = [(256, 80), (320, 96), (251, 83)][rng.integers(3)]
+    n_inst = int(rng.integers(1, 4))
+    map_kw = dict(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                  sdf_local_block_num=int(rng.choice([9000, 20000])), hash_bucket_num=0x8000, excess_list_size=0x2000)
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=int(rng.choice([3, 100])), view_frustum_min=0.2, view_frustum_max=30.0,
+                   sdf_local_block_num=int(rng.choice([600, 7142])), hash_bucket_num=0x100000, excess_list_size=0x20000)
+    sc = StreetScene(W, H, n_instances=n_inst, noise_px=float(rng.choice([0.0, 0.4])))
+    calib = make_calib(*sc.intrinsics(), W, H)
+    gm = EngineCore(default_settings(**map_kw, sync_status=1), calib)
+    gi = [EngineCore(default_settings(**inst_kw, sync_status=1), calib) for _ in range(n_inst)]
+    om = OracleEngine(oracle_settings(**map_kw), calib, threads=8)
+    oi = [OracleEngine(oracle_settings(**inst_kw), calib, threads=8) for _ in range(n_inst)]
+    shared = pv == 0 and rng.random() < 0.5
+    if shared:
+        for e in gi:
+            e.share_stream(gm)
+    dev = torch.device("cuda", 0)
+    frame, log = int(rng.integers(0, 3)), [("pipelined view", pv, "shared" if shared else "")]
+    fused = [False] * n_inst
+    keep = []
+    try:
+        for step in range(int(rng.integers(5, 10))):
+            frame = max(0, frame + int(rng.choice([1, 1, 1, 2, 3, -2])))
+            rgba, d, T, inst_id = sc.frame(frame)
+            log.append(("frame", frame))
+            for main in (gm, om):
+                main.update_view(rgba, d)
+            for k in range(n_inst):
+                ys, xs = np.nonzero(inst_id == k)
+                if len(ys) == 0 or rng.random() < 0.2:
+                    continue
+                y0, y1, x0, x1 = int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1
+                mask = np.ascontiguousarray((inst_id[y0:y1, x0:x1] == k).astype(np.uint8))
+                how = rng.choice(["two", "split", "two_dev", "split_dev"])
+                log.append((how, k))
+                if how == "two":
+                    gm.extract_silhouette(gi[k], mask, x0, y0); gm.remove_silhouette(mask, x0, y0)
+                elif how == "split":
+                    gm.split_silhouette(gi[k], mask, x0, y0)
+                else:
+                    mt = torch.from_numpy(mask).to(dev)
+                    keep.append(mt)
+                    if how == "two_dev":
+                        gm.extract_silhouette_dev(gi[k], mt.data_ptr(), x0, y0, mask.shape[1], mask.shape[0])
+                        gm.remove_silhouette_dev(mt.data_ptr(), x0, y0, mask.shape[1], mask.shape[0])
+                    else:
+                        gm.split_silhouette_dev(gi[k], mt.data_ptr(), x0, y0, mask.shape[1], mask.shape[0])
+                om.extract_silhouette(oi[k], mask, x0, y0); om.remove_silhouette(mask, x0, y0)
+                rel = (np.linalg.inv(sc.instance_pose(k, frame).astype(np.float64)) @ T.astype(np.float64)).astype(np.float32)
+                raised = []
+                for e in (gi[k], oi[k]):
+                    e.set_pose_inv_m(rel)
+                    try:
+                        e.process_frame(); raised.append(False)
+                    except OutOfBlocksError:
+                        raised.append(True)
+                    e.prepare()
+                assert raised[0] == raised[1], (log, "out-of-blocks status differs")
+                fused[k] = True
+                if rng.random() < 0.4:      # the instance's preview right away (PrepareNextStep of the reference host)
+                    M = np.linalg.inv(np.asarray(rel, np.float64)); M[:3, 3] += rng.normal(0, 0.03, 3); M = M.astype(np.float32)
+                    t = RENDER_TYPES[rng.integers(len(RENDER_TYPES))]
+                    log.append(("preview", k, int(t)))
+                    cg, dg = gi[k].get_image(t, pose_m=M, want_rgba=True, want_depth=True)
+                    co, do = oi[k].get_image(t, pose_m=M, want_rgba=True, want_depth=True)
+                    assert np.array_equal(dg, do) and np.array_equal(cg, co), (log, "instance preview differs")
+            raised = []
+            for main in (gm, om):
+                main.set_pose_inv_m(T)
+                try:
+                    main.process_frame(); raised.append(False)
+                except OutOfBlocksError:
+                    raised.append(True)
+                main.prepare()
+            assert raised[0] == raised[1], (log, "out-of-blocks status of the map differs")
+            if rng.random() < 0.2:
+                args = (int(rng.choice([1, 3])), int(rng.choice([0, 2])), False)
+                log.append(("decay",) + args)
+                for main in (gm, om):
+                    main.decay(*args)
+            if rng.random() < 0.5:
+                M = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
+                t = RENDER_TYPES[rng.integers(len(RENDER_TYPES))]
+                log.append(("map preview", int(t)))
+                cg, dg = gm.get_image(t, pose_m=M, want_rgba=True, want_depth=True)
+                co, do = om.get_image(t, pose_m=M, want_rgba=True, want_depth=True)
+                assert np.array_equal(dg, do) and np.array_equal(cg, co), (log, "map preview differs")
+            vg, vo = gm.get_view(), om.get_view()
+            assert np.array_equal(vg[0], vo[0]) and np.array_equal(vg[1], vo[1]), (log, "blanked main view differs")
+            assert_scene_equal(gm, om, voxels=False)
+            assert_render_equal(gm, om, skip=("minmax",) if om.get_stats().no_visible_blocks == 0 else ())
+            for k in range(n_inst):
+                if not fused[k]:
+                    continue
+                vg, vo = gi[k].get_view(), oi[k].get_view()
+                assert np.array_equal(vg[0], vo[0]) and np.array_equal(vg[1], vo[1]), (log, f"view of instance {k} differs")
+                assert_scene_equal(gi[k], oi[k], voxels=False)
+                assert_render_equal(gi[k], oi[k], skip=("minmax",) if oi[k].get_stats().no_visible_blocks == 0 else ())
+            keep.clear()
+        assert_scene_equal(gm, om)
+        for k in range(n_inst):
+            assert_scene_equal(gi[k], oi[k])
+    except AssertionError as ex:
+        raise AssertionError(f"host seed {seed}: {W}x{H}, {n_inst} instances, map {map_kw['sdf_local_block_num']} blocks, "
+                             f"instances {inst_kw['sdf_local_block_num']} blocks max_w {inst_kw['max_w']}\ncalls: {log}\n{ex}") from None
+    finally:
+        for e in [gm, om] + gi + oi:
+            e.close()
