@@ -396,3 +396,78 @@ def test_random_host_pipelines_equal_the_oracle(hip_api, monkeypatch, seed):
     finally:
         for e in [gm, om] + gi + oi:
             e.close()
+
+
+def _scene_seeds():
+    spec = os.environ.get("DSR_FUZZ_SCENE_SEEDS")
+    if spec:
+        a, b = spec.split(":")
+        return list(range(int(a), int(b)))
+    return [1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", _scene_seeds())
+def test_random_sharded_scenes_equal_the_oracle(hip_api, seed):
+    """`ShardedScene` — what `bench.py` runs: the volumes of one GPU as a batch (or one by one), renders written straight into the
+    exchange's slots, the composite over the exchange's own target — on the HIP engines against the same class driving the oracle
+    (CPU tensors, the oracle's composite), over a random sequence: jumping poses, detections that come and go (empty layers), steps
+    without a preview, track ids in any order, tint / dimming drawn per step.  The composited preview of every step, bit for bit."""
+    import torch
+    from bench import _gen_frame
+    from dynslam_amd.engine import EngineCore, default_settings, make_calib
+    from dynslam_amd.multigpu import ShardedScene
+    from dynslam_amd.synth import StreetScene
+    from oracle.oracle import OracleEngine, load_api, oracle_settings
+    rng = np.random.default_rng(11000 + seed)
+    W, H = [(256, 80), (320, 96)][rng.integers(2)]
+    has_static = bool(rng.random() < 0.5)
+    n_inst = int(rng.integers(1, 7))
+    n_volumes = n_inst + (1 if has_static else 0)
+    static_kw = dict(voxel_size=0.05, mu=0.2, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                     sdf_local_block_num=40000, hash_bucket_num=0x10000, excess_list_size=0x4000)
+    inst_kw = dict(voxel_size=0.035, mu=1.0, max_w=100, view_frustum_min=0.2, view_frustum_max=30.0,
+                   sdf_local_block_num=7142, hash_bucket_num=int(rng.choice([0x10000, 0x100000])), excess_list_size=0x4000)
+    # (the reference host throws when a volume runs out of blocks, and so does the oracle: exhaustion is the other tests' subject)
+    kinds = {"static": static_kw, "instance": inst_kw, "view": dict(static_kw, sdf_local_block_num=64, hash_bucket_num=64, excess_list_size=64)}
+    sc = StreetScene(W, H, n_instances=n_inst)
+    calib = make_calib(*sc.intrinsics(), W, H)
+    torch.cuda.set_device(0)
+    use_batch = bool(rng.random() < 0.7)
+    sg = ShardedScene(lambda kind: EngineCore(default_settings(**kinds[kind], device=0, sync_status=0), calib), W, H, n_volumes, 1, 0,
+                      torch.device("cuda", 0), None, has_static=has_static, use_batch=use_batch)
+    so = ShardedScene(lambda kind: OracleEngine(oracle_settings(**kinds[kind]), calib, threads=8), W, H, n_volumes, 1, 0, torch.device("cpu"),
+                      None, has_static=has_static)
+    so.exchange.host_api = load_api()
+    frame, log = int(rng.integers(0, 3)), [("static" if has_static else "no static", n_inst, "batch" if use_batch else "loop")]
+    keep = []
+    try:
+        for step in range(int(rng.integers(4, 9))):
+            frame = max(0, frame + int(rng.choice([1, 1, 1, 2, 3, -2])))
+            rgba, d, T, masks = _gen_frame((W, H, frame, n_inst))
+            masks = [m for m in masks if rng.random() < 0.8]        # detections come and go
+            log.append(("frame", frame, [m[0] for m in masks]))
+            keep = [torch.from_numpy(rgba).cuda(), torch.from_numpy(d).cuda(), [torch.from_numpy(np.ascontiguousarray(m[3])).cuda() for m in masks]]
+            dev_masks = [(k, x0, y0, (t.data_ptr(), m.shape[1], m.shape[0]), rel) for (k, x0, y0, m, rel), t in zip(masks, keep[2])]
+            sg.step(keep[0].data_ptr(), keep[1].data_ptr(), T, dev_masks)
+            so.step(rgba, d, T, masks)
+            if rng.random() < 0.25:
+                sg.sync()
+                continue                                             # a step without a preview
+            M = np.linalg.inv(T.astype(np.float64)).astype(np.float32)
+            inst_m = {k: np.linalg.inv(rel.astype(np.float64)).astype(np.float32) for k, _, _, _, rel in masks}
+            ids = rng.permutation(n_inst) * 3 + 1
+            track_ids = {k: int(ids[k]) for k in range(n_inst)}
+            tint, dim = float(rng.choice([1.0, 0.35])), bool(rng.random() < 0.5)
+            log.append(("preview", tint, dim))
+            og = sg.preview(M, inst_m, track_ids, tint_strength=tint, dim_background=dim)
+            oo = so.preview(M, inst_m, track_ids, tint_strength=tint, dim_background=dim)
+            sg.sync(); torch.cuda.synchronize()
+            dg, do = og[1].cpu().numpy(), oo[1].cpu().numpy()
+            cg, co = og[0].cpu().numpy(), oo[0].cpu().numpy()
+            assert np.array_equal(dg, do), (log, f"composited depth differs at {(dg != do).sum()} pixels")
+            assert np.array_equal(cg, co), (log, f"composited colour differs at {(cg != co).any(axis=-1).sum()} pixels")
+    except AssertionError as ex:
+        raise AssertionError(f"scene seed {seed}: {W}x{H}\ncalls: {log}\n{ex}") from None
+    finally:
+        sg.close(); so.close()
