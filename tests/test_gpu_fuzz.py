@@ -112,6 +112,9 @@ def test_random_call_sequences_equal_the_oracle(hip_api, seed):
         if swapping:
             sg, so = g.dump_swap_state(), o.dump_swap_state()
             assert np.array_equal(sg[0], so[0]) and np.array_equal(sg[1], so[1]), log
+        # SaveSceneToMesh of whatever the sequence left (tombstones, exhausted arrays, swapped-out blocks): triangle for triangle
+        tg, to = g.mesh_scene(), o.mesh_scene()
+        assert tg.shape == to.shape and np.array_equal(tg.view(np.uint32), to.view(np.uint32)), (log, f"mesh differs: {tg.shape} vs {to.shape}")
     except AssertionError as ex:
         raise AssertionError(f"seed {seed} kind {kind} {W}x{H} {kw}\ncalls: {log}\n{ex}") from None
     finally:
