@@ -28,6 +28,8 @@ def _seeds():
 
 def _draw_settings(rng):
     W, H = [(256, 80), (320, 96), (251, 83), (192, 64)][rng.integers(4)]
+    if os.environ.get("DSR_FUZZ_SIZE"):   # a soak at another image size, "640x192"
+        W, H = [int(v) for v in os.environ["DSR_FUZZ_SIZE"].split("x")]
     kind = rng.integers(4)
     if os.environ.get("DSR_FUZZ_KIND"):   # a soak of one kind of settings
         kind = int(os.environ["DSR_FUZZ_KIND"])
